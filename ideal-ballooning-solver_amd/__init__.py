@@ -1,0 +1,8 @@
+"""MI355X-native batched ideal-ballooning eigen-solver (hot path of rahulgaur104/ideal-ballooning-solver).
+
+Importable as `ibs_amd` (see ibs_amd.py at the repository root; this directory's name is not a
+valid Python identifier).
+"""
+from ._lib import IbsError, LIB_PATH, MEM_DEVICE, MEM_HOST, SYMBOLS  # noqa: F401
+from .solver import Context, default_context  # noqa: F401
+from .operators import gamma_ball_full, dPdrho_of, uniform_spacing  # noqa: F401

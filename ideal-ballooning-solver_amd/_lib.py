@@ -1,0 +1,67 @@
+"""ctypes binding of lib/libibs_hip.so (C ABI: include/ibs.h).
+
+There is NO CPU fallback: if the HIP library is missing or cannot be loaded this module raises,
+and every compute call raises when no GPU/context is available.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libibs_hip.so")
+
+MEM_DEVICE = 0
+MEM_HOST = 1
+
+# every symbol include/ibs.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_D = C.c_double
+_I32 = C.c_int32
+_I64 = C.c_int64
+SYMBOLS = {
+    "ibs_version": (C.c_int, []),
+    "ibs_last_error": (C.c_char_p, []),
+    "ibs_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "ibs_destroy": (C.c_int, [_P]),
+    "ibs_set_stream": (C.c_int, [_P, _P]),
+    "ibs_synchronize": (C.c_int, [_P]),
+    "ibs_device_count": (C.c_int, []),
+    "ibs_solve_gcf_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
+    "ibs_solve_gcf_f32": (C.c_int, [_P, _I64, _I32, C.c_float, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
+    "ibs_gamma_scan_f64": (C.c_int, [_P, _I32, _I32, _I32, _D, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, _I32]),
+    "ibs_sturm_count_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _I64, _P, _P, _I32]),
+    "ibs_surface_argmax_f64": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I32]),
+}
+
+
+class IbsError(RuntimeError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise IbsError(
+            "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or make -C ideal-ballooning-solver_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export the symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = load()
+    return _LIB
+
+
+def check(rc, what):
+    if rc < 0:
+        raise IbsError("%s failed (%d): %s" % (what, rc, lib().ibs_last_error().decode()))
+    return rc

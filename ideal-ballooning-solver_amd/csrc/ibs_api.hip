@@ -1,0 +1,360 @@
+// C-ABI layer of libibs_hip.so (declarations and reference citations: include/ibs.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ibs.h"
+#include "ibs_launch.hpp"
+#include "ibs_wave.hpp"
+
+namespace ibs {
+LaunchTable& launch_table() {
+  static LaunchTable t{};
+  return t;
+}
+}  // namespace ibs
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(IBS_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct ibs_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // staging workspace for IBS_MEM_HOST calls (grown on demand, reused)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  int lds_per_block = 160 * 1024;
+};
+
+namespace {
+
+struct Arena {  // carve device buffers out of the context workspace
+  ibs_ctx* c; size_t off = 0;
+  explicit Arena(ibs_ctx* c_) : c(c_) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = reinterpret_cast<T*>(static_cast<char*>(c->ws) + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
+
+int ensure_ws(ibs_ctx* c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return 0;
+  if (c->ws) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+  HIPCHK(hipMalloc(&c->ws, bytes));
+  c->ws_bytes = bytes;
+  return 0;
+}
+
+int check_grid(int32_t N, double h) {
+  if (N < 66 || N > 64 * ibs::kMaxM + 2) return fail(IBS_ERR_UNSUPPORTED, "N=%d outside [66, %d]", N, 64 * ibs::kMaxM + 2);
+  if ((N & 1) == 0) return fail(IBS_ERR_UNSUPPORTED, "N=%d is even: the reference's Simpson rule is restated for odd N only", N);
+  if (!(h > 0)) return fail(IBS_ERR_ARG, "h must be > 0");
+  return 0;
+}
+int rows_per_lane(int N) { return (N - 2 + 63) / 64; }
+
+__global__ void k_count_status(long n, const int* info, int* out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int bad = (i < n) && ((info[i] >> 16) != 0);
+  unsigned long long m = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+
+// first-argmax per surface (ball_scan.py:283-295 tie rule: lowest row-major index wins)
+__global__ void __launch_bounds__(256) k_surface_argmax(int n_per, const double* gam, int* idx, double* val) {
+  __shared__ double sv[4];
+  __shared__ int si[4];
+  const double* g = gam + (size_t)blockIdx.x * n_per;
+  double best = -1.7976931348623157e308;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n_per; i += blockDim.x) {
+    const double v = g[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const double v2 = __shfl_xor(best, d);
+    const int i2 = __shfl_xor(bi, d);
+    if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+    idx[blockIdx.x] = bi;
+    val[blockIdx.x] = best;
+  }
+}
+
+template <typename T>
+int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, const T* c, const T* f, int64_t ld,
+                   T* lam, T* gam, T* X, T* dX, int32_t* info, int32_t mem,
+                   hipError_t (*const* table)(const ibs::GcfArgs<T>&, hipStream_t)) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_sys < 0 || !g || !c || !f || ld < N) return fail(IBS_ERR_ARG, "bad arguments (n_sys=%lld ld=%lld N=%d)", (long long)n_sys, (long long)ld, N);
+  if (int r = check_grid(N, (double)h)) return r;
+  if (n_sys == 0) return 0;
+  const int M = rows_per_lane(N);
+  if (!table[M]) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t per_wave = (size_t)4 * N * sizeof(T);
+  int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
+  if (wpb > 4) wpb = 4;
+  // keep >= 2 blocks per CU resident when LDS allows it
+  while (wpb > 1 && (size_t)wpb * per_wave * 2 > (size_t)ctx->lds_per_block) --wpb;
+  if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d needs %zu B of LDS per wave", N, per_wave);
+  ibs::GcfArgs<T> a{};
+  a.n_sys = n_sys; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
+  int* d_info = nullptr;
+  int* d_nbad = nullptr;
+  if (mem == IBS_MEM_HOST) {
+    const size_t in_elems = (size_t)n_sys * ld, out_elems = (size_t)n_sys * N;
+    size_t need = 3 * pad256(in_elems * sizeof(T)) + 2 * pad256(n_sys * sizeof(T)) + 2 * pad256(out_elems * sizeof(T)) +
+                  pad256(n_sys * sizeof(int)) + 4096;
+    if (int r = ensure_ws(ctx, need)) return r;
+    Arena ar(ctx);
+    T* dg = ar.take<T>(in_elems); T* dc = ar.take<T>(in_elems); T* df = ar.take<T>(in_elems);
+    T* dlam = ar.take<T>(n_sys); T* dgam = ar.take<T>(n_sys);
+    T* dX_ = X ? ar.take<T>(out_elems) : nullptr; T* ddX = dX ? ar.take<T>(out_elems) : nullptr;
+    d_info = ar.take<int>(n_sys); d_nbad = ar.take<int>(1);
+    HIPCHK(hipMemcpyAsync(dg, g, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dc, c, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(df, f, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    a.g = dg; a.c = dc; a.f = df; a.lam = dlam; a.gam = dgam; a.X = dX_; a.dX = ddX; a.info = d_info;
+    HIPCHK(table[M](a, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
+    if (lam) HIPCHK(hipMemcpyAsync(lam, dlam, n_sys * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    if (gam) HIPCHK(hipMemcpyAsync(gam, dgam, n_sys * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    if (X) HIPCHK(hipMemcpyAsync(X, dX_, out_elems * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    if (dX) HIPCHK(hipMemcpyAsync(dX, ddX, out_elems * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    if (info) HIPCHK(hipMemcpyAsync(info, d_info, n_sys * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    int nbad = 0;
+    HIPCHK(hipMemcpyAsync(&nbad, d_nbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return nbad;
+  }
+  a.g = g; a.c = c; a.f = f; a.lam = lam; a.gam = gam; a.X = X; a.dX = dX; a.info = info;
+  HIPCHK(table[M](a, ctx->stream));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ibs_version(void) { return 100; }
+const char* ibs_last_error(void) { return g_err.c_str(); }
+
+int ibs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ibs_create(ibs_ctx** out, int device_id) {
+  if (!out) return fail(IBS_ERR_ARG, "null output pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail(IBS_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(IBS_ERR_ARG, "device %d out of range (0..%d)", device_id, n - 1);
+  HIPCHK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_id));
+  ibs_ctx* c = new ibs_ctx();
+  c->device = device_id;
+  c->lds_per_block = (int)prop.sharedMemPerBlock > 64 * 1024 ? (int)prop.sharedMemPerBlock : 64 * 1024;
+  if (prop.maxSharedMemoryPerMultiProcessor > (size_t)c->lds_per_block) c->lds_per_block = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (c->lds_per_block > 160 * 1024) c->lds_per_block = 160 * 1024;
+  *out = c;
+  return 0;
+}
+
+int ibs_destroy(ibs_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  if (c->ws) hipFree(c->ws);
+  delete c;
+  return 0;
+}
+
+int ibs_set_stream(ibs_ctx* c, void* s) {
+  if (!c) return fail(IBS_ERR_ARG, "null context");
+  c->stream = reinterpret_cast<hipStream_t>(s);
+  return 0;
+}
+
+int ibs_synchronize(ibs_ctx* c) {
+  if (!c) return fail(IBS_ERR_ARG, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int ibs_solve_gcf_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
+                      const double* f, int64_t ld, double* lam, double* gam, double* X, double* dX,
+                      int32_t* info, int32_t mem) {
+  return solve_gcf_impl<double>(ctx, n_sys, N, h, g, c, f, ld, lam, gam, X, dX, info, mem, ibs::launch_table().gcf_f64);
+}
+
+int ibs_solve_gcf_f32(ibs_ctx* ctx, int64_t n_sys, int32_t N, float h, const float* g, const float* c,
+                      const float* f, int64_t ld, float* lam, float* gam, float* X, float* dX,
+                      int32_t* info, int32_t mem) {
+  return solve_gcf_impl<float>(ctx, n_sys, N, h, g, c, f, ld, lam, gam, X, dX, info, mem, ibs::launch_table().gcf_f32);
+}
+
+int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
+                       const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
+                       const double* gds2, const double* gds21, const double* gds22, int64_t ld,
+                       const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
+                       double* dX, double* dth0, int32_t* info, int32_t mem) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_lines < 0 || n_theta0 < 0 || !bmag || !gradpar || !cvdrift || !cvdrift0 || !gds2 || !gds21 || !gds22 ||
+      !dPdrho || !theta0 || ld < N)
+    return fail(IBS_ERR_ARG, "bad arguments (n_lines=%d n_theta0=%d ld=%lld N=%d)", n_lines, n_theta0, (long long)ld, N);
+  if (int r = check_grid(N, h)) return r;
+  if (n_lines == 0 || n_theta0 == 0) return 0;
+  const int M = rows_per_lane(N);
+  auto fn = ibs::launch_table().scan_f64[M];
+  if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t per_arr = (size_t)N * sizeof(double);
+  if (8 * per_arr > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
+  int wpb = (int)(((size_t)ctx->lds_per_block - 7 * per_arr) / per_arr);
+  const int cap = ibs::scan_max_threads(M) / 64;
+  if (wpb > cap) wpb = cap;
+  if (wpb > n_theta0) wpb = n_theta0;
+  // balance the theta0 values over the blocks of a line
+  const int nblk = (n_theta0 + wpb - 1) / wpb;
+  wpb = (n_theta0 + nblk - 1) / nblk;
+  ibs::ScanArgs<double> a{};
+  a.n_lines = n_lines; a.n_theta0 = n_theta0; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
+  const size_t n_sys = (size_t)n_lines * n_theta0;
+  if (mem == IBS_MEM_HOST) {
+    const size_t in_elems = (size_t)n_lines * ld, out_elems = n_sys * N;
+    size_t need = 7 * pad256(in_elems * 8) + pad256(n_lines * 8) + pad256(n_theta0 * 8) + 3 * pad256(n_sys * 8) +
+                  2 * pad256(out_elems * 8) + pad256(n_sys * 4) + 8192;
+    if (int r = ensure_ws(ctx, need)) return r;
+    Arena ar(ctx);
+    const double* src[7] = {bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22};
+    double* dev[7];
+    for (int k = 0; k < 7; ++k) {
+      dev[k] = ar.take<double>(in_elems);
+      HIPCHK(hipMemcpyAsync(dev[k], src[k], in_elems * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    double* ddP = ar.take<double>(n_lines); double* dt0 = ar.take<double>(n_theta0);
+    HIPCHK(hipMemcpyAsync(ddP, dPdrho, (size_t)n_lines * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dt0, theta0, (size_t)n_theta0 * 8, hipMemcpyHostToDevice, ctx->stream));
+    double* dgam = ar.take<double>(n_sys); double* dlam = ar.take<double>(n_sys); double* dd = ar.take<double>(n_sys);
+    double* dX_ = X ? ar.take<double>(out_elems) : nullptr; double* ddX = dX ? ar.take<double>(out_elems) : nullptr;
+    int* d_info = ar.take<int>(n_sys); int* d_nbad = ar.take<int>(1);
+    a.bmag = dev[0]; a.gradpar = dev[1]; a.cvdrift = dev[2]; a.cvdrift0 = dev[3]; a.gds2 = dev[4]; a.gds21 = dev[5]; a.gds22 = dev[6];
+    a.dPdrho = ddP; a.theta0 = dt0; a.gam = dgam; a.lam = dlam; a.X = dX_; a.dX = ddX; a.dth0 = dth0 ? dd : nullptr; a.info = d_info;
+    HIPCHK(fn(a, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
+    if (gam) HIPCHK(hipMemcpyAsync(gam, dgam, n_sys * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (lam) HIPCHK(hipMemcpyAsync(lam, dlam, n_sys * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (dth0) HIPCHK(hipMemcpyAsync(dth0, dd, n_sys * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (X) HIPCHK(hipMemcpyAsync(X, dX_, out_elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (dX) HIPCHK(hipMemcpyAsync(dX, ddX, out_elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (info) HIPCHK(hipMemcpyAsync(info, d_info, n_sys * 4, hipMemcpyDeviceToHost, ctx->stream));
+    int nbad = 0;
+    HIPCHK(hipMemcpyAsync(&nbad, d_nbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return nbad;
+  }
+  a.bmag = bmag; a.gradpar = gradpar; a.cvdrift = cvdrift; a.cvdrift0 = cvdrift0; a.gds2 = gds2; a.gds21 = gds21; a.gds22 = gds22;
+  a.dPdrho = dPdrho; a.theta0 = theta0; a.gam = gam; a.lam = lam; a.X = X; a.dX = dX; a.dth0 = dth0; a.info = info;
+  HIPCHK(fn(a, ctx->stream));
+  return 0;
+}
+
+int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
+                        const double* f, int64_t ld, const double* shift, int32_t* count, int32_t mem) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_sys < 0 || !g || !c || !f || !shift || !count || ld < N) return fail(IBS_ERR_ARG, "bad arguments");
+  // the Sturm count itself has no Simpson stage: even N is fine here
+  if (N < 66 || N > 64 * ibs::kMaxM + 2) return fail(IBS_ERR_UNSUPPORTED, "N=%d outside [66, %d]", N, 64 * ibs::kMaxM + 2);
+  if (!(h > 0)) return fail(IBS_ERR_ARG, "h must be > 0");
+  if (n_sys == 0) return 0;
+  const int M = rows_per_lane(N);
+  auto fn = ibs::launch_table().sturm_f64[M];
+  if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t per_wave = (size_t)3 * N * sizeof(double);
+  int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d needs %zu B of LDS per wave", N, per_wave);
+  ibs::SturmArgs<double> a{};
+  a.n_sys = n_sys; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
+  if (mem == IBS_MEM_HOST) {
+    const size_t in_elems = (size_t)n_sys * ld;
+    size_t need = 3 * pad256(in_elems * 8) + pad256(n_sys * 8) + pad256(n_sys * 4) + 4096;
+    if (int r = ensure_ws(ctx, need)) return r;
+    Arena ar(ctx);
+    double* dg = ar.take<double>(in_elems); double* dc = ar.take<double>(in_elems); double* df = ar.take<double>(in_elems);
+    double* ds = ar.take<double>(n_sys); int* dcount = ar.take<int>(n_sys);
+    HIPCHK(hipMemcpyAsync(dg, g, in_elems * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dc, c, in_elems * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(df, f, in_elems * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ds, shift, n_sys * 8, hipMemcpyHostToDevice, ctx->stream));
+    a.g = dg; a.c = dc; a.f = df; a.shift = ds; a.count = dcount;
+    HIPCHK(fn(a, ctx->stream));
+    HIPCHK(hipMemcpyAsync(count, dcount, n_sys * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  a.g = g; a.c = c; a.f = f; a.shift = shift; a.count = count;
+  HIPCHK(fn(a, ctx->stream));
+  return 0;
+}
+
+int ibs_surface_argmax_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per, const double* gam, int32_t* idx,
+                           double* val, int32_t mem) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_surf < 0 || n_per <= 0 || !gam || !idx || !val) return fail(IBS_ERR_ARG, "bad arguments");
+  if (n_surf == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (mem == IBS_MEM_HOST) {
+    const size_t ne = (size_t)n_surf * n_per;
+    if (int r = ensure_ws(ctx, pad256(ne * 8) + pad256(n_surf * 8) + pad256(n_surf * 4) + 4096)) return r;
+    Arena ar(ctx);
+    double* dg = ar.take<double>(ne); double* dv = ar.take<double>(n_surf); int* di = ar.take<int>(n_surf);
+    HIPCHK(hipMemcpyAsync(dg, gam, ne * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, dg, di, dv);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(idx, di, (size_t)n_surf * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(val, dv, (size_t)n_surf * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, gam, idx, val);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

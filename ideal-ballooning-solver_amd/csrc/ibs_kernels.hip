@@ -1,0 +1,255 @@
+// Kernels of the ballooning hot path, one translation unit per rows-per-lane value M
+// (compiled with -DIBS_M=<m>; see Makefile).  Launchers are registered in a table the C-ABI
+// layer (ibs_api.hip) dispatches on M = ceil((N-2)/64).
+//
+//  k_solve_gcf   : raw (g, c, f) systems            -> lam, gam, [X, dX]        (config 5 / C1)
+//  k_gamma_scan  : field-line geometry x theta0 grid -> gam, lam, [X, dX, dgam/dtheta0]
+//                  (ball_scan.py:248-275 inner loops, utils.py:1556-1624, utils.py:1666-1680)
+//  k_sturm_count : inertia of T - lam F at given shifts (pins the s-alpha stability test)
+#include "ibs_wave.hpp"
+#include "ibs_launch.hpp"
+
+#ifndef IBS_M
+#error "compile with -DIBS_M=<rows per lane>"
+#endif
+
+namespace ibs {
+
+// ---------------------------------------------------------------- coefficient sources (LDS-backed)
+template <typename T>
+struct SrcGCF {
+  const T* gs; const T* cs; const T* fs;
+  __device__ __forceinline__ T g(int j) const { return gs[j]; }
+  __device__ __forceinline__ T c(int j) const { return cs[j]; }
+  __device__ __forceinline__ T f(int j) const { return fs[j]; }
+};
+
+// geometry of one field line staged in LDS as 7 derived arrays (shared by all theta0 of the line):
+//   A1 = |gradpar|/B, A3 = 1/(|gradpar| B^3), C0 = -dPdrho cvdrift/(|gradpar| B),
+//   C1 = -dPdrho cvdrift0/(|gradpar| B), G0 = gds2, G1 = gds21, G2 = gds22
+// so that for a given theta0 (ball_scan.py:267-268, utils.py:1560-1562)
+//   gds2_fth = G0 + 2 theta0 G1 + theta0^2 G2,  g = A1 gds2_fth,  f = A3 gds2_fth,  c = C0 + theta0 C1
+template <typename T>
+struct SrcGeo {
+  const T* A1; const T* A3; const T* C0; const T* C1; const T* G0; const T* G1; const T* G2;
+  T th0, two_th0, th0sq;
+  __device__ __forceinline__ T gd(int j) const { return G0[j] + two_th0 * G1[j] + th0sq * G2[j]; }
+  __device__ __forceinline__ T g(int j) const { return A1[j] * gd(j); }
+  __device__ __forceinline__ T c(int j) const { return C0[j] + th0 * C1[j]; }
+  __device__ __forceinline__ T f(int j) const { return A3[j] * gd(j); }
+  // d/dtheta0 tangents (utils.py:1669-1673)
+  __device__ __forceinline__ T gdp(int j) const { return T(2) * G1[j] + two_th0 * G2[j]; }
+  __device__ __forceinline__ T g_t(int j) const { return A1[j] * gdp(j); }
+  __device__ __forceinline__ T c_t(int j) const { return C1[j]; }
+  __device__ __forceinline__ T f_t(int j) const { return A3[j] * gdp(j); }
+};
+
+// shared tail: eigenvector -> X in LDS -> growth rate (and optional outputs)
+template <typename T, int M, class Src, bool HF>
+__device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int N, T h, T* Xs,
+                                       T lam, const SolveInfo& inf, long sys, T* lam_out, T* gam_out,
+                                       T* X_out, T* dX_out, T* dth0_out, int* info_out) {
+  const int lane = ws.lane;
+  const int n = N - 2;
+  T x[M];
+  ws.assemble(x);
+  T m = T(0);
+#pragma unroll
+  for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
+  m = uniform(wave_max(m));
+  const int a = WaveSolver<T, M>::rows_start(lane, n);
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+    if ((i < M - 1) || ws.has_last) Xs[a + i + 1] = x[i] / m;      // utils.py:1605
+  if (lane == 0) { Xs[0] = T(0); Xs[N - 1] = T(0); }                // utils.py:1607-1608
+  __syncthreads();
+  const T ih = T(1) / h;
+  T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
+  for (int j = lane; j < N; j += kWave) {
+    const T X = Xs[j];
+    const T dX = fd_derivative(Xs, j, N, ih);
+    const T w = T(simpson_w(j, N));
+    const T X2 = X * X, dX2 = dX * dX;
+    y0 += w * (src.c(j) * X2 - src.g(j) * dX2);                      // utils.py:1618
+    y1 += w * (src.f(j) * X2);                                       // utils.py:1619
+    if constexpr (HF) {
+      hc += w * (src.c_t(j) * X2); hg += w * (src.g_t(j) * dX2); hf += w * (src.f_t(j) * X2);
+    }
+    if (X_out) X_out[sys * N + j] = X;
+    if (dX_out) dX_out[sys * N + j] = dX;
+  }
+  y0 = wave_sum(y0); y1 = wave_sum(y1);
+  const T gam = y0 / y1;                                             // utils.py:1621 (the 1/3 of Simpson cancels)
+  if constexpr (HF) {
+    if (dth0_out) {
+      hc = wave_sum(hc); hg = wave_sum(hg); hf = wave_sum(hf);
+      const T jac = hc / y1 - hg / y1 - gam * hf / y1;               // utils.py:1676-1680
+      if (lane == 0) dth0_out[sys] = jac;
+    }
+  }
+  if (lane == 0) {
+    if (lam_out) lam_out[sys] = lam;
+    if (gam_out) gam_out[sys] = gam;
+    if (info_out) info_out[sys] = inf.iters | (inf.status << 16);
+  }
+}
+
+// ---------------------------------------------------------------- raw (g, c, f) systems
+// block = WPB waves, one system per wave; dynamic LDS = WPB * 4N * sizeof(T)
+template <typename T, int M>
+__global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const T* __restrict__ g,
+                                                   const T* __restrict__ c, const T* __restrict__ f, long ld,
+                                                   T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const long sys = (long)blockIdx.x * wpb + wave;
+  const bool valid = sys < n_sys;
+  const long sysc = valid ? sys : (n_sys - 1);
+  T* gs = smem + (size_t)wave * 4 * N;
+  T* cs = gs + N; T* fs = cs + N; T* Xs = fs + N;
+  const T* gg = g + sysc * ld; const T* cg = c + sysc * ld; const T* fg = f + sysc * ld;
+  for (int j = lane; j < N; j += kWave) { gs[j] = gg[j]; cs[j] = cg[j]; fs[j] = fg[j]; }
+  __syncthreads();
+  SrcGCF<T> src{gs, cs, fs};
+  WaveSolver<T, M> ws;
+  SolveInfo inf{0, 0};
+  const bool bad = ws.setup(src, N, h);
+  T lam = T(0);
+  if (!bad) lam = ws.solve(inf);
+  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  finish<T, M, SrcGCF<T>, false>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                 valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                 nullptr, valid ? info_out : nullptr);
+}
+
+// ---------------------------------------------------------------- geometry-fed theta0 scan
+// grid = (ceil(n_theta0 / wpb), n_lines); block = wpb waves; wave w solves theta0 index blockIdx.x*wpb + w.
+// dynamic LDS = (7 + wpb) * N * sizeof(T).  Geometry arrays are [n_lines][ld].
+template <typename T, int M>
+__global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines, int n_theta0, int N, T h,
+                                                     const T* __restrict__ bmag, const T* __restrict__ gradpar,
+                                                     const T* __restrict__ cvdrift, const T* __restrict__ cvdrift0,
+                                                     const T* __restrict__ gds2, const T* __restrict__ gds21,
+                                                     const T* __restrict__ gds22, long ld,
+                                                     const T* __restrict__ dPdrho, const T* __restrict__ theta0,
+                                                     T* gam_out, T* lam_out, T* X_out, T* dX_out, T* dth0_out,
+                                                     int* info_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int line = blockIdx.y;
+  T* A1 = smem; T* A3 = A1 + N; T* C0 = A3 + N; T* C1 = C0 + N; T* G0 = C1 + N; T* G1 = G0 + N; T* G2 = G1 + N;
+  T* Xs = G2 + N + (size_t)wave * N;
+  {
+    const long off = (long)line * ld;
+    const T mdP = -dPdrho[line];
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const T B = bmag[off + j], gp = xabs(gradpar[off + j]);
+      const T inv = T(1) / (gp * B);                    // 1/(|gradpar| B)
+      A1[j] = gp / B;                                   // g = |gradpar| gds2 / B        (utils.py:1560)
+      A3[j] = inv / (B * B);                            // f = gds2/B^2 /(|gradpar| B)   (utils.py:1562)
+      C0[j] = mdP * cvdrift[off + j] * inv;             // c = -dPdrho cvdrift/(|gradpar| B) (utils.py:1561)
+      C1[j] = mdP * cvdrift0[off + j] * inv;
+      G0[j] = gds2[off + j]; G1[j] = gds21[off + j]; G2[j] = gds22[off + j];
+    }
+  }
+  __syncthreads();
+  const int it0 = blockIdx.x * wpb + wave;
+  const bool valid = it0 < n_theta0;
+  const int it0c = valid ? it0 : (n_theta0 - 1);
+  const T th0 = theta0[it0c];
+  SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
+  WaveSolver<T, M> ws;
+  SolveInfo inf{0, 0};
+  const bool bad = ws.setup(src, N, h);
+  T lam = T(0);
+  if (!bad) lam = ws.solve(inf);
+  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  const long sys = (long)line * n_theta0 + it0c;
+  finish<T, M, SrcGeo<T>, true>(ws, src, N, h, Xs, lam, inf, sys, valid ? lam_out : nullptr,
+                                valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                valid ? dth0_out : nullptr, valid ? info_out : nullptr);
+}
+
+// ---------------------------------------------------------------- Sturm count at given shifts
+template <typename T, int M>
+__global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, const T* __restrict__ g,
+                                                     const T* __restrict__ c, const T* __restrict__ f, long ld,
+                                                     const T* __restrict__ shift, int* count_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const long sys = (long)blockIdx.x * wpb + wave;
+  const bool valid = sys < n_sys;
+  const long sysc = valid ? sys : (n_sys - 1);
+  T* gs = smem + (size_t)wave * 3 * N;
+  T* cs = gs + N; T* fs = cs + N;
+  const T* gg = g + sysc * ld; const T* cg = c + sysc * ld; const T* fg = f + sysc * ld;
+  for (int j = lane; j < N; j += kWave) { gs[j] = gg[j]; cs[j] = cg[j]; fs[j] = fg[j]; }
+  __syncthreads();
+  SrcGCF<T> src{gs, cs, fs};
+  WaveSolver<T, M> ws;
+  ws.setup(src, N, h);
+  const int cnt = ws.sweep(shift[sysc]);
+  if (valid && lane == 0) count_out[sys] = cnt;
+}
+
+// ---------------------------------------------------------------- launchers
+template <typename T>
+static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
+  const int wpb = a.wpb;
+  const size_t lds = (size_t)wpb * 4 * a.N * sizeof(T);
+  const long nblk = (a.n_sys + wpb - 1) / wpb;
+  auto kern = k_solve_gcf<T, IBS_M>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
+                     a.lam, a.gam, a.X, a.dX, a.info);
+  return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
+  const int wpb = a.wpb;
+  const size_t lds = (size_t)(7 + wpb) * a.N * sizeof(T);
+  auto kern = k_gamma_scan<T, IBS_M>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  dim3 grid((a.n_theta0 + wpb - 1) / wpb, a.n_lines);
+  hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
+                     a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
+                     a.dX, a.dth0, a.info);
+  return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_sturm(const SturmArgs<T>& a, hipStream_t st) {
+  const int wpb = a.wpb;
+  const size_t lds = (size_t)wpb * 3 * a.N * sizeof(T);
+  const long nblk = (a.n_sys + wpb - 1) / wpb;
+  auto kern = k_sturm_count<T, IBS_M>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
+                     a.shift, a.count);
+  return hipGetLastError();
+}
+
+#define IBS_CAT2(a, b) a##b
+#define IBS_CAT(a, b) IBS_CAT2(a, b)
+struct IBS_CAT(Registrar, IBS_M) {
+  IBS_CAT(Registrar, IBS_M)() {
+    LaunchTable& t = launch_table();
+    t.gcf_f64[IBS_M] = &launch_gcf<double>;
+    t.scan_f64[IBS_M] = &launch_scan<double>;
+    t.sturm_f64[IBS_M] = &launch_sturm<double>;
+#ifdef IBS_WITH_F32
+    t.gcf_f32[IBS_M] = &launch_gcf<float>;
+#endif
+  }
+};
+static IBS_CAT(Registrar, IBS_M) IBS_CAT(registrar_instance_, IBS_M);
+
+}  // namespace ibs

@@ -1,0 +1,38 @@
+// Launch-argument structs and the per-M launcher table shared by ibs_kernels.hip (one object per
+// rows-per-lane value M) and ibs_api.hip (the C-ABI layer).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ibs {
+
+constexpr int kMaxM = 32;   // rows per lane: N - 2 <= 64 * kMaxM  (N <= 2050)
+
+template <typename T>
+struct GcfArgs {
+  long n_sys; int N; T h; const T* g; const T* c; const T* f; long ld;
+  T* lam; T* gam; T* X; T* dX; int* info; int wpb;
+};
+template <typename T>
+struct ScanArgs {
+  int n_lines, n_theta0, N; T h;
+  const T *bmag, *gradpar, *cvdrift, *cvdrift0, *gds2, *gds21, *gds22; long ld;
+  const T *dPdrho, *theta0;
+  T *gam, *lam, *X, *dX, *dth0; int* info; int wpb;
+};
+template <typename T>
+struct SturmArgs {
+  long n_sys; int N; T h; const T* g; const T* c; const T* f; long ld; const T* shift; int* count; int wpb;
+};
+
+struct LaunchTable {
+  hipError_t (*gcf_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
+  hipError_t (*gcf_f32[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);
+  hipError_t (*scan_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
+  hipError_t (*sturm_f64[kMaxM + 1])(const SturmArgs<double>&, hipStream_t);
+};
+LaunchTable& launch_table();
+
+// threads per block the scan kernel is compiled for (register budget: 5M doubles per lane)
+constexpr int scan_max_threads(int M) { return M <= 16 ? 512 : 256; }
+
+}  // namespace ibs

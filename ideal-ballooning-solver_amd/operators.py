@@ -1,0 +1,47 @@
+"""Drop-in operators with the reference's names and signatures (utils.py:1550-1552, 1632).
+
+    from ibs_amd import gamma_ball_full          # instead of `from utils import *` (ball_scan.py:19)
+
+`vguess` and `sigma0` only steer ARPACK upstream (utils.py:1597); the deterministic HIP solver
+accepts and ignores them.  All eigen-work runs on the GPU through libibs_hip.so; the only host
+arithmetic is the elementwise coefficient formulas returned to the caller as (g, c, f).
+"""
+import numpy as np
+
+from .solver import default_context
+from ._lib import IbsError
+
+
+def uniform_spacing(theta, rtol=1e-9):
+    """h of a uniform grid; the reference regrids by np.interp (utils.py:1567-1571), which is the
+    identity on uniform grids.  Non-uniform grids are rejected (not silently mis-solved)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    N = len(theta)
+    h = (theta[-1] - theta[0]) / (N - 1)
+    if np.max(np.abs(np.diff(theta) - h)) > rtol * abs(h) * N:
+        raise IbsError("theta_PEST is not uniform; non-uniform grids are not supported by the HIP path yet")
+    return float(h)
+
+
+def gamma_ball_full(dPdrho, theta_PEST, B, gradpar, cvdrift, gds2, vguess=None, sigma0=0.42, ctx=None):
+    """reference: utils.py:1550-1624.  Returns (gam, X, dX, g, c, f) with the same meaning."""
+    ctx = ctx or default_context()
+    h = uniform_spacing(theta_PEST)
+    B = np.asarray(B, dtype=np.float64)
+    gradpar = np.asarray(gradpar, dtype=np.float64)
+    cvdrift = np.asarray(cvdrift, dtype=np.float64)
+    gds2 = np.asarray(gds2, dtype=np.float64)
+    N = len(B)
+    z = np.zeros((1, N))
+    r = ctx.gamma_scan(h, B[None], gradpar[None], cvdrift[None], z, gds2[None], z, z,
+                       np.array([float(dPdrho)]), np.zeros(1), want_X=True)
+    gp = np.abs(gradpar)
+    g = gp * gds2 / B                         # utils.py:1560
+    c = -1 * dPdrho * cvdrift * 1 / (gp * B)  # utils.py:1561
+    f = gds2 / B ** 2 * 1 / (gp * B)          # utils.py:1562
+    return float(r["gam"][0, 0]), r["X"][0, 0], r["dX"][0, 0], g, c, f
+
+
+def dPdrho_of(cvdrift, gbdrift, bmag):
+    """ball_scan.py:262 / utils.py:1657"""
+    return -1.0 * 0.5 * np.mean((cvdrift - gbdrift) * bmag ** 2)

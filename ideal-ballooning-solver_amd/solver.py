@@ -1,0 +1,175 @@
+"""Host-side handle on the HIP solver: one Context per process/GPU.
+
+Accepts numpy arrays (host memory: staged by the library) or torch CUDA tensors (device memory:
+zero-copy, asynchronous on the torch current stream).  Mirrors the reference operators'
+argument meaning; see operators.py for the exact drop-in signatures.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MEM_DEVICE, MEM_HOST, IbsError, check
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class _Args:
+    """marshals a homogeneous set of arrays (all numpy or all torch-cuda) to raw pointers"""
+
+    def __init__(self, dtype=np.float64):
+        self.mem = None
+        self.keep = []
+        self.dtype = np.dtype(dtype)
+
+    def _torch_dtype(self):
+        import torch
+        return {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32,
+                np.dtype(np.int32): torch.int32}
+
+    def inp(self, x, dtype=None):
+        dtype = np.dtype(dtype or self.dtype)
+        if _is_torch(x):
+            if not x.is_cuda:
+                raise IbsError("torch tensors must live on the GPU (got %s)" % x.device)
+            td = self._torch_dtype()[dtype]
+            if x.dtype != td or not x.is_contiguous():
+                x = x.to(td).contiguous()
+            self._set(MEM_DEVICE)
+            self.keep.append(x)
+            return C.c_void_p(x.data_ptr())
+        a = np.ascontiguousarray(x, dtype=dtype)
+        self._set(MEM_HOST)
+        self.keep.append(a)
+        return C.c_void_p(a.ctypes.data)
+
+    def out(self, shape, like_torch=None, dtype=None, want=True):
+        dtype = np.dtype(dtype or self.dtype)
+        if not want:
+            return None, C.c_void_p(None)
+        if self.mem == MEM_DEVICE:
+            import torch
+            t = torch.empty(shape, dtype=self._torch_dtype()[dtype], device=like_torch.device)
+            self.keep.append(t)
+            return t, C.c_void_p(t.data_ptr())
+        a = np.empty(shape, dtype=dtype)
+        self.keep.append(a)
+        return a, C.c_void_p(a.ctypes.data)
+
+    def _set(self, mem):
+        if self.mem is None:
+            self.mem = mem
+        elif self.mem != mem:
+            raise IbsError("mixing host (numpy) and device (torch.cuda) arrays in one call is not supported")
+
+
+class Context:
+    def __init__(self, device=0):
+        self._lib = _lib.lib()
+        self._h = C.c_void_p(None)
+        check(self._lib.ibs_create(C.byref(self._h), int(device)), "ibs_create")
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ibs_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    __del__ = close
+
+    def _stream_from_torch(self, ref):
+        import torch
+        self._lib.ibs_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream))
+
+    def synchronize(self):
+        check(self._lib.ibs_synchronize(self._h), "ibs_synchronize")
+
+    # ---- raw (g, c, f) systems --------------------------------------------------------------
+    def solve_gcf(self, h, g, c, f, want_X=False, want_info=False, dtype=np.float64):
+        """g, c, f: (n_sys, N).  Returns dict(lam, gam[, X, dX][, info])."""
+        ar = _Args(dtype)
+        n_sys, N = g.shape
+        pg, pc, pf = ar.inp(g), ar.inp(c), ar.inp(f)
+        ref = g if ar.mem == MEM_DEVICE else None
+        if ref is not None:
+            self._stream_from_torch(ref)
+        lam, plam = ar.out((n_sys,), ref)
+        gam, pgam = ar.out((n_sys,), ref)
+        X, pX = ar.out((n_sys, N), ref, want=want_X)
+        dX, pdX = ar.out((n_sys, N), ref, want=want_X)
+        info, pinfo = ar.out((n_sys,), ref, dtype=np.int32, want=want_info)
+        fn = self._lib.ibs_solve_gcf_f64 if np.dtype(dtype) == np.float64 else self._lib.ibs_solve_gcf_f32
+        hh = float(h)
+        rc = check(fn(self._h, n_sys, N, hh, pg, pc, pf, N, plam, pgam, pX, pdX, pinfo, ar.mem), "ibs_solve_gcf")
+        out = dict(lam=lam, gam=gam, nbad=rc)
+        if want_X:
+            out.update(X=X, dX=dX)
+        if want_info:
+            out.update(info=info)
+        return out
+
+    # ---- geometry x theta0 scan ---------------------------------------------------------------
+    def gamma_scan(self, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, dPdrho, theta0,
+                   want_X=False, want_dtheta0=False, want_info=False):
+        """geometry arrays: (n_lines, N); dPdrho: (n_lines,); theta0: (n_theta0,).
+        Returns dict(gam, lam[, X, dX][, dgam_dtheta0]) shaped (n_lines, n_theta0[, N])."""
+        ar = _Args()
+        n_lines, N = bmag.shape
+        n_t0 = int(theta0.shape[0])
+        ptrs = [ar.inp(a) for a in (bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22)]
+        pdP, pt0 = ar.inp(dPdrho), ar.inp(theta0)
+        ref = bmag if ar.mem == MEM_DEVICE else None
+        if ref is not None:
+            self._stream_from_torch(ref)
+        gam, pgam = ar.out((n_lines, n_t0), ref)
+        lam, plam = ar.out((n_lines, n_t0), ref)
+        X, pX = ar.out((n_lines, n_t0, N), ref, want=want_X)
+        dX, pdX = ar.out((n_lines, n_t0, N), ref, want=want_X)
+        dth, pdth = ar.out((n_lines, n_t0), ref, want=want_dtheta0)
+        info, pinfo = ar.out((n_lines, n_t0), ref, dtype=np.int32, want=want_info)
+        rc = check(self._lib.ibs_gamma_scan_f64(self._h, n_lines, n_t0, N, float(h), *ptrs, N, pdP, pt0,
+                                                pgam, plam, pX, pdX, pdth, pinfo, ar.mem), "ibs_gamma_scan_f64")
+        out = dict(gam=gam, lam=lam, nbad=rc)
+        if want_X:
+            out.update(X=X, dX=dX)
+        if want_dtheta0:
+            out.update(dgam_dtheta0=dth)
+        if want_info:
+            out.update(info=info)
+        return out
+
+    def sturm_count(self, h, g, c, f, shift):
+        ar = _Args()
+        n_sys, N = g.shape
+        pg, pc, pf, ps = ar.inp(g), ar.inp(c), ar.inp(f), ar.inp(shift)
+        ref = g if ar.mem == MEM_DEVICE else None
+        if ref is not None:
+            self._stream_from_torch(ref)
+        cnt, pcnt = ar.out((n_sys,), ref, dtype=np.int32)
+        check(self._lib.ibs_sturm_count_f64(self._h, n_sys, N, float(h), pg, pc, pf, N, ps, pcnt, ar.mem),
+              "ibs_sturm_count_f64")
+        return cnt
+
+    def surface_argmax(self, gam):
+        """gam: (n_surf, n_per_surf) -> (idx int32 (n_surf,), val (n_surf,)); first index on ties (ball_scan.py:283-288)."""
+        ar = _Args()
+        n_surf, n_per = gam.shape
+        pg = ar.inp(gam)
+        ref = gam if ar.mem == MEM_DEVICE else None
+        if ref is not None:
+            self._stream_from_torch(ref)
+        idx, pidx = ar.out((n_surf,), ref, dtype=np.int32)
+        val, pval = ar.out((n_surf,), ref)
+        check(self._lib.ibs_surface_argmax_f64(self._h, n_surf, n_per, pg, pidx, pval, ar.mem), "ibs_surface_argmax_f64")
+        return idx, val
+
+
+_DEFAULT = {}
+
+
+def default_context(device=0):
+    if device not in _DEFAULT:
+        _DEFAULT[device] = Context(device)
+    return _DEFAULT[device]

@@ -1,0 +1,88 @@
+/* libibs_hip.so -- C ABI of the MI355X-native ideal-ballooning hot path.
+ *
+ * Drop-in boundary for the reference's module-level Python operators (there is no FFI upstream:
+ * the operators are reached by `from utils import *`, ball_scan.py:19).  Each entry point names
+ * the reference interface it replaces (paths relative to the reference checkout).  Plain pointers
+ * and sizes only; no exceptions cross the boundary.
+ *
+ * Conventions
+ *   - return value: 0 = ok; < 0 = argument/runtime error (text via ibs_last_error());
+ *     > 0 = number of systems whose info word reports a non-zero status.
+ *   - `mem`: IBS_MEM_DEVICE = all data pointers are device (HBM) pointers, the call is
+ *     asynchronous on the context's stream; IBS_MEM_HOST = host pointers, the library stages
+ *     through its own device workspace and the call returns after the results are back.
+ *   - grids are uniform in theta with N points (N odd, 66 <= N <= 2050) and spacing h;
+ *     arrays of one system/line are contiguous, consecutive systems are `ld` elements apart.
+ *   - optional outputs may be NULL.
+ *   - info word per system: bits 0..15 = fused sweeps used, bits 16.. = status
+ *     (1 = iteration cap hit, 2 = invalid data: non-finite, g <= 0 or f <= 0).
+ */
+#ifndef IBS_H
+#define IBS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IBS_MEM_DEVICE 0
+#define IBS_MEM_HOST 1
+
+#define IBS_ERR_ARG (-1)
+#define IBS_ERR_HIP (-2)
+#define IBS_ERR_UNSUPPORTED (-3)
+
+typedef struct ibs_ctx ibs_ctx;
+
+int ibs_version(void);
+const char* ibs_last_error(void);
+
+/* context = device + stream + staging workspace.  One per process/GPU (ball_scan.py runs one
+ * process per MPI rank; here one process per GPU). */
+int ibs_create(ibs_ctx** ctx, int device_id);
+int ibs_destroy(ibs_ctx* ctx);
+/* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
+int ibs_set_stream(ibs_ctx* ctx, void* hip_stream);
+int ibs_synchronize(ibs_ctx* ctx);
+int ibs_device_count(void);
+
+/* Raw (g, c, f) systems -> largest eigenvalue of the tridiagonal pencil and the reference growth rate.
+ * Replaces: utils.py:1574-1624 (the part of gamma_ball_full after the coefficient assembly), batched.
+ *   lam[n_sys]  matrix eigenvalue lam_max(T, F)            (optional)
+ *   gam[n_sys]  Simpson/FD4 Rayleigh quotient (utils.py:1618-1621)  (optional)
+ *   X, dX [n_sys][N]  normalised eigenfunction and its derivative (utils.py:1602-1616) (optional)
+ *   info[n_sys] (optional) */
+int ibs_solve_gcf_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
+                      const double* f, int64_t ld, double* lam, double* gam, double* X, double* dX,
+                      int32_t* info, int32_t mem);
+int ibs_solve_gcf_f32(ibs_ctx* ctx, int64_t n_sys, int32_t N, float h, const float* g, const float* c,
+                      const float* f, int64_t ld, float* lam, float* gam, float* X, float* dX,
+                      int32_t* info, int32_t mem);
+
+/* Field-line geometry x theta0 grid -> growth rates.
+ * Replaces: the inner loops of ball_scan.py:248-275 (theta0 fold :267-268, gamma_ball_full call :269)
+ * and utils.py:1556-1624; with dgam_dtheta0 also utils.py:1666-1680 (Hellmann-Feynman d/dtheta0).
+ *   geometry arrays [n_lines][ld] (first N of each row used): bmag, gradpar (gradpar_theta_pest),
+ *   cvdrift, cvdrift0, gds2, gds21, gds22;  dPdrho[n_lines] (ball_scan.py:262);  theta0[n_theta0].
+ *   outputs are [n_lines][n_theta0] (X, dX: [n_lines][n_theta0][N]). */
+int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
+                       const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
+                       const double* gds2, const double* gds21, const double* gds22, int64_t ld,
+                       const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
+                       double* dX, double* dgam_dtheta0, int32_t* info, int32_t mem);
+
+/* Number of eigenvalues of (T, F) strictly above shift[i] for each system (Sturm sequence).
+ * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0). */
+int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
+                        const double* f, int64_t ld, const double* shift, int32_t* count, int32_t mem);
+
+/* Per-surface reduction of a scan: first (row-major) index of the maximum and its value, the rule of
+ * ball_scan.py:279-295.  gam is [n_surf][n_per_surf]. */
+int ibs_surface_argmax_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per_surf, const double* gam,
+                           int32_t* idx, double* val, int32_t mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBS_H */

@@ -1,0 +1,163 @@
+"""GPU: parity of the HIP path (through the C ABI) with the oracle and the golden vectors.
+FP64 tolerance: |gam_HIP - gam_ref| < 1e-8 (BASELINE.json north_star); measured errors are ~1e-12."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ibs_amd
+    return ibs_amd.Context(0)
+
+
+@pytest.fixture(scope="module")
+def bo():
+    from oracle import ballooning_oracle
+    return ballooning_oracle
+
+
+def salpha_batch(bo, N, params):
+    th = bo.theta_grid(N)
+    g = np.empty((len(params), N)); c = np.empty_like(g)
+    for k, (sh, al, t0) in enumerate(params):
+        g[k], c[k] = bo.salpha_gc(th, sh, al, t0)
+    return th, g, c
+
+
+@pytest.mark.parametrize("N", [257, 513, 1025])
+def test_G1_salpha_against_reference_goldens(ctx, bo, N):
+    g1 = np.load(os.path.join(G, "G1_salpha.npz"))
+    sel = g1["params"][:, 0] == N
+    params = g1["params"][sel][:, 1:]
+    th, g, c = salpha_batch(bo, N, params)
+    r = ctx.solve_gcf(th[1] - th[0], g, c, g, want_X=True, want_info=True)
+    assert r["nbad"] == 0
+    assert np.abs(r["gam"] - g1["gam"][sel]).max() < TOL
+    for k, (sh, al, t0) in enumerate(params):
+        key = "X_%d_%g_%g_%g" % (N, sh, al, t0)
+        if key in g1:
+            Xref = g1[key] * np.sign(g1[key][np.argmax(np.abs(g1[key]))])
+            dXref = g1["d" + key] * np.sign(g1[key][np.argmax(np.abs(g1[key]))])
+            assert np.abs(r["X"][k] - Xref).max() < 1e-7
+            assert np.abs(r["dX"][k] - dXref).max() < 1e-6
+        go, lo, Xo, dXo = bo.solve_gcf(th, g[k], c[k], g[k])
+        assert abs(r["lam"][k] - lo) < 1e-10
+        assert abs(r["gam"][k] - go) < 1e-10
+        assert np.abs(r["X"][k] - Xo).max() < 1e-8
+        assert np.abs(r["dX"][k] - dXo).max() < 1e-7
+
+
+@pytest.mark.parametrize("which,N,extent", [(3, 1601, 61), (4, 401, 20)])
+def test_G2_sturm_count_reproduces_reference_stability_test(ctx, bo, which, N, extent):
+    tab = np.load(os.path.join(G, "G2_salpha_stability.npz"))["table"]
+    th = np.linspace(-extent * np.pi, extent * np.pi, N)
+    g = np.empty((len(tab), N)); c = np.empty_like(g)
+    for k, row in enumerate(tab):
+        g[k], c[k] = bo.salpha_gc(th, row[0], row[1], row[2])
+    cnt = ctx.sturm_count(th[1] - th[0], g, c, np.ones_like(g), np.zeros(len(tab)))
+    assert ((cnt > 0).astype(int) == tab[:, which].astype(int)).all()
+
+
+@pytest.mark.parametrize("N", [513, 969, 1025])
+def test_G3_ncsx_scan(ctx, bo, N):
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    geo = g3["geo_%d" % N]
+    th = bo.theta_grid(N)
+    a = [np.ascontiguousarray(geo[:, k, :]) for k in range(7)]
+    r = ctx.gamma_scan(th[1] - th[0], *a, g3["dPdrho_%d" % N], g3["theta0"], want_X=True, want_dtheta0=True)
+    assert r["nbad"] == 0
+    assert np.abs(r["gam"] - g3["gam_tight_%d" % N]).max() < 1e-10     # reference formula, ARPACK converged
+    assert np.abs(r["gam"] - g3["gam_%d" % N]).max() < TOL             # reference as shipped
+    # eigenfunctions + Hellmann-Feynman d/dtheta0 against the oracle (utils.py:1666-1680)
+    for i in (0, len(geo) - 1):
+        bmag, gp, cv, cv0, gd2, gd21, gd22, gb = geo[i]
+        for j, t0 in enumerate(g3["theta0"]):
+            cvf, gdf = bo.fold_theta0(t0, cv, cv0, gd2, gd21, gd22)
+            gam, X, dX, gg, cc, ff = bo.gamma_ball_full(g3["dPdrho_%d" % N][i], th, bmag, gp, cvf, gdf)
+            assert np.abs(r["X"][i, j] - X).max() < 1e-7
+            g_t = np.abs(gp) * (2 * gd21 + 2 * t0 * gd22) / bmag
+            c_t = -g3["dPdrho_%d" % N][i] * cv0 / (np.abs(gp) * bmag)
+            f_t = (2 * gd21 + 2 * t0 * gd22) / bmag ** 2 / (np.abs(gp) * bmag)
+            assert abs(r["dgam_dtheta0"][i, j] - bo.hf_derivative(gam, X, dX, ff, g_t, c_t, f_t)) < 1e-8
+
+
+@pytest.mark.parametrize("N", [257, 513])
+def test_G6_rough_random_eigenvalue(ctx, bo, N):
+    g6 = np.load(os.path.join(G, "G6_random_rough.npz"))
+    gcf = g6["gcf_%d" % N]
+    th = bo.theta_grid(N)
+    r = ctx.solve_gcf(th[1] - th[0], gcf[:, 0], gcf[:, 1], gcf[:, 2], want_info=True)
+    assert r["nbad"] == 0
+    for k in range(len(gcf)):
+        go, lo, _, _ = bo.solve_gcf(th, *gcf[k])
+        assert abs(r["lam"][k] - lo) < 1e-9
+        assert abs(r["gam"][k] - g6["gam_tight_%d" % N][k]) < 1e-7
+
+
+def test_gamma_ball_full_dropin_signature(ctx, bo):
+    import ibs_amd
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    N = 513
+    th = bo.theta_grid(N)
+    bmag, gp, cv, cv0, gd2, gd21, gd22, gb = g3["geo_513"][5]
+    dP = ibs_amd.dPdrho_of(cv, gb, bmag)
+    cvf, gdf = bo.fold_theta0(0.5, cv, cv0, gd2, gd21, gd22)
+    out = ibs_amd.gamma_ball_full(dP, th, bmag, gp, cvf, gdf, bo.vguess(th), 1.0, ctx=ctx)
+    ref = bo.gamma_ball_full(dP, th, bmag, gp, cvf, gdf)
+    assert len(out) == 6 and abs(out[0] - ref[0]) < 1e-10 and abs(out[0] - g3["gam_513"][5, 1]) < TOL
+    for a, b in zip(out[1:], ref[1:]):
+        assert a.shape == (N,) and np.abs(a - b).max() < 1e-7
+
+
+def test_device_pointers_and_ragged_batch(ctx, bo):
+    import torch
+    N = 641                                  # D3D reference grid (ball_scan.py:203)
+    rng = np.random.default_rng(7)
+    params = np.stack([rng.uniform(0.1, 2, 37), rng.uniform(0, 1.2, 37), rng.uniform(0, 1.5, 37)], 1)
+    th, g, c = salpha_batch(bo, N, params)
+    dev = torch.device("cuda:0")
+    r = ctx.solve_gcf(th[1] - th[0], torch.from_numpy(g).to(dev), torch.from_numpy(c).to(dev),
+                      torch.from_numpy(g).to(dev), want_info=True)
+    rh = ctx.solve_gcf(th[1] - th[0], g, c, g)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["gam"].cpu().numpy(), rh["gam"])          # same kernel, same bits
+    for k in range(0, 37, 6):
+        assert abs(rh["gam"][k] - bo.solve_gcf(th, g[k], c[k], g[k])[0]) < 1e-10
+    assert ((r["info"].cpu().numpy() >> 16) == 0).all()
+
+
+def test_surface_argmax_first_tie(ctx):
+    tab = np.array([[0.1, 0.5, 0.5, -1.0], [3.0, 3.0, 1.0, 3.0], [-2.0, -3.0, -2.5, -2.0]])
+    idx, val = ctx.surface_argmax(tab)
+    assert idx.tolist() == [1, 0, 0] and val.tolist() == [0.5, 3.0, -2.0]
+    g5 = np.load(os.path.join(G, "G5_scan_trace.npz"))
+    idx, val = ctx.surface_argmax(g5["gam_table"].reshape(1, -1))
+    assert divmod(int(idx[0]), 15) == tuple(int(v) for v in g5["argmax"])
+
+
+def test_G5_coarse_scan_table(ctx, bo):
+    g5 = np.load(os.path.join(G, "G5_scan_trace.npz"))
+    th = bo.theta_grid(513)
+    a = [np.ascontiguousarray(g5["geo"][:, k, :]) for k in range(7)]
+    r = ctx.gamma_scan(th[1] - th[0], *a, g5["dPdrho"], g5["theta0_scan"])
+    assert r["gam"].shape == (24, 15)
+    assert np.abs(r["gam"] - g5["gam_table"]).max() < TOL
+    idx, val = ctx.surface_argmax(r["gam"].reshape(1, -1))
+    assert divmod(int(idx[0]), 15) == tuple(int(v) for v in g5["argmax"])
+
+
+def test_rejects_unsupported_grids(ctx):
+    import ibs_amd
+    for N in (512, 33, 4099):
+        z = np.ones((2, N))
+        with pytest.raises(ibs_amd.IbsError):
+            ctx.solve_gcf(0.1, z, z, z)
+    r = ctx.solve_gcf(0.1, -np.ones((1, 257)), np.ones((1, 257)), np.ones((1, 257)), want_info=True)
+    assert r["nbad"] == 1 and (r["info"][0] >> 16) == 2
