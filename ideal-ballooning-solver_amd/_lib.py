@@ -38,12 +38,32 @@ class IbsError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """libibs_hip.so carries no DT_NEEDED on libamdhip64 (csrc/Makefile): the process must hold ONE
+    HIP runtime.  With PyTorch present that is PyTorch's bundled copy (two runtimes in one process
+    cannot both open the GPU); otherwise the ROCm installation's."""
+    cands = []
+    try:
+        import torch
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except ImportError:
+        pass
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root:
+            cands += [os.path.join(root, "lib", "libamdhip64.so.7"), os.path.join(root, "lib", "libamdhip64.so")]
+    for c in cands:
+        if os.path.exists(c):
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+    raise IbsError("no HIP runtime (libamdhip64.so) found; tried %s" % cands)
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise IbsError(
             "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or make -C ideal-ballooning-solver_amd/csrc).  There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    _preload_hip_runtime()
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export the symbol
         fn.restype = res

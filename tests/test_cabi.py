@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
-    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib = _lib.lib()
     names = header_symbols()
     assert len(names) >= 12
     for n in names:
