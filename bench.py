@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the ballooning hot path on MI355X (contract: task statement, section 4).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over one batch: the D3D-shape configuration of
+BASELINE.json (configs[1]): 16 flux surfaces x 8 alpha x 8 theta0 = 1,024 field-line eigen-solves
+on N_zeta=512 (513-point) grids, FP64, geometry resident in HBM.  A step is the geometry-fed scan
+kernel + the per-surface argmax kernel (+ for N>1 one RCCL all-gather of the per-surface maxima).
+Weak scaling: every rank processes its own 16-surface batch.
+
+Prints ONE JSON line on rank 0 (metric/unit from BASELINE.json) with `roofline` (dominant kernel
+k_gamma_scan, HIP-event timed) and `cpu_baseline` (C oracle on the host cores, bounded sample);
+the extra `stress` object is config 5 (raw (g,c,f) systems) where the batch is large enough for a
+roofline figure to mean something.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SURF, N_ALPHA, N_THETA0, NPTS = 16, 8, 8, 513
+
+
+def build_workload(rank, device):
+    """D3D-shape batch from the NCSX_op-derived golden lines (true D3D geometry needs VMEC: SURVEY H6):
+    128 lines = 16 surfaces x 8 alpha, each a golden line with a smooth per-line perturbation."""
+    import torch
+    g3 = np.load(os.path.join(ROOT, "tests", "golden", "G3_ncsx_lines.npz"))
+    geo = g3["geo_513"]                      # (16, 8, 513)
+    nl = N_SURF * N_ALPHA
+    rng = np.random.default_rng(1000 + rank)
+    base = geo[np.arange(nl) % len(geo)].copy()
+    eps = rng.uniform(-0.03, 0.03, size=(nl, 2))
+    base[:, 4:7, :] *= (1 + eps[:, 0])[:, None, None]      # gds2, gds21, gds22
+    base[:, 2:4, :] *= (1 + eps[:, 1])[:, None, None]      # cvdrift, cvdrift0
+    base[:, 7, :] *= (1 + eps[:, 1])[:, None]              # gbdrift (keeps cvdrift-gbdrift consistent)
+    dP = -0.5 * np.mean((base[:, 2] - base[:, 7]) * base[:, 0] ** 2, axis=1)   # ball_scan.py:262
+    theta0 = np.linspace(0.0, 0.5 * np.pi, N_THETA0)                           # ball_scan.py:225
+    h = 8 * np.pi / (NPTS - 1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    geo7 = [t(base[:, k, :]) for k in range(7)]
+    return h, geo7, t(dP), t(theta0), base, dP, theta0
+
+
+def cpu_baseline(h, base, dP, theta0, budget_s=12.0):
+    """C oracle (oracle/ibs_oracle.c, 'port') on the same D3D-shape batch, all host cores."""
+    from oracle import c_oracle as co
+    arrs = [base[:, k, :] for k in range(7)]
+    cores = os.cpu_count() or 1
+    co.gamma_scan(h, *[a[:8] for a in arrs], dP[:8], theta0, nthreads=cores)      # warm the pool
+    n = 0
+    t0 = time.time()
+    used = cores
+    while time.time() - t0 < budget_s:
+        gam, lam, used = co.gamma_scan(h, *arrs, dP, theta0, nthreads=cores)
+        n += gam.size
+    dt = time.time() - t0
+    return dict(value=n / dt, unit="solves/s", cores=int(used), kind="port",
+                sample="%d passes of the same 1,024-solve D3D-shape batch (%.1f s), Sturm bisection + inverse "
+                       "iteration in C/OpenMP" % (n // gam.size, dt)), gam
+
+
+def cpu_reference_cost(h, base, dP, theta0, nsolve=24):
+    """the reference's own formulation (dense (N-2)^2 matrix + ARPACK shift-invert) restated in the oracle, 1 core"""
+    from oracle import ballooning_oracle as bo
+    th = bo.theta_grid(NPTS)
+    vg = bo.vguess(th)
+    t0 = time.time()
+    for k in range(nsolve):
+        line = base[k % len(base)]
+        cv, gd = bo.fold_theta0(theta0[k % len(theta0)], line[2], line[3], line[4], line[5], line[6])
+        bo.gamma_ball_full_dense_arpack(dP[k % len(base)], th, line[0], line[1], cv, gd, vg, 1.0)
+    dt = time.time() - t0
+    return dict(value=nsolve / dt, unit="solves/s", cores=1, kind="reference-formulation restated (dense LU + ARPACK)",
+                sample="%d solves" % nsolve)
+
+
+def stress(ctx, device, n_sys, family, reps=3):
+    """config 5: raw (g, c, f) systems, N_zeta=512, FP64; returns solves/s and the roofline of k_solve_gcf"""
+    import torch
+    N = NPTS
+    th = torch.linspace(-4 * np.pi, 4 * np.pi, N, dtype=torch.float64, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(20240 + 512)
+    u = lambda lo, hi, shape: lo + (hi - lo) * torch.rand(shape, dtype=torch.float64, device=device, generator=gen)
+    if family == "smooth":      # s-alpha coefficients (bishop_ball_s-alpha.py:30-45), f = g
+        sh, al, t0 = u(0.1, 2.0, (n_sys, 1)), u(0.0, 1.2, (n_sys, 1)), u(0.0, np.pi / 2, (n_sys, 1))
+        lam = sh * (th[None] - t0) - al * (torch.sin(th)[None] - torch.sin(t0))
+        g = 1 + lam ** 2
+        c = al * (torch.cos(th)[None] + torch.sin(th)[None] * lam)
+        f = g
+        del lam
+    else:                       # iid per point inside the measured NCSX_op envelopes
+        g = torch.exp(u(np.log(0.01), np.log(50.0), (n_sys, N)))
+        c = u(-2.5, 3.5, (n_sys, N))
+        f = torch.exp(u(np.log(0.2), np.log(3e3), (n_sys, N)))
+    h = 8 * np.pi / (N - 1)
+    r = ctx.solve_gcf(h, g, c, f, want_info=True)                  # warm-up + correctness word
+    torch.cuda.synchronize()
+    nbad = int(((r["info"] >> 16) != 0).sum().item())
+    sweeps = float((r["info"] & 0xffff).double().mean().item())
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        ctx.solve_gcf(h, g, c, f)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    bytes_per = (3 * N + 1) * 8
+    gbs = n_sys * bytes_per / (ms * 1e-3) / 1e9
+    return dict(workload="config 5 raw (g,c,f), %s family, %d systems, N_zeta=512, f64" % (family, n_sys),
+                solves_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms, mean_sweeps=sweeps, nonconverged=nbad,
+                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                              traffic=None, kernel="k_solve_gcf<double,8>", bytes_per_solve=bytes_per))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-stress", action="store_true", help="skip the config-5 stress leg")
+    ap.add_argument("--stress-systems", type=int, default=262144)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ibs_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    ctx = ibs_amd.Context(local)
+
+    h, geo7, dP_d, th0_d, base, dP, theta0 = build_workload(rank, device)
+    plan = ibs_amd.ScanPlan(ctx, h, geo7, dP_d, th0_d, N_SURF)
+    n_solves = N_SURF * N_ALPHA * N_THETA0
+    gathered = torch.empty((world, N_SURF, 2), dtype=torch.float64, device=device) if world > 1 else None
+    local_pack = torch.empty((N_SURF, 2), dtype=torch.float64, device=device)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        plan.scan()
+        if ev is not None:
+            ev[1].record()
+        plan.argmax()
+        if world > 1:       # replaces comm_lead.Gather x3 (ball_scan.py:345-347): (lam_max, flat index) per surface
+            local_pack[:, 0] = plan.best_val
+            local_pack[:, 1] = plan.best_idx.double()
+            dist.all_gather_into_tensor(gathered, local_pack)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    info = plan.info.cpu().numpy()
+    nbad = int(((info >> 16) != 0).sum())
+    sweeps = float((info & 0xffff).mean())
+
+    if rank == 0:
+        bytes_per_solve = (7 * NPTS * 8 + 8) / N_THETA0 + 8            # geometry-fed path
+        alg_bytes = n_solves * bytes_per_solve
+        gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "field-line eigenvalue solves/sec (N_zeta=512)",
+            "value": world * n_solves * args.steps / dt,
+            "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (NCSX_op-derived field-line geometry, perturbed per line)",
+            "config": {"workload": "configs[1] D3D-shape: 16 surfaces x 8 alpha x 8 theta0 = 1024 solves/step/GPU, "
+                                   "N_zeta=512 (513 points), geometry-fed scan + per-surface argmax"
+                                   + (" + RCCL all-gather" if world > 1 else ""),
+                       "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
+                       "nonconverged": nbad},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_gamma_scan<double,8>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "FP64-VALU-issue bound, not HBM bound: see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu:
+            cb, gam_cpu = cpu_baseline(h, base, dP, theta0)
+            out["cpu_baseline"] = cb
+            out["max_abs_dgam_vs_oracle"] = float(np.abs(plan.gam.cpu().numpy() - gam_cpu).max())
+            out["cpu_reference_cost"] = cpu_reference_cost(h, base, dP, theta0)
+        if world == 1 and not args.no_stress:
+            out["stress"] = stress(ctx, device, args.stress_systems, "smooth")
+            out["stress_rough"] = stress(ctx, device, max(args.stress_systems // 4, 1024), "rough")
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,5 +4,5 @@ Importable as `ibs_amd` (see ibs_amd.py at the repository root; this directory's
 valid Python identifier).
 """
 from ._lib import IbsError, LIB_PATH, MEM_DEVICE, MEM_HOST, SYMBOLS  # noqa: F401
-from .solver import Context, default_context  # noqa: F401
+from .solver import Context, ScanPlan, default_context  # noqa: F401
 from .operators import gamma_ball_full, dPdrho_of, uniform_spacing  # noqa: F401

@@ -173,3 +173,55 @@ def default_context(device=0):
     if device not in _DEFAULT:
         _DEFAULT[device] = Context(device)
     return _DEFAULT[device]
+
+
+class ScanPlan:
+    """Pre-marshalled geometry x theta0 scan + per-surface argmax on device-resident tensors: one
+    optimizer iteration's worth of work is two kernel launches and no allocation.
+    (Counterpart of the per-surface body of ball_scan.py:248-295.)
+
+    geometry tensors: (n_lines, N) torch.cuda float64, lines ordered surface-major
+    (n_lines = n_surf * n_alpha).  Results live in .gam (n_lines, n_theta0), .lam, .best_val (n_surf,),
+    .best_idx (n_surf,) -- index into the flattened (alpha, theta0) table of the surface."""
+
+    def __init__(self, ctx, h, geo7, dPdrho, theta0, n_surf, want_dtheta0=False):
+        import torch
+        self.ctx = ctx
+        self.lib = ctx._lib
+        t64 = torch.float64
+        self.geo = [g.to(t64).contiguous() for g in geo7]
+        dev = self.geo[0].device
+        self.dP = dPdrho.to(t64).contiguous()
+        self.t0 = theta0.to(t64).contiguous()
+        n_lines, N = self.geo[0].shape
+        n_t0 = self.t0.shape[0]
+        if n_lines % n_surf:
+            raise IbsError("n_lines=%d is not a multiple of n_surf=%d" % (n_lines, n_surf))
+        self.n_lines, self.N, self.n_t0, self.n_surf = n_lines, N, n_t0, n_surf
+        self.gam = torch.empty((n_lines, n_t0), dtype=t64, device=dev)
+        self.lam = torch.empty((n_lines, n_t0), dtype=t64, device=dev)
+        self.dth0 = torch.empty((n_lines, n_t0), dtype=t64, device=dev) if want_dtheta0 else None
+        self.info = torch.empty((n_lines, n_t0), dtype=torch.int32, device=dev)
+        self.best_val = torch.empty((n_surf,), dtype=t64, device=dev)
+        self.best_idx = torch.empty((n_surf,), dtype=torch.int32, device=dev)
+        ctx._stream_from_torch(self.geo[0])
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+        self._scan_args = (ctx._h, n_lines, n_t0, N, float(h), *[p(g) for g in self.geo], N, p(self.dP), p(self.t0),
+                           p(self.gam), p(self.lam), C.c_void_p(None), C.c_void_p(None), p(self.dth0), p(self.info),
+                           MEM_DEVICE)
+        self._amax_args = (ctx._h, n_surf, (n_lines // n_surf) * n_t0, p(self.gam), p(self.best_idx), p(self.best_val),
+                           MEM_DEVICE)
+
+    def scan(self):
+        rc = self.lib.ibs_gamma_scan_f64(*self._scan_args)
+        if rc < 0:
+            check(rc, "ibs_gamma_scan_f64")
+
+    def argmax(self):
+        rc = self.lib.ibs_surface_argmax_f64(*self._amax_args)
+        if rc < 0:
+            check(rc, "ibs_surface_argmax_f64")
+
+    def __call__(self):
+        self.scan()
+        self.argmax()

@@ -222,3 +222,22 @@ def salpha_unstable(shat, alpha, theta0, N=1601, extent=61):
     g, c = salpha_gc(theta, shat, alpha, theta0)
     d, e, fd, h, gu, cu, fu = assemble(theta, g, c, np.ones(N))
     return int(sturm_count_above(d, e, fd, 0.0) > 0)
+
+
+def gamma_ball_full_dense_arpack(dPdrho, theta_PEST, B, gradpar, cvdrift, gds2, vguess=None, sigma0=0.42):
+    """Faithful-COST restatement of utils.py:1582-1624: materialise the dense (N-2)^2 matrix
+    A = F^-1 T and take the eigenpair nearest sigma0 by ARPACK shift-invert (dense LU inside), as the
+    reference does.  Used only to time what the reference's formulation costs on the GPU box's CPU."""
+    from scipy.sparse.linalg import eigs
+    g, c, f = gcf(dPdrho, B, gradpar, cvdrift, gds2)
+    d, e, fd, h, gu, cu, fu = assemble(theta_PEST, g, c, f)
+    n = len(d)
+    A = np.zeros((n, n))
+    idx = np.arange(n)
+    A[idx, idx] = d / fd
+    A[idx[1:], idx[:-1]] = e[1:n] / fd[1:]
+    A[idx[:-1], idx[1:]] = e[1:n] / fd[:-1]
+    w, v = eigs(A, 1, sigma=sigma0, v0=vguess, tol=5.0e-7, OPpart="r")
+    x = v[:, 0].real
+    gam, X, dX = rayleigh_growth(x, h, gu, cu, fu)
+    return gam, X, dX, gu, cu, fu
