@@ -54,7 +54,7 @@ def cpu_baseline(h, base, dP, theta0, budget_s=12.0):
     """C oracle (oracle/ibs_oracle.c, 'port') on the same D3D-shape batch, all host cores."""
     from oracle import c_oracle as co
     arrs = [base[:, k, :] for k in range(7)]
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share
     co.gamma_scan(h, *[a[:8] for a in arrs], dP[:8], theta0, nthreads=cores)      # warm the pool
     n = 0
     t0 = time.time()

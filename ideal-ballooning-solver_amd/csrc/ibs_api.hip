@@ -41,6 +41,7 @@ struct ibs_ctx {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   int lds_per_block = 160 * 1024;
+  int n_cu = 256;
 };
 
 namespace {
@@ -119,11 +120,11 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   const int M = rows_per_lane(N);
   if (!table[M]) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   HIPCHK(hipSetDevice(ctx->device));
-  const size_t per_wave = (size_t)4 * N * sizeof(T);
+  const size_t per_wave = (size_t)3 * N * sizeof(T);
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
-  // keep >= 2 blocks per CU resident when LDS allows it
-  while (wpb > 1 && (size_t)wpb * per_wave * 2 > (size_t)ctx->lds_per_block) --wpb;
+  // keep >= 3 blocks per CU resident when LDS allows it
+  while (wpb > 1 && (size_t)wpb * per_wave * 3 > (size_t)ctx->lds_per_block) --wpb;
   if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d needs %zu B of LDS per wave", N, per_wave);
   ibs::GcfArgs<T> a{};
   a.n_sys = n_sys; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
@@ -189,6 +190,7 @@ int ibs_create(ibs_ctx** out, int device_id) {
   c->lds_per_block = (int)prop.sharedMemPerBlock > 64 * 1024 ? (int)prop.sharedMemPerBlock : 64 * 1024;
   if (prop.maxSharedMemoryPerMultiProcessor > (size_t)c->lds_per_block) c->lds_per_block = (int)prop.maxSharedMemoryPerMultiProcessor;
   if (c->lds_per_block > 160 * 1024) c->lds_per_block = 160 * 1024;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   *out = c;
   return 0;
 }
@@ -247,6 +249,14 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
   const int cap = ibs::scan_max_threads(M) / 64;
   if (wpb > cap) wpb = cap;
   if (wpb > n_theta0) wpb = n_theta0;
+  // small batches: spread the waves over all CUs (the solver is issue-bound, one wave per SIMD is
+  // the fastest placement) instead of packing a line's theta0 values onto one CU
+  {
+    const long waves = (long)n_lines * n_theta0;
+    long per_blk = waves / ctx->n_cu;
+    if (per_blk < 1) per_blk = 1;
+    if (per_blk < wpb) wpb = (int)per_blk;
+  }
   // balance the theta0 values over the blocks of a line
   const int nblk = (n_theta0 + wpb - 1) / wpb;
   wpb = (n_theta0 + nblk - 1) / nblk;

@@ -95,7 +95,9 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
 }
 
 // ---------------------------------------------------------------- raw (g, c, f) systems
-// block = WPB waves, one system per wave; dynamic LDS = WPB * 4N * sizeof(T)
+// block = WPB waves, one system per wave; dynamic LDS = WPB * 3N * sizeof(T): (g, c, f) staged once
+// through LDS for the chunked register load; afterwards the eigenfunction X reuses f's slot and the
+// growth-rate stage re-reads f (coalesced, L2-resident) from global memory.
 template <typename T, int M>
 __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const T* __restrict__ g,
                                                    const T* __restrict__ c, const T* __restrict__ f, long ld,
@@ -107,8 +109,8 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   const long sys = (long)blockIdx.x * wpb + wave;
   const bool valid = sys < n_sys;
   const long sysc = valid ? sys : (n_sys - 1);
-  T* gs = smem + (size_t)wave * 4 * N;
-  T* cs = gs + N; T* fs = cs + N; T* Xs = fs + N;
+  T* gs = smem + (size_t)wave * 3 * N;
+  T* cs = gs + N; T* fs = cs + N; T* Xs = fs;
   const T* gg = g + sysc * ld; const T* cg = c + sysc * ld; const T* fg = f + sysc * ld;
   for (int j = lane; j < N; j += kWave) { gs[j] = gg[j]; cs[j] = cg[j]; fs[j] = fg[j]; }
   __syncthreads();
@@ -116,9 +118,11 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
   const bool bad = ws.setup(src, N, h);
+  __syncthreads();   // every lane has taken its f chunk: the slot can be reused for X
   T lam = T(0);
   if (!bad) lam = ws.solve(inf);
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  src.fs = fg;       // growth-rate stage: f from global memory
   finish<T, M, SrcGCF<T>, false>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                  valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
                                  nullptr, valid ? info_out : nullptr);
@@ -194,7 +198,7 @@ __global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, con
   SrcGCF<T> src{gs, cs, fs};
   WaveSolver<T, M> ws;
   ws.setup(src, N, h);
-  const int cnt = ws.sweep(shift[sysc]);
+  const int cnt = ws.sweep_fwd(shift[sysc]);
   if (valid && lane == 0) count_out[sys] = cnt;
 }
 
@@ -202,7 +206,7 @@ __global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, con
 template <typename T>
 static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
-  const size_t lds = (size_t)wpb * 4 * a.N * sizeof(T);
+  const size_t lds = (size_t)wpb * 3 * a.N * sizeof(T);
   const long nblk = (a.n_sys + wpb - 1) / wpb;
   auto kern = k_solve_gcf<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

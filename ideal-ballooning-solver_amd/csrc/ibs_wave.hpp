@@ -66,27 +66,37 @@ __device__ __forceinline__ float dpp_t(float old, float src) {
   return __int_as_float(dpp_i<CTRL, ROWMASK>(__float_as_int(old), __float_as_int(src)));
 }
 
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double readlane_t(double v, int l) {
+  return __hiloint2double(readlane_i(__double2hiint(v), l), readlane_i(__double2loint(v), l));
+}
+__device__ __forceinline__ float readlane_t(float v, int l) { return __int_as_float(readlane_i(__float_as_int(v), l)); }
+
+// wave-wide reductions on the VALU (DPP row_shr / row_bcast: no LDS round trips); the result is
+// read from lane 63 into SGPRs, i.e. it is wave-uniform.
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
+  v += dpp_t<0x111, 0xF>(T(0), v);
+  v += dpp_t<0x112, 0xF>(T(0), v);
+  v += dpp_t<0x114, 0xF>(T(0), v);
+  v += dpp_t<0x118, 0xF>(T(0), v);
+  v += dpp_t<0x142, 0xA>(T(0), v);
+  v += dpp_t<0x143, 0xC>(T(0), v);
+  return readlane_t(v, 63);
 }
 template <typename T>
-__device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = xmax(v, __shfl_xor(v, d));
-  return v;
+__device__ __forceinline__ T wave_max(T v) {  // identity for missing lanes: the value itself
+  v = xmax(v, dpp_t<0x111, 0xF>(v, v));
+  v = xmax(v, dpp_t<0x112, 0xF>(v, v));
+  v = xmax(v, dpp_t<0x114, 0xF>(v, v));
+  v = xmax(v, dpp_t<0x118, 0xF>(v, v));
+  v = xmax(v, dpp_t<0x142, 0xA>(v, v));
+  v = xmax(v, dpp_t<0x143, 0xC>(v, v));
+  return readlane_t(v, 63);
 }
 template <typename T>
 __device__ __forceinline__ T uniform(T v) {  // value is already identical in all lanes: make it scalar
-  if constexpr (sizeof(T) == 8) {
-    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-  } else {
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-  }
+  return readlane_t(v, 0);
 }
 
 // ---------------------------------------------------------------- 2x2 transfer matrices with exponent
@@ -103,8 +113,8 @@ __device__ __forceinline__ void renorm(M2<T>& R) {
   R.a = xldexp(R.a, -ex); R.b = xldexp(R.b, -ex); R.c = xldexp(R.c, -ex); R.d = xldexp(R.d, -ex);
   R.e += ex;
 }
-// R = A * B (A applied after B), renormalised
-template <typename T>
+// R = A * B (A applied after B).  NORM: renormalise to max-entry in [0.5, 1)
+template <typename T, bool NORM>
 __device__ __forceinline__ M2<T> mul(const M2<T>& A, const M2<T>& B) {
   M2<T> R;
   R.a = xfma(A.a, B.a, A.b * B.c);
@@ -112,49 +122,67 @@ __device__ __forceinline__ M2<T> mul(const M2<T>& A, const M2<T>& B) {
   R.c = xfma(A.c, B.a, A.d * B.c);
   R.d = xfma(A.c, B.b, A.d * B.d);
   R.e = A.e + B.e;
-  renorm(R);
+  if (NORM) renorm(R);
   return R;
 }
+// neighbour fetch for the scans: lanes without a valid source receive garbage/zero and are masked
+// out by the caller (the product is applied under `if (valid)`), so no identity has to be built.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dppz_i(int src) { return __builtin_amdgcn_update_dpp(0, src, CTRL, ROWMASK, 0xF, true); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dppz_t(double src) {
+  return __hiloint2double(dppz_i<CTRL, ROWMASK>(__double2hiint(src)), dppz_i<CTRL, ROWMASK>(__double2loint(src)));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dppz_t(float src) { return __int_as_float(dppz_i<CTRL, ROWMASK>(__float_as_int(src))); }
 template <typename T, int CTRL, int ROWMASK>
-__device__ __forceinline__ M2<T> dpp_fetch(const M2<T>& s) {  // lanes without a source get the identity
+__device__ __forceinline__ M2<T> dpp_fetch(const M2<T>& s) {
   M2<T> r;
-  r.a = dpp_t<CTRL, ROWMASK>(T(1), s.a);
-  r.b = dpp_t<CTRL, ROWMASK>(T(0), s.b);
-  r.c = dpp_t<CTRL, ROWMASK>(T(0), s.c);
-  r.d = dpp_t<CTRL, ROWMASK>(T(1), s.d);
-  r.e = dpp_i<CTRL, ROWMASK>(0, s.e);
+  r.a = dppz_t<CTRL, ROWMASK>(s.a); r.b = dppz_t<CTRL, ROWMASK>(s.b);
+  r.c = dppz_t<CTRL, ROWMASK>(s.c); r.d = dppz_t<CTRL, ROWMASK>(s.d);
+  r.e = dppz_i<CTRL, ROWMASK>(s.e);
   return r;
 }
 template <typename T>
-__device__ __forceinline__ M2<T> lane_fetch(const M2<T>& s, int src_lane, bool take) {
+__device__ __forceinline__ M2<T> lane_bcast(const M2<T>& s, int src_lane) {  // src_lane is a constant
   M2<T> r;
-  T a = __shfl(s.a, src_lane), b = __shfl(s.b, src_lane), c = __shfl(s.c, src_lane), d = __shfl(s.d, src_lane);
-  int e = __shfl(s.e, src_lane);
-  r.a = take ? a : T(1); r.b = take ? b : T(0); r.c = take ? c : T(0); r.d = take ? d : T(1); r.e = take ? e : 0;
+  r.a = readlane_t(s.a, src_lane); r.b = readlane_t(s.b, src_lane);
+  r.c = readlane_t(s.c, src_lane); r.d = readlane_t(s.d, src_lane);
+  r.e = readlane_i(s.e, src_lane);
   return r;
 }
 
-// inclusive prefix product over lanes:  P_L = A_L * A_{L-1} * ... * A_0
+// inclusive prefix product over lanes:  P_L = A_L * A_{L-1} * ... * A_0.
+// Entries stay in range without renormalising every step: inputs have max-entry < 1, a product of
+// two such matrices is < 2, of four < 8; renormalise every second step.
 template <typename T>
-__device__ __forceinline__ M2<T> scan_fwd(M2<T> P) {
-  P = mul(P, dpp_fetch<T, 0x111, 0xF>(P));  // row_shr:1
-  P = mul(P, dpp_fetch<T, 0x112, 0xF>(P));  // row_shr:2
-  P = mul(P, dpp_fetch<T, 0x114, 0xF>(P));  // row_shr:4
-  P = mul(P, dpp_fetch<T, 0x118, 0xF>(P));  // row_shr:8
-  P = mul(P, dpp_fetch<T, 0x142, 0xA>(P));  // row_bcast:15 -> rows 1,3
-  P = mul(P, dpp_fetch<T, 0x143, 0xC>(P));  // row_bcast:31 -> rows 2,3
+__device__ __forceinline__ M2<T> scan_fwd(M2<T> P, int lane) {
+  const int l16 = lane & 15, row = lane >> 4;
+  { const M2<T> F = dpp_fetch<T, 0x111, 0xF>(P); if (l16 >= 1) P = mul<T, false>(P, F); }   // row_shr:1
+  { const M2<T> F = dpp_fetch<T, 0x112, 0xF>(P); if (l16 >= 2) P = mul<T, true>(P, F); }    // row_shr:2
+  { const M2<T> F = dpp_fetch<T, 0x114, 0xF>(P); if (l16 >= 4) P = mul<T, false>(P, F); }   // row_shr:4
+  { const M2<T> F = dpp_fetch<T, 0x118, 0xF>(P); if (l16 >= 8) P = mul<T, true>(P, F); }    // row_shr:8
+  { const M2<T> F = dpp_fetch<T, 0x142, 0xA>(P); if (row & 1) P = mul<T, false>(P, F); }    // row_bcast:15 -> rows 1,3
+  { const M2<T> F = dpp_fetch<T, 0x143, 0xC>(P); if (row >= 2) P = mul<T, true>(P, F); }    // row_bcast:31 -> rows 2,3
   return P;
 }
 // inclusive suffix product over lanes:  Q_L = B_L * B_{L+1} * ... * B_63
 template <typename T>
 __device__ __forceinline__ M2<T> scan_bwd(M2<T> Q, int lane) {
-  Q = mul(Q, dpp_fetch<T, 0x101, 0xF>(Q));  // row_shl:1
-  Q = mul(Q, dpp_fetch<T, 0x102, 0xF>(Q));  // row_shl:2
-  Q = mul(Q, dpp_fetch<T, 0x104, 0xF>(Q));  // row_shl:4
-  Q = mul(Q, dpp_fetch<T, 0x108, 0xF>(Q));  // row_shl:8
-  const int row = lane >> 4;
-  Q = mul(Q, lane_fetch(Q, (row + 1) << 4, (row & 1) == 0));  // rows 0,2 <- first lane of rows 1,3
-  Q = mul(Q, lane_fetch(Q, 32, row < 2));                      // rows 0,1 <- lane 32 (rows 2+3)
+  const int l16 = lane & 15, row = lane >> 4;
+  { const M2<T> F = dpp_fetch<T, 0x101, 0xF>(Q); if (l16 < 15) Q = mul<T, false>(Q, F); }   // row_shl:1
+  { const M2<T> F = dpp_fetch<T, 0x102, 0xF>(Q); if (l16 < 14) Q = mul<T, true>(Q, F); }    // row_shl:2
+  { const M2<T> F = dpp_fetch<T, 0x104, 0xF>(Q); if (l16 < 12) Q = mul<T, false>(Q, F); }   // row_shl:4
+  { const M2<T> F = dpp_fetch<T, 0x108, 0xF>(Q); if (l16 < 8) Q = mul<T, true>(Q, F); }     // row_shl:8
+  // rows 0,2 <- first lane of rows 1,3 (their row totals); then rows 0,1 <- lane 32 (rows 2+3)
+  {
+    const M2<T> t16 = lane_bcast(Q, 16), t48 = lane_bcast(Q, 48);
+    M2<T> F;
+    F.a = row == 0 ? t16.a : t48.a; F.b = row == 0 ? t16.b : t48.b;
+    F.c = row == 0 ? t16.c : t48.c; F.d = row == 0 ? t16.d : t48.d; F.e = row == 0 ? t16.e : t48.e;
+    if ((row & 1) == 0) Q = mul<T, false>(Q, F);
+  }
+  { const M2<T> F = lane_bcast(Q, 32); if (row < 2) Q = mul<T, true>(Q, F); }
   return Q;
 }
 
@@ -226,8 +254,8 @@ struct WaveSolver {
     kap = sc; ikap = T(1) / sc;
     bad = bad || !(e_first > T(0));
     // wave-level bounds:  lam_max <= max c/f (Gershgorin);  lam_max >= any Rayleigh quotient
-    const T e0 = __shfl(e_first, 0);
-    const T en = __shfl(e_lo, kWave - 1);
+    const T e0 = readlane_t(e_first, 0);
+    const T en = readlane_t(e_lo, kWave - 1);
     const T sc_all = wave_sum(sum_c), sf_all = wave_sum(sum_f);
     normA = uniform(wave_max(vna));
     hi = uniform(wave_max(vhi));
@@ -237,43 +265,26 @@ struct WaveSolver {
     return __any(bad) != 0;
   }
 
-  // one fused forward+backward sweep at shift sig.  Returns the Sturm count (eigenvalues > sig).
-  __device__ __forceinline__ int sweep(T sig) {
-    // ---- pass 1: chunk transfer matrices (two columns each direction)
+  // forward sweep at shift sig (solution from the left end).  Returns the Sturm count (eigenvalues > sig).
+  __device__ __forceinline__ int sweep_fwd(T sig) {
     T fA = T(1), fAp = T(0), fB = T(0), fBp = T(1);
-    T bA = T(1), bAn = T(0), bB = T(0), bBn = T(1);
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-      const int ib = M - 1 - i;
       const T tf = xfma(-sig, Ph[i], D[i]);
-      const T tb = xfma(-sig, Ph[ib], D[ib]);
       if ((i < M - 1) || has_last) {
         const T nA = xfma(-tf, fA, -fAp), nB = xfma(-tf, fB, -fBp);
         fAp = fA; fA = nA; fBp = fB; fB = nB;
       }
-      if ((ib < M - 1) || has_last) {
-        const T nA = xfma(-tb, bA, -bAn), nB = xfma(-tb, bB, -bBn);
-        bAn = bA; bA = nA; bBn = bB; bB = nB;
-      }
     }
-    M2<T> F, B;
-    // forward: (z_0, z_-1) -> (kap z_cnt, z_{cnt-1}/kap)   [hand-over into the next lane's scaling]
+    M2<T> F;
+    // (z_0, z_-1) -> (kap z_cnt, z_{cnt-1}/kap)   [hand-over into the next lane's scaling]
     F.a = fA * kap; F.b = fB * kap; F.c = fAp * ikap; F.d = fBp * ikap; F.e = 0;
     renorm(F);
-    // backward: incoming (p, q) from lane L+1 is first rescaled into this lane's (z_{cnt-1}, z_cnt) = (kap p, q/kap)
-    B.a = bA * kap; B.b = bB * ikap; B.c = bAn * kap; B.d = bBn * ikap; B.e = 0;
-    renorm(B);
-    // ---- wave scans
-    const M2<T> P = scan_fwd(F);
-    const M2<T> Q = scan_bwd(B, lane);
-    // incoming vectors: first column of the neighbour's inclusive product; (1,0) at the two ends
-    T u0 = dpp_t<0x138, 0xF>(T(1), P.a);   // wave_shr:1
-    T um = dpp_t<0x138, 0xF>(T(0), P.c);
+    const M2<T> P = scan_fwd(F, lane);
+    // incoming vector: first column of the left neighbour's inclusive product; (1,0) at the left end
+    const T u0 = dpp_t<0x138, 0xF>(T(1), P.a);   // wave_shr:1
+    const T um = dpp_t<0x138, 0xF>(T(0), P.c);
     Eu = dpp_i<0x138, 0xF>(0, P.e);
-    T wp = dpp_t<0x130, 0xF>(T(1), Q.a);   // wave_shl:1   (p, q) = (z_-1, z_0) of lane L+1
-    T wq = dpp_t<0x130, 0xF>(T(0), Q.c);
-    Ew = dpp_i<0x130, 0xF>(0, Q.e);
-    // ---- pass 2: replay, keep the solutions, count sign changes of the forward solution
     zu_m1 = um;
     T zc = u0, zp = um;
     int count = 0;
@@ -287,6 +298,28 @@ struct WaveSolver {
       count += __popcll(__ballot(flip));
       if (act) { zp = zc; zc = zn; }
     }
+    return count;
+  }
+
+  // backward sweep at shift sig (solution from the right end); fills zw
+  __device__ __forceinline__ void sweep_bwd(T sig) {
+    T bA = T(1), bAn = T(0), bB = T(0), bBn = T(1);
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      const T tb = xfma(-sig, Ph[i], D[i]);
+      if ((i < M - 1) || has_last) {
+        const T nA = xfma(-tb, bA, -bAn), nB = xfma(-tb, bB, -bBn);
+        bAn = bA; bA = nA; bBn = bB; bB = nB;
+      }
+    }
+    M2<T> B;
+    // incoming (p, q) from lane L+1 is first rescaled into this lane's (z_{cnt-1}, z_cnt) = (kap p, q/kap)
+    B.a = bA * kap; B.b = bB * ikap; B.c = bAn * kap; B.d = bBn * ikap; B.e = 0;
+    renorm(B);
+    const M2<T> Q = scan_bwd(B, lane);
+    const T wp = dpp_t<0x130, 0xF>(T(1), Q.a);   // wave_shl:1   (p, q) = (z_-1, z_0) of lane L+1
+    const T wq = dpp_t<0x130, 0xF>(T(0), Q.c);
+    Ew = dpp_i<0x130, 0xF>(0, Q.e);
     T wc = wp * kap, wn = wq * ikap;   // (z_{cnt-1}, z_cnt)
     zw_p1 = wn;
 #pragma unroll
@@ -297,7 +330,12 @@ struct WaveSolver {
       const T z2 = xfma(-t, wc, -wn);
       if (act) { wn = wc; wc = z2; }
     }
-    return count;
+  }
+
+  __device__ __forceinline__ int sweep(T sig) {
+    const int c = sweep_fwd(sig);
+    sweep_bwd(sig);
+    return c;
   }
 
   // twisted estimate from the last sweep.  Returns rho (Rayleigh/Newton update of sig); fills the
@@ -305,42 +343,47 @@ struct WaveSolver {
   T fu, fw;
   int thr;
   __device__ __forceinline__ T twisted(T sig) {
-    T best = T(0), bnum = T(0), bu = T(1), bw = T(1);
+    // k = argmax |u_k w_k| (= argmin |gamma_k|, discrete Wronskian): per-lane candidate first
+    T best = T(0);
     int bi = 0;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-      const T t = xfma(-sig, Ph[i], D[i]);
-      const T uw = zu[i] * zw[i];
-      const T pr = S[i] * S[i] * uw;
-      const T um1 = (i == 0) ? zu_m1 : zu[i > 0 ? i - 1 : 0];
-      const T wp1 = (i == M - 1) ? zw_p1 : zw[i < M - 1 ? i + 1 : M - 1];
-      const T num = xfma(um1, zw[i], xfma(t, uw, wp1 * zu[i]));
-      const bool better = xabs(pr) > xabs(best);
-      best = better ? pr : best; bnum = better ? num : bnum; bi = better ? i : bi;
-      bu = better ? S[i] * zu[i] : bu; bw = better ? S[i] * zw[i] : bw;
+      const T a = xabs(S[i] * S[i] * (zu[i] * zw[i]));
+      const bool better = a > best;
+      best = better ? a : best; bi = better ? i : bi;
     }
-    // wave argmax of |u_k w_k| in (exponent, mantissa) form
-    const T ab = xabs(best);
-    const int ex = fexp(ab);
-    T key = (ab > T(0) && finite_of(ab)) ? T(ex + Eu + Ew) + xldexp(ab, -ex) : -T(1e30);
-    int kl = lane;
+    // wave argmax in (exponent, mantissa) form; the lane id rides in the low 6 mantissa bits
+    const int ex = fexp(best);
+    T key = (best > T(0) && finite_of(best)) ? T(ex + Eu + Ew) + xldexp(best, -ex) : -T(1e30);
+    int Lk;
+    if constexpr (sizeof(T) == 8) {
+      key = __hiloint2double(__double2hiint(key), (__double2loint(key) & ~63) | lane);
+      Lk = __double2loint(wave_max(key)) & 63;
+    } else {
+      key = __int_as_float((__float_as_int(key) & ~63) | lane);
+      Lk = __float_as_int(wave_max(key)) & 63;
+    }
+    const int ik = readlane_i(bi, Lk);
+    // fetch the entries around (Lk, ik): ik is wave-uniform, so this is a scalar branch chain
+    T zu_k = T(1), zw_k = T(1), S_k = T(1), t_k = T(0), um1 = T(0), wp1 = T(0);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const T k2 = __shfl_xor(key, d);
-      const int l2 = __shfl_xor(kl, d);
-      const bool take = (k2 > key) || (k2 == key && l2 < kl);
-      key = take ? k2 : key; kl = take ? l2 : kl;
+    for (int i = 0; i < M; ++i) {
+      if (i == ik) {
+        zu_k = readlane_t(zu[i], Lk); zw_k = readlane_t(zw[i], Lk); S_k = readlane_t(S[i], Lk);
+        t_k = readlane_t(xfma(-sig, Ph[i], D[i]), Lk);
+        um1 = readlane_t(i == 0 ? zu_m1 : zu[i > 0 ? i - 1 : 0], Lk);
+        wp1 = readlane_t(i == M - 1 ? zw_p1 : zw[i < M - 1 ? i + 1 : M - 1], Lk);
+      }
     }
-    const int Lk = __builtin_amdgcn_readfirstlane(kl);
-    const int ik = __shfl(bi, Lk);
-    const T gam_k = __shfl(bnum, Lk) / __shfl(best, Lk);
-    const T uk = __shfl(bu, Lk), wk = __shfl(bw, Lk);
-    const int Euk = __shfl(Eu, Lk), Ewk = __shfl(Ew, Lk);
+    const T uw = zu_k * zw_k;
+    const T num = xfma(um1, zw_k, xfma(t_k, uw, wp1 * zu_k));   // row-k residual of the twisted vector (x u_k w_k)
+    const T gam_k = num / (S_k * S_k * uw);
+    const int Euk = readlane_i(Eu, Lk), Ewk = readlane_i(Ew, Lk);
     int du = Eu - Euk, dw = Ew - Ewk;
     du = du > 1000 ? 1000 : (du < -2000 ? -2000 : du);
     dw = dw > 1000 ? 1000 : (dw < -2000 ? -2000 : dw);
-    fu = xldexp(T(1) / uk, du);
-    fw = xldexp(T(1) / wk, dw);
+    fu = xldexp(T(1) / (S_k * zu_k), du);
+    fw = xldexp(T(1) / (S_k * zw_k), dw);
     thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
     T acc = T(0);
 #pragma unroll
@@ -350,7 +393,7 @@ struct WaveSolver {
       if ((i < M - 1) || has_last) acc = xfma(Ph[i] * x, x, acc);
     }
     const T tot = wave_sum(acc);
-    return uniform(sig + gam_k / tot);
+    return sig + gam_k / tot;
   }
 
   // eigenvector entries of this lane's rows (twisted, x_k = 1) from the last sweep/twisted() call
@@ -371,13 +414,14 @@ struct WaveSolver {
     bool done = false;
     constexpr int kMaxIt = 160;
     while (!done && it < kMaxIt) {
-      const int C = sweep(sig);
+      const int C = sweep_fwd(sig);
       ++it;
       if (C == 0) hi = xmin(hi, sig); else lo = xmax(lo, sig);
-      const T rho = twisted(sig);
-      const bool ok = finite_of(rho);
-      const bool tryn = ok && (C == 1 || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej)));
+      const bool want = (C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej));
       bool moved = false;
+      T rho = sig;
+      bool tryn = false;
+      if (want) { sweep_bwd(sig); rho = twisted(sig); tryn = finite_of(rho); }
       if (tryn) {
         const bool acc = (rho > lo) && (rho < hi);
         lo = xmax(lo, rho - tol);
