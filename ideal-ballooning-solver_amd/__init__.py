@@ -5,4 +5,5 @@ valid Python identifier).
 """
 from ._lib import IbsError, LIB_PATH, MEM_DEVICE, MEM_HOST, SYMBOLS  # noqa: F401
 from .solver import Context, ScanPlan, default_context  # noqa: F401
-from .operators import gamma_ball_full, dPdrho_of, uniform_spacing  # noqa: F401
+from .operators import gamma_ball_full, dPdrho_of, uniform_spacing, make_obj_w_grad  # noqa: F401
+from .scan import BallooningScan, shard_surfaces, gather_surfaces, pick_start, append_history, GEO_ORDER  # noqa: F401

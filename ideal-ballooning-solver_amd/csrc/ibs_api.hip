@@ -303,6 +303,59 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
   return 0;
 }
 
+int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const double* geo, int64_t ld,
+                       const double* theta0, double del_alpha, double* val, double* jac, int32_t* info,
+                       int32_t mem) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_pts < 0 || !geo || !theta0 || !val || !jac || ld < N || !(del_alpha > 0)) return fail(IBS_ERR_ARG, "bad arguments");
+  if (int r = check_grid(N, h)) return r;
+  if (n_pts == 0) return 0;
+  const int M = rows_per_lane(N);
+  auto fn = ibs::launch_table().grad_f64[M];
+  if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t per_wave = (size_t)8 * N * sizeof(double);
+  int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
+  {
+    long per_blk = (long)n_pts / ctx->n_cu;
+    if (per_blk < 1) per_blk = 1;
+    if (per_blk < wpb) wpb = (int)per_blk;
+  }
+  ibs::GradArgs<double> a{};
+  a.n_pts = n_pts; a.N = N; a.h = h; a.ld = ld; a.del_alpha = del_alpha; a.wpb = wpb;
+  const size_t geo_elems = (size_t)n_pts * 3 * 8 * ld;
+  const bool host = (mem == IBS_MEM_HOST);
+  size_t need = 3 * pad256((size_t)n_pts * 8) + pad256((size_t)n_pts * 4) + 4096;
+  if (host) need += pad256(geo_elems * 8) + pad256((size_t)n_pts * 8) * 2 + pad256((size_t)n_pts * 16) + 4096;
+  if (int r = ensure_ws(ctx, need)) return r;
+  Arena ar(ctx);
+  a.gam = ar.take<double>(n_pts); a.dalpha = ar.take<double>(n_pts); a.dth0 = ar.take<double>(n_pts);
+  int* d_info = ar.take<int>(n_pts);
+  if (host) {
+    double* dgeo = ar.take<double>(geo_elems); double* dt0 = ar.take<double>(n_pts);
+    double* dval = ar.take<double>(n_pts); double* djac = ar.take<double>((size_t)2 * n_pts);
+    int* d_nbad = ar.take<int>(1);
+    HIPCHK(hipMemcpyAsync(dgeo, geo, geo_elems * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dt0, theta0, (size_t)n_pts * 8, hipMemcpyHostToDevice, ctx->stream));
+    a.geo = dgeo; a.theta0 = dt0; a.val = dval; a.jac = djac; a.info = d_info;
+    HIPCHK(fn(a, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_pts, d_info, d_nbad);
+    HIPCHK(hipMemcpyAsync(val, dval, (size_t)n_pts * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(jac, djac, (size_t)n_pts * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (info) HIPCHK(hipMemcpyAsync(info, d_info, (size_t)n_pts * 4, hipMemcpyDeviceToHost, ctx->stream));
+    int nbad = 0;
+    HIPCHK(hipMemcpyAsync(&nbad, d_nbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return nbad;
+  }
+  a.geo = geo; a.theta0 = theta0; a.val = val; a.jac = jac; a.info = info ? info : d_info;
+  HIPCHK(fn(a, ctx->stream));
+  return 0;
+}
+
 int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
                         const double* f, int64_t ld, const double* shift, int32_t* count, int32_t mem) {
   if (!ctx) return fail(IBS_ERR_ARG, "null context");

@@ -8,6 +8,7 @@
 //  k_sturm_count : inertia of T - lam F at given shifts (pins the s-alpha stability test)
 #include "ibs_wave.hpp"
 #include "ibs_launch.hpp"
+#include <type_traits>
 
 #ifndef IBS_M
 #error "compile with -DIBS_M=<rows per lane>"
@@ -44,11 +45,33 @@ struct SrcGeo {
   __device__ __forceinline__ T f_t(int j) const { return A3[j] * gdp(j); }
 };
 
+struct NoTangent {};
+
+// alpha-tangent of (g, c, f): central difference between the field lines at alpha +- del_alpha/2,
+// each with ITS OWN dPdrho (utils.py:1683-1718); lines are read from global memory.
+template <typename T>
+struct AlphaTangent {
+  const T* l; const T* r; long ld;   // [8][ld]: bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, gbdrift
+  T mdP_l, mdP_r, th0, two_th0, th0sq, inv_da;
+  __device__ __forceinline__ void gcf(const T* p, T mdP, int j, T& g, T& c, T& f) const {
+    const T B = p[j], gp = xabs(p[ld + j]);
+    const T cv = p[2 * ld + j] + th0 * p[3 * ld + j];                                   // utils.py:1692 / 1704
+    const T gd = p[4 * ld + j] + two_th0 * p[5 * ld + j] + th0sq * p[6 * ld + j];     // utils.py:1693 / 1705
+    g = gp * gd / B; c = mdP * cv / (gp * B); f = gd / (B * B) / (gp * B);              // utils.py:1707-1713
+  }
+  __device__ __forceinline__ void at(int j, T& ga, T& ca, T& fa) const {
+    T g1, c1, f1, g2, c2, f2;
+    gcf(r, mdP_r, j, g1, c1, f1); gcf(l, mdP_l, j, g2, c2, f2);
+    ga = (g1 - g2) * inv_da; ca = (c1 - c2) * inv_da; fa = (f1 - f2) * inv_da;         // utils.py:1716-1718
+  }
+};
+
 // shared tail: eigenvector -> X in LDS -> growth rate (and optional outputs)
-template <typename T, int M, class Src, bool HF>
+template <typename T, int M, class Src, bool HF, class Tan = NoTangent>
 __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int N, T h, T* Xs,
                                        T lam, const SolveInfo& inf, long sys, T* lam_out, T* gam_out,
-                                       T* X_out, T* dX_out, T* dth0_out, int* info_out) {
+                                       T* X_out, T* dX_out, T* dth0_out, int* info_out,
+                                       const Tan* tan = nullptr, T* dalpha_out = nullptr) {
   const int lane = ws.lane;
   const int n = N - 2;
   T x[M];
@@ -64,7 +87,7 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
   if (lane == 0) { Xs[0] = T(0); Xs[N - 1] = T(0); }                // utils.py:1607-1608
   __syncthreads();
   const T ih = T(1) / h;
-  T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
+  T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0), ac = T(0), ag = T(0), af = T(0);
   for (int j = lane; j < N; j += kWave) {
     const T X = Xs[j];
     const T dX = fd_derivative(Xs, j, N, ih);
@@ -74,6 +97,11 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
     y1 += w * (src.f(j) * X2);                                       // utils.py:1619
     if constexpr (HF) {
       hc += w * (src.c_t(j) * X2); hg += w * (src.g_t(j) * dX2); hf += w * (src.f_t(j) * X2);
+    }
+    if constexpr (!std::is_same<Tan, NoTangent>::value) {
+      T ga, ca, fa;
+      tan->at(j, ga, ca, fa);
+      ac += w * (ca * X2); ag += w * (ga * dX2); af += w * (fa * X2);
     }
     if (X_out) X_out[sys * N + j] = X;
     if (dX_out) dX_out[sys * N + j] = dX;
@@ -86,6 +114,11 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
       const T jac = hc / y1 - hg / y1 - gam * hf / y1;               // utils.py:1676-1680
       if (lane == 0) dth0_out[sys] = jac;
     }
+  }
+  if constexpr (!std::is_same<Tan, NoTangent>::value) {
+    ac = wave_sum(ac); ag = wave_sum(ag); af = wave_sum(af);
+    const T jac = ac / y1 - ag / y1 - gam * af / y1;                 // utils.py:1721-1725
+    if (lane == 0 && dalpha_out) dalpha_out[sys] = jac;
   }
   if (lane == 0) {
     if (lam_out) lam_out[sys] = lam;
@@ -178,6 +211,63 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
                                 valid ? dth0_out : nullptr, valid ? info_out : nullptr);
 }
 
+
+// ---------------------------------------------------------------- objective + Hellmann-Feynman gradient
+// One wave per (alpha, theta0) evaluation point (utils.py:1632-1728 obj_w_grad given the three field
+// lines alpha-d/2, alpha, alpha+d/2).  geo: [n_pts][3][8][ld] in the order bmag, gradpar, cvdrift,
+// cvdrift0, gds2, gds21, gds22, gbdrift.  out: val[n_pts] = -gam, jac[n_pts][2] = (-dgam/dalpha, -dgam/dtheta0).
+template <typename T>
+__device__ __forceinline__ T line_dPdrho(const T* p, long ld, int N, int lane) {
+  T s = T(0);
+  for (int j = lane; j < N; j += kWave) { const T B = p[j]; s += (p[2 * ld + j] - p[7 * ld + j]) * B * B; }
+  return T(-0.5) * wave_sum(s) / T(N);                                // utils.py:1657 / 1691 / 1703
+}
+template <typename T, int M>
+__global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const T* __restrict__ geo, long ld,
+                                                    const T* __restrict__ theta0, T del_alpha, T* val_out,
+                                                    T* jac_out, T* gam_out, T* dalpha_out, T* dth0_out, int* info_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int pt = blockIdx.x * wpb + wave;
+  const bool valid = pt < n_pts;
+  const int ptc = valid ? pt : (n_pts - 1);
+  T* A1 = smem + (size_t)wave * 8 * N;
+  T* A3 = A1 + N; T* C0 = A3 + N; T* C1 = C0 + N; T* G0 = C1 + N; T* G1 = G0 + N; T* G2 = G1 + N; T* Xs = G2 + N;
+  const T* pl = geo + ((long)ptc * 3 + 0) * 8 * ld;
+  const T* pc = geo + ((long)ptc * 3 + 1) * 8 * ld;
+  const T* pr = geo + ((long)ptc * 3 + 2) * 8 * ld;
+  const T dP_l = line_dPdrho(pl, ld, N, lane), dP_c = line_dPdrho(pc, ld, N, lane), dP_r = line_dPdrho(pr, ld, N, lane);
+  for (int j = lane; j < N; j += kWave) {
+    const T B = pc[j], gp = xabs(pc[ld + j]);
+    const T inv = T(1) / (gp * B);
+    A1[j] = gp / B; A3[j] = inv / (B * B);
+    C0[j] = -dP_c * pc[2 * ld + j] * inv; C1[j] = -dP_c * pc[3 * ld + j] * inv;
+    G0[j] = pc[4 * ld + j]; G1[j] = pc[5 * ld + j]; G2[j] = pc[6 * ld + j];
+  }
+  __syncthreads();
+  const T th0 = theta0[ptc];
+  SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
+  WaveSolver<T, M> ws;
+  SolveInfo inf{0, 0};
+  const bool bad = ws.setup(src, N, h);
+  T lam = T(0);
+  if (!bad) lam = ws.solve(inf);
+  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  AlphaTangent<T> tan{pl, pr, ld, -dP_l, -dP_r, th0, T(2) * th0, th0 * th0, T(1) / del_alpha};
+  // results land in per-point scratch slots of the output arrays, then are folded into (val, jac)
+  finish<T, M, SrcGeo<T>, true, AlphaTangent<T>>(ws, src, N, h, Xs, lam, inf, ptc, nullptr, valid ? gam_out : nullptr,
+                                                 nullptr, nullptr, valid ? dth0_out : nullptr,
+                                                 valid ? info_out : nullptr, &tan, valid ? dalpha_out : nullptr);
+  __syncthreads();
+  if (valid && lane == 0) {
+    val_out[pt] = -gam_out[pt];                                      // utils.py:1728
+    jac_out[2 * pt] = -dalpha_out[pt];
+    jac_out[2 * pt + 1] = -dth0_out[pt];
+  }
+}
+
 // ---------------------------------------------------------------- Sturm count at given shifts
 template <typename T, int M>
 __global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, const T* __restrict__ g,
@@ -241,6 +331,18 @@ static hipError_t launch_sturm(const SturmArgs<T>& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <typename T>
+static hipError_t launch_grad(const GradArgs<T>& a, hipStream_t st) {
+  const int wpb = a.wpb;
+  const size_t lds = (size_t)wpb * 8 * a.N * sizeof(T);
+  auto kern = k_obj_w_grad<T, IBS_M>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((a.n_pts + wpb - 1) / wpb), dim3(wpb * 64), lds, st, a.n_pts, a.N, a.h, a.geo, a.ld,
+                     a.theta0, a.del_alpha, a.val, a.jac, a.gam, a.dalpha, a.dth0, a.info);
+  return hipGetLastError();
+}
+
 #define IBS_CAT2(a, b) a##b
 #define IBS_CAT(a, b) IBS_CAT2(a, b)
 struct IBS_CAT(Registrar, IBS_M) {
@@ -249,6 +351,7 @@ struct IBS_CAT(Registrar, IBS_M) {
     t.gcf_f64[IBS_M] = &launch_gcf<double>;
     t.scan_f64[IBS_M] = &launch_scan<double>;
     t.sturm_f64[IBS_M] = &launch_sturm<double>;
+    t.grad_f64[IBS_M] = &launch_grad<double>;
 #ifdef IBS_WITH_F32
     t.gcf_f32[IBS_M] = &launch_gcf<float>;
 #endif

@@ -24,11 +24,18 @@ struct SturmArgs {
   long n_sys; int N; T h; const T* g; const T* c; const T* f; long ld; const T* shift; int* count; int wpb;
 };
 
+template <typename T>
+struct GradArgs {
+  int n_pts, N; T h; const T* geo; long ld; const T* theta0; T del_alpha;
+  T *val, *jac, *gam, *dalpha, *dth0; int* info; int wpb;
+};
+
 struct LaunchTable {
   hipError_t (*gcf_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
   hipError_t (*gcf_f32[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);
   hipError_t (*scan_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
   hipError_t (*sturm_f64[kMaxM + 1])(const SturmArgs<double>&, hipStream_t);
+  hipError_t (*grad_f64[kMaxM + 1])(const GradArgs<double>&, hipStream_t);
 };
 LaunchTable& launch_table();
 

@@ -45,3 +45,22 @@ def gamma_ball_full(dPdrho, theta_PEST, B, gradpar, cvdrift, gds2, vguess=None, 
 def dPdrho_of(cvdrift, gbdrift, bmag):
     """ball_scan.py:262 / utils.py:1657"""
     return -1.0 * 0.5 * np.mean((cvdrift - gbdrift) * bmag ** 2)
+
+
+def make_obj_w_grad(fieldlines, ctx=None, del_alpha=0.004):
+    """Factory for a drop-in `obj_w_grad(x0, vs, rho_val, theta, vguess00, sigma00=0.42)` (utils.py:1632).
+
+    `fieldlines(vs, rho_val, alphas, theta)` supplies the geometry exactly as the reference gets it from
+    `vmec_fieldlines(vs, rho_val, alphas, theta1d=theta)` (utils.py:1641-1646) and must return an array
+    (3, 8, N) in scan.GEO_ORDER.  With the reference available:
+        fl = lambda vs, s, al, th: np.stack([[getattr(utils.vmec_fieldlines(vs, s, al, theta1d=th), k)[0][i]
+                                             for k in GEO_ORDER] for i in range(3)])
+    Returns (-gam, array([-dgam/dalpha, -dgam/dtheta0])) like utils.py:1728 (scipy jac=True convention)."""
+    def obj_w_grad(x0, vs, rho_val, theta, vguess00=None, sigma00=0.42):
+        c = ctx or default_context()
+        alpha_val, theta0_val = float(x0[0]), float(x0[1])
+        al = np.array([alpha_val - 0.5 * del_alpha, alpha_val, alpha_val + 0.5 * del_alpha])
+        geo = np.asarray(fieldlines(vs, rho_val, al, theta), dtype=np.float64)
+        val, jac = c.obj_w_grad(uniform_spacing(theta), geo[None], np.array([theta0_val]), del_alpha)
+        return float(val[0]), np.asarray(jac[0], dtype=np.float64)
+    return obj_w_grad

@@ -1,0 +1,135 @@
+"""Per-equilibrium scan driver: the build's counterpart of ball_scan.py:190-386.
+
+One process per GPU.  Surfaces are sharded over ranks (surface r goes to rank r % world, the
+`mpi.group` <-> surface mapping of ball_scan.py:172, 251-252); every rank scans its surfaces on
+its GPU, refines the per-surface maximum, and one all-gather (RCCL on GPUs, gloo in CPU tests)
+replaces the three comm_lead.Gather calls of ball_scan.py:345-347.  No data-path collective
+exists besides that gather.
+
+Geometry is produced on the host by the caller (SIMSOPT/VMEC stay untouched, BASELINE north_star):
+`fieldlines(s, alphas)` must return an array (len(alphas), 8, N) in the order
+bmag, gradpar_theta_pest, cvdrift, cvdrift0, gds2, gds21, gds22, gbdrift -- e.g. a thin wrapper
+around the reference's own utils.vmec_fieldlines (ball_scan.py:251-261).
+"""
+import numpy as np
+
+from ._lib import IbsError
+
+GEO_ORDER = ("bmag", "gradpar_theta_pest", "cvdrift", "cvdrift0", "gds2", "gds21", "gds22", "gbdrift")
+
+
+def shard_surfaces(n_surf, rank, world):
+    """indices of the surfaces owned by `rank` (round-robin)"""
+    return list(range(rank, n_surf, world))
+
+
+def pick_start(gam_table, alpha_scan, theta0_scan):
+    """ball_scan.py:279-295: start point of the refinement from the coarse table (first maximum on ties;
+    an all-zero table starts from (0, 0) with sigma0 = 0.05)."""
+    m = np.max(gam_table)
+    if m == 0.0:
+        return 0.0, 0.0, 0.05, None
+    idx = np.where(gam_table == m)
+    i, j = int(idx[0][0]), int(idx[1][0])
+    return float(alpha_scan[i]), float(theta0_scan[j]), 1.3 * abs(float(gam_table[i, j])) + 0.05, (i, j)
+
+
+def gather_surfaces(local, n_surf, rank, world, dist=None, device=None):
+    """all-gather of per-surface rows.  local: (n_local, k) rows of the surfaces shard_surfaces() lists.
+    Returns (n_surf, k) on every rank (replaces ball_scan.py:345-347)."""
+    local = np.asarray(local, dtype=np.float64)
+    k = local.shape[1]
+    if world == 1:
+        return local.copy()
+    import torch
+    n_max = (n_surf + world - 1) // world
+    pad = torch.full((n_max, k), float("nan"), dtype=torch.float64)
+    pad[: local.shape[0]] = torch.from_numpy(local)
+    if device is not None:
+        pad = pad.to(device)
+    out = torch.empty((world * n_max, k), dtype=torch.float64, device=pad.device)
+    dist.all_gather_into_tensor(out, pad)
+    out = out.cpu().numpy().reshape(world, n_max, k)
+    full = np.empty((n_surf, k))
+    for r in range(world):
+        own = shard_surfaces(n_surf, r, world)
+        full[own] = out[r, : len(own)]
+    return full
+
+
+class BallooningScan:
+    """Coarse (alpha, theta0) scan -> argmax -> L-BFGS-B refinement -> final solve, per surface."""
+
+    def __init__(self, ctx, fieldlines, theta, rho_arr, nalpha=24, ntheta0=15, del_alpha=0.004,
+                 rank=0, world=1, dist=None, gather_device=None):
+        self.ctx = ctx
+        self.fieldlines = fieldlines
+        self.theta = np.asarray(theta, dtype=np.float64)
+        self.h = float((self.theta[-1] - self.theta[0]) / (len(self.theta) - 1))
+        self.rho_arr = np.asarray(rho_arr, dtype=np.float64)               # ball_scan.py:197
+        self.alpha_scan = np.linspace(0, np.pi, nalpha)                    # ball_scan.py:226
+        self.theta0_scan = np.linspace(0.0, 0.5 * np.pi, ntheta0)          # ball_scan.py:225
+        self.del_alpha = del_alpha
+        self.rank, self.world, self.dist, self.gather_device = rank, world, dist, gather_device
+        self.own = shard_surfaces(len(self.rho_arr), rank, world)
+
+    # -- A5: coarse scan of the surfaces this rank owns, one launch
+    def coarse(self):
+        geos = [np.asarray(self.fieldlines(self.rho_arr[k], self.alpha_scan)) for k in self.own]
+        if not geos:
+            return np.zeros((0, len(self.alpha_scan), len(self.theta0_scan)))
+        geo = np.concatenate(geos, axis=0)                                 # (n_own*nalpha, 8, N)
+        dP = -0.5 * np.mean((geo[:, 2] - geo[:, 7]) * geo[:, 0] ** 2, axis=1)   # ball_scan.py:262
+        r = self.ctx.gamma_scan(self.h, *[np.ascontiguousarray(geo[:, k]) for k in range(7)], dP, self.theta0_scan)
+        return np.asarray(r["gam"]).reshape(len(self.own), len(self.alpha_scan), len(self.theta0_scan))
+
+    # -- A6: objective with gradient at one point of one surface (utils.py:1632-1728)
+    def obj_w_grad(self, x, s):
+        a, t0 = float(x[0]), float(x[1])
+        d = self.del_alpha
+        geo = np.asarray(self.fieldlines(s, np.array([a - 0.5 * d, a, a + 0.5 * d])))
+        val, jac = self.ctx.obj_w_grad(self.h, geo[None], np.array([t0]), d)
+        return float(val[0]), np.asarray(jac[0], dtype=np.float64)
+
+    # -- A7: refinement + final solve (ball_scan.py:305-339)
+    def refine(self, s, a0, t0):
+        from scipy.optimize import minimize
+        res = minimize(self.obj_w_grad, x0=(a0, t0), args=(s,), jac=True,
+                       bounds=((0.0, np.pi), (0.0, 0.5 * np.pi)),
+                       options={"ftol": 5.0e-11, "gtol": 2.0e-08, "maxiter": 30})
+        a, t = float(res.x[0]), float(res.x[1])
+        geo = np.asarray(self.fieldlines(s, np.array([a])))[0]
+        dP = -0.5 * np.mean((geo[2] - geo[7]) * geo[0] ** 2)
+        r = self.ctx.gamma_scan(self.h, *[geo[k][None] for k in range(7)], np.array([dP]), np.array([t]))
+        return t, a, float(np.asarray(r["gam"])[0, 0]), res
+
+    def run(self, refine=True):
+        """returns (theta0_arr, alpha_arr, gam_arr), each (nsurfs,), identical on every rank"""
+        tabs = self.coarse()
+        rows = []
+        for k, tab in zip(self.own, tabs):
+            a0, t0, sigma0, ij = pick_start(tab, self.alpha_scan, self.theta0_scan)
+            if refine:
+                t, a, gam, _ = self.refine(self.rho_arr[k], a0, t0)
+            else:
+                t, a, gam = t0, a0, float(np.max(tab))
+            rows.append((t, a, gam))
+        local = np.array(rows, dtype=np.float64).reshape(len(self.own), 3)
+        full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device)
+        return full[:, 0], full[:, 1], full[:, 2]
+
+
+# -- A8 / F4: on-disk history contract of ball_scan.py:359-384 (consumed by sims_runner_*.py:198-199, 300-306)
+def append_history(path, dof_idx, iter0, gam_arr, theta0_arr, alpha_arr):
+    import os
+    out = {}
+    for name, row in (("ball_gam", gam_arr), ("ball_theta0", theta0_arr), ("ball_alpha", alpha_arr)):
+        fn = os.path.join(path, "%s%d.npy" % (name, int(dof_idx)))
+        old = np.load(fn, allow_pickle=True)
+        if iter0 == 0:
+            new = np.delete(np.append(old, row), 0)        # ball_scan.py:369-375: replace the placeholder
+        else:
+            new = np.vstack((old, row))                    # ball_scan.py:376-379
+        np.save(fn, new)
+        out[name] = new
+    return out

@@ -140,6 +140,25 @@ class Context:
             out.update(info=info)
         return out
 
+    def obj_w_grad(self, h, geo, theta0, del_alpha=0.004, want_info=False):
+        """geo: (n_pts, 3, 8, N) -- lines (alpha-d/2, alpha, alpha+d/2) x (bmag, gradpar, cvdrift, cvdrift0,
+        gds2, gds21, gds22, gbdrift); theta0: (n_pts,).  Returns (val (n_pts,), jac (n_pts, 2)) with the
+        sign convention of utils.py:1728: val = -gam, jac = (-dgam/dalpha, -dgam/dtheta0)."""
+        ar = _Args()
+        n_pts, three, eight, N = geo.shape
+        if three != 3 or eight != 8:
+            raise IbsError("geo must be (n_pts, 3, 8, N)")
+        pg, pt = ar.inp(geo), ar.inp(theta0)
+        ref = geo if ar.mem == MEM_DEVICE else None
+        if ref is not None:
+            self._stream_from_torch(ref)
+        val, pval = ar.out((n_pts,), ref)
+        jac, pjac = ar.out((n_pts, 2), ref)
+        info, pinfo = ar.out((n_pts,), ref, dtype=np.int32, want=want_info)
+        check(self._lib.ibs_obj_w_grad_f64(self._h, n_pts, N, float(h), pg, N, pt, float(del_alpha), pval, pjac,
+                                           pinfo, ar.mem), "ibs_obj_w_grad_f64")
+        return (val, jac, info) if want_info else (val, jac)
+
     def sturm_count(self, h, g, c, f, shift):
         ar = _Args()
         n_sys, N = g.shape

@@ -72,6 +72,16 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
                        const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
                        double* dX, double* dgam_dtheta0, int32_t* info, int32_t mem);
 
+/* Objective and Hellmann-Feynman ("adjoint") gradient at n_pts points (alpha, theta0).
+ * Replaces: utils.py:1632-1728 obj_w_grad, given the geometry of the three field lines
+ * (alpha - del_alpha/2, alpha, alpha + del_alpha/2) that utils.py:1641-1646 obtains from vmec_fieldlines.
+ *   geo [n_pts][3][8][ld]: per line bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, gbdrift
+ *   (dPdrho of each line is formed on the device, utils.py:1657/1691/1703);  theta0[n_pts];
+ *   val[n_pts] = -gam;  jac[n_pts][2] = (-dgam/dalpha, -dgam/dtheta0)   (utils.py:1728). */
+int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const double* geo, int64_t ld,
+                       const double* theta0, double del_alpha, double* val, double* jac, int32_t* info,
+                       int32_t mem);
+
 /* Number of eigenvalues of (T, F) strictly above shift[i] for each system (Sturm sequence).
  * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0). */
 int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
