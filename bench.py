@@ -25,6 +25,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
+    (tools/profile_run.py -> tools/pmc_summary.py -> profiles/pmc_current.json); None if absent."""
+    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
+    if not os.path.exists(fn):
+        return None
+    for k, v in json.load(open(fn)).items():
+        if k.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 N_SURF, N_ALPHA, N_THETA0, NPTS = 16, 8, 8, 513
 
@@ -119,7 +131,9 @@ def stress(ctx, device, n_sys, family, reps=3):
     return dict(workload="config 5 raw (g,c,f), %s family, %d systems, N_zeta=512, f64" % (family, n_sys),
                 solves_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms, mean_sweeps=sweeps, nonconverged=nbad,
                 roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                              traffic=None, kernel="k_solve_gcf<double,8>", bytes_per_solve=bytes_per))
+                              traffic=(pmc_traffic("ibs::k_solve_gcf<double") if n_sys == 262144 and family == "smooth"
+                                       else None),
+                              kernel="k_solve_gcf<double,8>", bytes_per_solve=bytes_per))
 
 
 def main():
@@ -207,7 +221,7 @@ def main():
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
                        "nonconverged": nbad},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("ibs::k_gamma_scan<double"),
                          "kernel": "k_gamma_scan<double,8>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "FP64-VALU-issue bound, not HBM bound: see DESIGN.md"},

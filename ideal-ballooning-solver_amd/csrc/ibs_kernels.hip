@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
 }
 
 // ---------------------------------------------------------------- geometry-fed theta0 scan
-// grid = (ceil(n_theta0 / wpb), n_lines); block = wpb waves; wave w solves theta0 index blockIdx.x*wpb + w.
+// grid = n_lines * ceil(n_theta0 / wpb) blocks; block = wpb waves; wave w solves theta0 index part*wpb + w.
 // dynamic LDS = (7 + wpb) * N * sizeof(T).  Geometry arrays are [n_lines][ld].
 template <typename T, int M>
 __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines, int n_theta0, int N, T h,
@@ -177,7 +177,19 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
-  const int line = blockIdx.y;
+  // XCD-aware block -> (line, part) map.  Workgroups are dealt round-robin over the 8 XCDs, so blocks b
+  // and b+8 share an L2: the `nparts` blocks that scan different theta0 of ONE line are placed 8 apart
+  // and the line's geometry is fetched from HBM once per XCD instead of once per block (speed only).
+  const int nparts = (n_theta0 + wpb - 1) / wpb;
+  int line, part;
+  {
+    const int b = blockIdx.x;
+    const int chunk = b / (8 * nparts), r = b - chunk * 8 * nparts;
+    const int lines_here = min(8, n_lines - chunk * 8);
+    line = chunk * 8 + r % lines_here;
+    part = r / lines_here;
+    if (part >= nparts) return;   // cannot happen (r < lines_here*nparts is guaranteed by the grid size)
+  }
   T* A1 = smem; T* A3 = A1 + N; T* C0 = A3 + N; T* C1 = C0 + N; T* G0 = C1 + N; T* G1 = G0 + N; T* G2 = G1 + N;
   T* Xs = G2 + N + (size_t)wave * N;
   {
@@ -194,7 +206,7 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
     }
   }
   __syncthreads();
-  const int it0 = blockIdx.x * wpb + wave;
+  const int it0 = part * wpb + wave;
   const bool valid = it0 < n_theta0;
   const int it0c = valid ? it0 : (n_theta0 - 1);
   const T th0 = theta0[it0c];
@@ -312,7 +324,7 @@ static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   auto kern = k_gamma_scan<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  dim3 grid((a.n_theta0 + wpb - 1) / wpb, a.n_lines);
+  dim3 grid((unsigned)(((a.n_theta0 + wpb - 1) / wpb) * a.n_lines));
   hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
                      a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
                      a.dX, a.dth0, a.info);
