@@ -405,39 +405,59 @@ struct WaveSolver {
     }
   }
 
-  // safeguarded Newton / bisection on the shift.  On return the last sweep was taken at a shift
-  // whose distance to lam_max is below the tolerance, so assemble() gives the eigenvector.
+  // safeguarded Newton / bisection on the shift.  The bracket [lo, hi] is moved by Sturm counts ONLY
+  // (count(lo) >= 1, count(hi) == 0: backward-stable certificates); the Rayleigh/Newton estimate rho of
+  // the twisted vector merely proposes the next shift (in floating point it is not a rigorous bound:
+  // the recurrences are unstable where the solution decays).  The solve ends when the certified bracket
+  // is narrower than 4 tol; near convergence the proposals aim tol to the uncertified side so that two
+  // counts close the bracket.  On return the last sweep (with its twisted vector) was taken inside the
+  // final bracket, so assemble() gives the eigenvector.
+#ifdef IBS_TRACE
+  T* trace = nullptr;   // debug builds only (tools/trace_solve.hip): 5 values per iteration
+#endif
   __device__ __forceinline__ T solve(SolveInfo& inf) {
-    const T tol = T(64) * Eps<T>::v * normA;
+    // f64: 64 ulp of ||A||;  f32: 8 ulp (the counts themselves are only good to ~eps32*||A||)
+    const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
     T sig = hi, rej = -T(1), lam = hi;
     int it = 0;
     bool done = false;
-    constexpr int kMaxIt = 160;
+    constexpr int kMaxIt = 200;
     while (!done && it < kMaxIt) {
       const int C = sweep_fwd(sig);
       ++it;
       if (C == 0) hi = xmin(hi, sig); else lo = xmax(lo, sig);
-      const bool want = (C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej));
+      const bool collapsed = (hi - lo) <= T(4) * tol;
+      const bool want = collapsed || (C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej));
       bool moved = false;
       T rho = sig;
-      bool tryn = false;
-      if (want) { sweep_bwd(sig); rho = twisted(sig); tryn = finite_of(rho); }
-      if (tryn) {
-        const bool acc = (rho > lo) && (rho < hi);
-        lo = xmax(lo, rho - tol);
-        if (xabs(rho - sig) <= tol) { lam = rho; done = true; }
-        else if (acc) { sig = rho; moved = true; }
-        else if (C == 0) rej = hi - lo;
+      bool ok = false;
+      if (want) {
+        sweep_bwd(sig);
+        rho = twisted(sig);
+        ok = finite_of(rho);
       }
-      if (!done && !moved) {
-        if (hi - lo <= tol) {
-          lam = T(0.5) * (lo + hi);
-          sweep(lam); twisted(lam); ++it;
-          done = true;
-        } else {
-          sig = T(0.5) * (lo + hi);
+#ifdef IBS_TRACE
+      if (lane == 0 && trace && it <= 64) { T* q = trace + 5 * (it - 1); q[0] = sig; q[1] = T(C); q[2] = ok ? rho : T(-999); q[3] = lo; q[4] = hi; }
+#endif
+      if (collapsed) {
+        lam = (ok && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi);
+        done = true;
+      } else if (ok) {
+        // near convergence rho is trusted to ~tol: place the missing count certificate tol beyond it
+        const bool near = xabs(rho - sig) <= T(4096) * tol;
+        T nxt = rho;
+        bool have = false;
+        if (near) {
+          if (hi > rho + T(2) * tol) { nxt = rho + tol; have = true; }
+          else if (lo < rho - T(2) * tol) { nxt = rho - tol; have = true; }
+          have = have && (nxt > lo) && (nxt < hi);
+        } else if (rho > lo && rho < hi) {
+          have = true;
         }
+        if (have) { sig = nxt; moved = true; }
+        else if (C == 0 && !near) rej = hi - lo;
       }
+      if (!done && !moved) sig = T(0.5) * (lo + hi);
     }
     inf.iters = it;
     inf.status = done ? 0 : 1;

@@ -198,3 +198,82 @@ def test_driver_on_gpu_matches_oracle_backed_driver(ctx, bo):
     v, j = drop((1.0, 0.4), None, 0.7, th, None, 0.42)
     vo, jo = bo.obj_w_grad_lines(th, 0.4, *fl(0.7, np.array([1.0 - 0.002, 1.0, 1.0 + 0.002])))
     assert abs(v - vo) < 1e-10 and np.abs(j - jo).max() < 1e-8
+
+
+@pytest.mark.parametrize("N", [257, 513, 1025])
+def test_fp32_variant_stated_tolerance(ctx, bo, N):
+    """config 5 FP32: eigenvalue error bounded relative to ||A|| (eps32*||A||), gam loosely"""
+    rng = np.random.default_rng(11)
+    params = np.stack([rng.uniform(0.3, 2, 24), rng.uniform(0.2, 1.2, 24), rng.uniform(0, 1.5, 24)], 1)
+    th, g, c = salpha_batch(bo, N, params)
+    h = th[1] - th[0]
+    r32 = ctx.solve_gcf(h, g.astype(np.float32), c.astype(np.float32), g.astype(np.float32),
+                        want_info=True, dtype=np.float32)
+    r64 = ctx.solve_gcf(h, g, c, g)
+    assert r32["lam"].dtype == np.float32 and ((r32["info"] >> 16) == 0).all()
+    normA = 4.0 / h ** 2 + 4.0                                   # ~ max_j (2 g/h^2 + |c|)/f for f = g
+    err = np.abs(r32["lam"].astype(np.float64) - r64["lam"])
+    assert err.max() < 32 * 1.2e-7 * normA and np.median(err) < 8 * 1.2e-7 * normA    # stated FP32 tolerance
+    assert np.abs(r32["gam"].astype(np.float64) - r64["gam"]).max() < 5e-2
+
+
+def test_large_grid_2049(ctx, bo):
+    """N_zeta = 2048 (rows-per-lane 32)"""
+    N = 2049
+    params = [(1.0, 0.8, 0.0), (0.5, 0.6, 0.3), (1.7, 1.1, 0.1)]
+    th, g, c = salpha_batch(bo, N, params)
+    r = ctx.solve_gcf(th[1] - th[0], g, c, g, want_info=True)
+    assert r["nbad"] == 0
+    for k in range(len(params)):
+        go, lo, _, _ = bo.solve_gcf(th, g[k], c[k], g[k])
+        assert abs(r["gam"][k] - go) < 1e-9 and abs(r["lam"][k] - lo) < 1e-9
+
+
+def test_full_size_stress_properties(ctx):
+    """BASELINE config 5 at scale (2^17 systems, N_zeta = 512), checked through size-independent properties:
+    the Sturm count is 0 just above the returned eigenvalue and exactly 1 just below it; lam is invariant
+    under a common scaling of (g, c) and shifts by s under c -> c + s f."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, N = 1 << 17, 513
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    u = lambda lo, hi, shape: lo + (hi - lo) * torch.rand(shape, dtype=torch.float64, device=dev, generator=gen)
+    g = torch.exp(u(np.log(0.01), np.log(50.0), (n, N)))
+    c = u(-2.5, 3.5, (n, N))
+    f = torch.exp(u(np.log(0.2), np.log(3e3), (n, N)))
+    h = 8 * np.pi / (N - 1)
+    r = ctx.solve_gcf(h, g, c, f, want_info=True)
+    lam = r["lam"]
+    assert int(((r["info"] >> 16) != 0).sum()) == 0
+    e = 0.5 * (g[:, :-1] + g[:, 1:]) / h ** 2
+    d = c[:, 1:-1] - (e[:, :-1] + e[:, 1:])
+    normA = ((d.abs() + e[:, :-1] + e[:, 1:]) / f[:, 1:-1]).amax(dim=1)        # the solver's ||A|| bound
+    eps = 2e-13 * normA              # certified bracket is 256 ulp(||A||) = 5.7e-14 ||A|| wide
+    above = ctx.sturm_count(h, g, c, f, lam + eps)
+    below = ctx.sturm_count(h, g, c, f, lam - eps)
+    # floating-point Sturm counts of rough systems are not perfectly monotone in the shift: allow a few
+    # inconsistent counts, but every such system must still agree with the independent C oracle
+    odd = torch.nonzero((above != 0) | (below < 1)).flatten().cpu().numpy()
+    assert len(odd) <= n // 10000
+    if len(odd):
+        from oracle import c_oracle as co
+        _, lam_c, _ = co.solve_gcf_batch(h, g[odd].cpu().numpy(), c[odd].cpu().numpy(), f[odd].cpu().numpy())
+        assert np.abs(lam[odd].cpu().numpy() - lam_c).max() < 1e-11 * float(normA[odd].max())
+    assert float((below == 1).double().mean()) > 0.999          # near-degenerate pairs are allowed but rare
+    r2 = ctx.solve_gcf(h, 2 * g[:4096], 2 * c[:4096] + 0.25 * 2 * f[:4096], 2 * f[:4096])
+    assert float(((r2["lam"] - (lam[:4096] + 0.25)).abs() / normA[:4096]).max()) < 3e-13   # inside the certified brackets
+
+
+def test_config3_shape_ncsx_1025_tiled(ctx, bo):
+    """NCSX-shape config (N_zeta = 1024, 16 theta0 per line) on tiled golden lines vs the C oracle"""
+    from oracle import c_oracle as co
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    geo = np.tile(g3["geo_1025"], (8, 1, 1))                    # 48 lines
+    geo[:, 4:7] *= (1 + 0.01 * np.arange(len(geo)))[:, None, None] / 1.2
+    dP = -0.5 * np.mean((geo[:, 2] - geo[:, 7]) * geo[:, 0] ** 2, axis=1)
+    th = bo.theta_grid(1025)
+    t0 = np.linspace(0, np.pi / 2, 16)
+    a = [np.ascontiguousarray(geo[:, k]) for k in range(7)]
+    r = ctx.gamma_scan(th[1] - th[0], *a, dP, t0)
+    gam_c, lam_c, _ = co.gamma_scan(th[1] - th[0], *a, dP, t0)
+    assert r["nbad"] == 0 and np.abs(r["gam"] - gam_c).max() < TOL and np.abs(r["lam"] - lam_c).max() < TOL
