@@ -419,6 +419,8 @@ struct WaveSolver {
     // f64: 64 ulp of ||A||;  f32: 8 ulp (the counts themselves are only good to ~eps32*||A||)
     const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
     T sig = hi, rej = -T(1), lam = hi;
+    T off_up = tol, off_dn = tol;   // how far beyond the estimate the next certificate is placed
+    int aimed = 0;                  // +1 / -1: the last proposal was an upper / lower certificate attempt
     int it = 0;
     bool done = false;
     constexpr int kMaxIt = 200;
@@ -426,6 +428,10 @@ struct WaveSolver {
       const int C = sweep_fwd(sig);
       ++it;
       if (C == 0) hi = xmin(hi, sig); else lo = xmax(lo, sig);
+      // a failed certificate attempt means the estimate is off by more than the offset: widen it
+      if (aimed > 0 && C != 0) off_up *= T(2);
+      if (aimed < 0 && C == 0) off_dn *= T(2);
+      aimed = 0;
       const bool collapsed = (hi - lo) <= T(4) * tol;
       const bool want = collapsed || (C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej));
       bool moved = false;
@@ -448,9 +454,11 @@ struct WaveSolver {
         T nxt = rho;
         bool have = false;
         if (near) {
-          if (hi > rho + T(2) * tol) { nxt = rho + tol; have = true; }
-          else if (lo < rho - T(2) * tol) { nxt = rho - tol; have = true; }
+          const T up = xmax(rho, lo), dn = xmin(rho, hi);
+          if (hi > up + T(2) * off_up) { nxt = up + off_up; have = true; aimed = 1; }
+          else if (lo < dn - T(2) * off_dn) { nxt = dn - off_dn; have = true; aimed = -1; }
           have = have && (nxt > lo) && (nxt < hi);
+          if (!have) aimed = 0;
         } else if (rho > lo && rho < hi) {
           have = true;
         }

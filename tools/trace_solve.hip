@@ -20,17 +20,22 @@ __global__ void __launch_bounds__(64) k(int N, double h, const double* g, const 
   if ((threadIdx.x & 63) == 0) { out[0] = lam; out[1] = inf.iters; out[2] = ws.normA; }
 }
 int main(int argc, char** argv) {
-  int N = atoi(argv[1]); double sh = atof(argv[2]), al = atof(argv[3]), t0 = atof(argv[4]);
+  int N = atoi(argv[1]);
   double h = 8 * M_PI / (N - 1);
-  std::vector<double> g(N), c(N);
-  for (int j = 0; j < N; ++j) { double th = -4 * M_PI + j * h; double lam = sh * (th - t0) - al * (sin(th) - sin(t0)); g[j] = 1 + lam * lam; c[j] = al * (cos(th) + sin(th) * lam); }
-  double *dg, *dc, *dt, *dout;
-  hipMalloc(&dg, N * 8); hipMalloc(&dc, N * 8); hipMalloc(&dt, 5 * 64 * 8); hipMalloc(&dout, 64);
+  std::vector<double> g(N), c(N), f(N);
+  if (argc == 3) {   // raw file: g, c, f (3N doubles)
+    FILE* fp = fopen(argv[2], "rb"); fread(g.data(), 8, N, fp); fread(c.data(), 8, N, fp); fread(f.data(), 8, N, fp); fclose(fp);
+  } else {
+    double sh = atof(argv[2]), al = atof(argv[3]), t0 = atof(argv[4]);
+    for (int j = 0; j < N; ++j) { double th = -4 * M_PI + j * h; double lam = sh * (th - t0) - al * (sin(th) - sin(t0)); g[j] = 1 + lam * lam; c[j] = al * (cos(th) + sin(th) * lam); f[j] = g[j]; }
+  }
+  double *dg, *dc, *df, *dt, *dout;
+  hipMalloc(&dg, N * 8); hipMalloc(&dc, N * 8); hipMalloc(&df, N * 8); hipMalloc(&dt, 5 * 64 * 8); hipMalloc(&dout, 64);
   hipMemset(dt, 0, 5 * 64 * 8);
-  hipMemcpy(dg, g.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(dc, c.data(), N * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dg, g.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(dc, c.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(df, f.data(), N * 8, hipMemcpyHostToDevice);
   int M = (N - 2 + 63) / 64;
-  if (M == 16) hipLaunchKernelGGL(k<16>, dim3(1), dim3(64), 0, 0, N, h, dg, dc, dg, dt, dout);
-  else if (M == 8) hipLaunchKernelGGL(k<8>, dim3(1), dim3(64), 0, 0, N, h, dg, dc, dg, dt, dout);
+  if (M == 16) hipLaunchKernelGGL(k<16>, dim3(1), dim3(64), 0, 0, N, h, dg, dc, df, dt, dout);
+  else if (M == 8) hipLaunchKernelGGL(k<8>, dim3(1), dim3(64), 0, 0, N, h, dg, dc, df, dt, dout);
   else { printf("M=%d not built\n", M); return 1; }
   std::vector<double> tr(5 * 64); double out[3];
   hipMemcpy(tr.data(), dt, 5 * 64 * 8, hipMemcpyDeviceToHost); hipMemcpy(out, dout, 24, hipMemcpyDeviceToHost);
