@@ -420,6 +420,7 @@ struct WaveSolver {
     const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
     T sig = hi, rej = -T(1), lam = hi;
     T off_up = tol, off_dn = tol;   // how far beyond the estimate the next certificate is placed
+    T rho_trust = hi;
     int aimed = 0;                  // +1 / -1: the last proposal was an upper / lower certificate attempt
     int it = 0;
     bool done = false;
@@ -429,11 +430,13 @@ struct WaveSolver {
       ++it;
       if (C == 0) hi = xmin(hi, sig); else lo = xmax(lo, sig);
       // a failed certificate attempt means the estimate is off by more than the offset: widen it
+      const bool cert = (aimed != 0);     // this sweep was a certificate attempt around rho_trust
       if (aimed > 0 && C != 0) off_up *= T(2);
       if (aimed < 0 && C == 0) off_dn *= T(2);
       aimed = 0;
       const bool collapsed = (hi - lo) <= T(4) * tol;
-      const bool want = collapsed || (C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej));
+      // certificate attempts need only the count: the trusted estimate is reused to place the next one
+      const bool want = collapsed || (!cert && ((C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej))));
       bool moved = false;
       T rho = sig;
       bool ok = false;
@@ -441,6 +444,9 @@ struct WaveSolver {
         sweep_bwd(sig);
         rho = twisted(sig);
         ok = finite_of(rho);
+      } else if (cert) {
+        rho = rho_trust;
+        ok = true;
       }
 #ifdef IBS_TRACE
       if (lane == 0 && trace && it <= 64) { T* q = trace + 5 * (it - 1); q[0] = sig; q[1] = T(C); q[2] = ok ? rho : T(-999); q[3] = lo; q[4] = hi; }
@@ -450,7 +456,8 @@ struct WaveSolver {
         done = true;
       } else if (ok) {
         // near convergence rho is trusted to ~tol: place the missing count certificate tol beyond it
-        const bool near = xabs(rho - sig) <= T(4096) * tol;
+        const bool near = cert || xabs(rho - sig) <= T(4096) * tol;
+        if (near) rho_trust = rho;
         T nxt = rho;
         bool have = false;
         if (near) {
