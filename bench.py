@@ -136,6 +136,35 @@ def stress(ctx, device, n_sys, family, reps=3):
                               kernel="k_solve_gcf<double,8>", bytes_per_solve=bytes_per))
 
 
+def sturm_sweep(ctx, device, n_sys, reps=5):
+    """the bandwidth kernel of the path: ONE Sturm-count sweep per system (k_sturm_count), N_zeta=512, f64"""
+    import torch
+    N = NPTS
+    gen = torch.Generator(device=device)
+    gen.manual_seed(7)
+    g = torch.exp(torch.rand((n_sys, N), dtype=torch.float64, device=device, generator=gen) * 3 - 1)
+    c = torch.rand((n_sys, N), dtype=torch.float64, device=device, generator=gen) * 6 - 2.5
+    f = torch.exp(torch.rand((n_sys, N), dtype=torch.float64, device=device, generator=gen) * 3)
+    sh = torch.zeros(n_sys, dtype=torch.float64, device=device)
+    h = 8 * np.pi / (N - 1)
+    ctx.sturm_count(h, g, c, f, sh)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        ctx.sturm_count(h, g, c, f, sh)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+    bytes_per = (3 * N + 1) * 8 + 4
+    gbs = n_sys * bytes_per / (ms * 1e-3) / 1e9
+    return dict(workload="one Sturm-count sweep per system, %d random systems, N_zeta=512, f64" % n_sys,
+                sweeps_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms,
+                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                              traffic=(pmc_traffic("ibs::k_sturm_count<double") if n_sys == 262144 else None),
+                              kernel="k_sturm_count<double,8>", bytes_per_sweep=bytes_per))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +263,7 @@ def main():
         if world == 1 and not args.no_stress:
             out["stress"] = stress(ctx, device, args.stress_systems, "smooth")
             out["stress_rough"] = stress(ctx, device, max(args.stress_systems // 4, 1024), "rough")
+            out["sturm_sweep"] = sturm_sweep(ctx, device, args.stress_systems)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -74,6 +75,25 @@ int check_grid(int32_t N, double h) {
 }
 int rows_per_lane(int N) { return (N - 2 + 63) / 64; }
 
+// lanes per system.  64 = one wave per system (lowest latency, any N).  Large batches of short grids are
+// throughput (VALU-issue) bound: 32 / 16 lanes per system amortise the scan over 2 / 4 systems per wave.
+// IBS_FORCE_P=64|32|16 overrides (tests).
+int pick_lanes(const ibs_ctx* ctx, int N, long n_sys) {
+  const int n = N - 2;
+  int P = 64;
+  // Measured (profiles/README.md, r01_e): with two systems per wave the wave runs max(iterations) of the
+  // pair and a full sweep whenever either system wants one, which eats the 1.5x cheaper sweeps; the
+  // sub-wave kernels are therefore opt-in until the iteration is made phase-uniform.
+  (void)ctx; (void)n_sys;
+  if (const char* e = getenv("IBS_FORCE_P")) {
+    const int f = atoi(e);
+    if (f == 64) P = 64;
+    if (f == 32 && n <= 32 * 16 && n >= 32 * 8 + 1) P = 32;
+    if (f == 16 && n <= 16 * 16 && n >= 16 * 3 + 1) P = 16;
+  }
+  return P;
+}
+
 __global__ void k_count_status(long n, const int* info, int* out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int bad = (i < n) && ((info[i] >> 16) != 0);
@@ -117,10 +137,19 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   if (n_sys < 0 || !g || !c || !f || ld < N) return fail(IBS_ERR_ARG, "bad arguments (n_sys=%lld ld=%lld N=%d)", (long long)n_sys, (long long)ld, N);
   if (int r = check_grid(N, (double)h)) return r;
   if (n_sys == 0) return 0;
-  const int M = rows_per_lane(N);
+  int M = rows_per_lane(N);
   if (!table[M]) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   HIPCHK(hipSetDevice(ctx->device));
-  const size_t per_wave = (size_t)3 * N * sizeof(T);
+  auto launch = table[M];
+  size_t per_wave = (size_t)3 * N * sizeof(T);
+  if constexpr (sizeof(T) == 8) {
+    const int P = pick_lanes(ctx, N, (long)n_sys);
+    if (P != 64) {
+      const int Mg = (N - 2 + P - 1) / P;
+      auto fn = ibs::launch_table().gcf_f64_g[P == 32 ? 0 : 1][Mg];
+      if (fn) { launch = fn; M = Mg; per_wave = (size_t)(64 / P) * N * sizeof(T); }
+    }
+  }
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
   // keep >= 3 blocks per CU resident when LDS allows it
@@ -144,7 +173,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     HIPCHK(hipMemcpyAsync(dc, c, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(df, f, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     a.g = dg; a.c = dc; a.f = df; a.lam = dlam; a.gam = dgam; a.X = dX_; a.dX = ddX; a.info = d_info;
-    HIPCHK(table[M](a, ctx->stream));
+    HIPCHK(launch(a, ctx->stream));
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
     if (lam) HIPCHK(hipMemcpyAsync(lam, dlam, n_sys * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
@@ -158,7 +187,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     return nbad;
   }
   a.g = g; a.c = c; a.f = f; a.lam = lam; a.gam = gam; a.X = X; a.dX = dX; a.info = info;
-  HIPCHK(table[M](a, ctx->stream));
+  HIPCHK(launch(a, ctx->stream));
   return 0;
 }
 
@@ -239,27 +268,38 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
     return fail(IBS_ERR_ARG, "bad arguments (n_lines=%d n_theta0=%d ld=%lld N=%d)", n_lines, n_theta0, (long long)ld, N);
   if (int r = check_grid(N, h)) return r;
   if (n_lines == 0 || n_theta0 == 0) return 0;
-  const int M = rows_per_lane(N);
+  int M = rows_per_lane(N);
   auto fn = ibs::launch_table().scan_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t per_arr = (size_t)N * sizeof(double);
   if (8 * per_arr > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
-  int wpb = (int)(((size_t)ctx->lds_per_block - 7 * per_arr) / per_arr);
-  const int cap = ibs::scan_max_threads(M) / 64;
+  int G = 1, cap = ibs::scan_max_threads(M) / 64;
+  {
+    const int P = pick_lanes(ctx, N, (long)n_lines * n_theta0);
+    if (P != 64 && n_theta0 % (64 / P) == 0) {
+      const int Mg = (N - 2 + P - 1) / P;
+      auto fg = ibs::launch_table().scan_f64_g[P == 32 ? 0 : 1][Mg];
+      if (fg) { fn = fg; M = Mg; G = 64 / P; cap = ibs::scan_max_threads_g(Mg) / 64; }
+    }
+  }
+  // wpb = waves per block; each wave solves G theta0 values of the block's line
+  int wpb = (int)(((size_t)ctx->lds_per_block - 7 * per_arr) / (per_arr * G));
   if (wpb > cap) wpb = cap;
-  if (wpb > n_theta0) wpb = n_theta0;
+  const int waves_per_line = (n_theta0 + G - 1) / G;
+  if (wpb > waves_per_line) wpb = waves_per_line;
+  if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
   // small batches: spread the waves over all CUs (the solver is issue-bound, one wave per SIMD is
   // the fastest placement) instead of packing a line's theta0 values onto one CU
   {
-    const long waves = (long)n_lines * n_theta0;
+    const long waves = (long)n_lines * waves_per_line;
     long per_blk = waves / ctx->n_cu;
     if (per_blk < 1) per_blk = 1;
     if (per_blk < wpb) wpb = (int)per_blk;
   }
-  // balance the theta0 values over the blocks of a line
-  const int nblk = (n_theta0 + wpb - 1) / wpb;
-  wpb = (n_theta0 + nblk - 1) / nblk;
+  // balance the waves over the blocks of a line
+  const int nblk = (waves_per_line + wpb - 1) / wpb;
+  wpb = (waves_per_line + nblk - 1) / nblk;
   ibs::ScanArgs<double> a{};
   a.n_lines = n_lines; a.n_theta0 = n_theta0; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
   const size_t n_sys = (size_t)n_lines * n_theta0;
@@ -368,7 +408,7 @@ int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const 
   auto fn = ibs::launch_table().sturm_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   HIPCHK(hipSetDevice(ctx->device));
-  const size_t per_wave = (size_t)3 * N * sizeof(double);
+  const size_t per_wave = (size_t)N * sizeof(double);
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
   if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d needs %zu B of LDS per wave", N, per_wave);

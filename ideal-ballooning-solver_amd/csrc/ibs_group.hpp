@@ -1,0 +1,390 @@
+// Sub-wave variant of the field-line solver: G = 64/P systems share one wavefront, P lanes each
+// (P = 32 or 16).  Same mathematics as ibs_wave.hpp (read its header first); what changes:
+//   * the Kogge-Stone scan needs log2(P) steps and is amortised over G systems -- the scan is ~70 %
+//     of a sweep at P = 64, so large batches of short grids (N <= 514 for P = 32, N <= 258 for
+//     P = 16) get ~2x / ~3x more solves per issued instruction;
+//   * everything that is wave-uniform in WaveSolver (shift, bracket, counts, k, ...) is only
+//     GROUP-uniform here and lives in VGPRs, replicated over the lanes of the group; the Newton /
+//     bisection state machine is written branch-free per lane and the wave loops until every
+//     group is done (a finished group keeps re-evaluating its frozen shift, so its last sweep --
+//     needed for the eigenvector -- stays intact).
+// Small batches keep P = 64 (one wave per SIMD is the lowest latency); the C-ABI layer picks P.
+#pragma once
+#include "ibs_wave.hpp"
+
+namespace ibs {
+
+template <int P>
+struct Grp {
+  static_assert(P == 16 || P == 32 || P == 64, "group size");
+  static constexpr int G = 64 / P;
+
+  // value held by the LAST lane of each group, broadcast to the whole group
+  template <typename T>
+  __device__ __forceinline__ static T bcast_last(T v, int lane) {
+    if constexpr (P == 64) return readlane_t(v, 63);
+    else if constexpr (P == 32) { const T a = readlane_t(v, 31), b = readlane_t(v, 63); return lane < 32 ? a : b; }
+    else return dpp_t<0x15F, 0xF>(v, v);   // row_newbcast:15
+  }
+  __device__ __forceinline__ static int bcast_last_i(int v, int lane) {
+    if constexpr (P == 64) return readlane_i(v, 63);
+    else if constexpr (P == 32) { const int a = readlane_i(v, 31), b = readlane_i(v, 63); return lane < 32 ? a : b; }
+    else return dpp_i<0x15F, 0xF>(v, v);
+  }
+  template <typename T>
+  __device__ __forceinline__ static T sum(T v, int lane) {
+    v += dpp_t<0x111, 0xF>(T(0), v);
+    v += dpp_t<0x112, 0xF>(T(0), v);
+    v += dpp_t<0x114, 0xF>(T(0), v);
+    v += dpp_t<0x118, 0xF>(T(0), v);
+    if constexpr (P >= 32) v += dpp_t<0x142, 0xA>(T(0), v);
+    if constexpr (P == 64) v += dpp_t<0x143, 0xC>(T(0), v);
+    return bcast_last(v, lane);
+  }
+  __device__ __forceinline__ static int sum_i(int v, int lane) {
+    v += dpp_i<0x111, 0xF>(0, v);
+    v += dpp_i<0x112, 0xF>(0, v);
+    v += dpp_i<0x114, 0xF>(0, v);
+    v += dpp_i<0x118, 0xF>(0, v);
+    if constexpr (P >= 32) v += dpp_i<0x142, 0xA>(0, v);
+    if constexpr (P == 64) v += dpp_i<0x143, 0xC>(0, v);
+    return bcast_last_i(v, lane);
+  }
+  template <typename T>
+  __device__ __forceinline__ static T max(T v, int lane) {
+    v = xmax(v, dpp_t<0x111, 0xF>(v, v));
+    v = xmax(v, dpp_t<0x112, 0xF>(v, v));
+    v = xmax(v, dpp_t<0x114, 0xF>(v, v));
+    v = xmax(v, dpp_t<0x118, 0xF>(v, v));
+    if constexpr (P >= 32) v = xmax(v, dpp_t<0x142, 0xA>(v, v));
+    if constexpr (P == 64) v = xmax(v, dpp_t<0x143, 0xC>(v, v));
+    return bcast_last(v, lane);
+  }
+  // inclusive prefix product inside each group
+  template <typename T>
+  __device__ __forceinline__ static M2<T> scan_fwd(M2<T> Q, int lane) {
+    const int l16 = lane & 15, row = lane >> 4;
+    { const M2<T> F = dpp_fetch<T, 0x111, 0xF>(Q); if (l16 >= 1) Q = mul<T, false>(Q, F); }
+    { const M2<T> F = dpp_fetch<T, 0x112, 0xF>(Q); if (l16 >= 2) Q = mul<T, true>(Q, F); }
+    { const M2<T> F = dpp_fetch<T, 0x114, 0xF>(Q); if (l16 >= 4) Q = mul<T, false>(Q, F); }
+    { const M2<T> F = dpp_fetch<T, 0x118, 0xF>(Q); if (l16 >= 8) Q = mul<T, true>(Q, F); }
+    if constexpr (P >= 32) { const M2<T> F = dpp_fetch<T, 0x142, 0xA>(Q); if (row & 1) Q = mul<T, P == 32>(Q, F); }
+    if constexpr (P == 64) { const M2<T> F = dpp_fetch<T, 0x143, 0xC>(Q); if (row >= 2) Q = mul<T, true>(Q, F); }
+    return Q;
+  }
+  // inclusive suffix product inside each group
+  template <typename T>
+  __device__ __forceinline__ static M2<T> scan_bwd(M2<T> Q, int lane) {
+    const int l16 = lane & 15, row = lane >> 4;
+    { const M2<T> F = dpp_fetch<T, 0x101, 0xF>(Q); if (l16 < 15) Q = mul<T, false>(Q, F); }
+    { const M2<T> F = dpp_fetch<T, 0x102, 0xF>(Q); if (l16 < 14) Q = mul<T, true>(Q, F); }
+    { const M2<T> F = dpp_fetch<T, 0x104, 0xF>(Q); if (l16 < 12) Q = mul<T, false>(Q, F); }
+    { const M2<T> F = dpp_fetch<T, 0x108, 0xF>(Q); if (l16 < 8) Q = mul<T, true>(Q, F); }
+    if constexpr (P >= 32) {
+      const M2<T> t16 = lane_bcast(Q, 16), t48 = lane_bcast(Q, 48);
+      M2<T> F;
+      F.a = row == 0 ? t16.a : t48.a; F.b = row == 0 ? t16.b : t48.b;
+      F.c = row == 0 ? t16.c : t48.c; F.d = row == 0 ? t16.d : t48.d; F.e = row == 0 ? t16.e : t48.e;
+      if ((row & 1) == 0) Q = mul<T, P == 32>(Q, F);
+    }
+    if constexpr (P == 64) { const M2<T> F = lane_bcast(Q, 32); if (row < 2) Q = mul<T, true>(Q, F); }
+    return Q;
+  }
+};
+
+template <typename T, int M, int P>
+struct GroupSolver {
+  using GP = Grp<P>;
+  static constexpr int G = 64 / P;
+  T D[M], Ph[M];            // the scaling s itself is not kept: it cancels in the iteration (see twisted())
+  T kap, ikap;
+  bool has_last;
+  int lane, lg, gid;
+  T zu[M], zw[M];
+  T zu_m1, zw_p1;
+  int Eu, Ew;
+  T lo, hi, normA;          // group-replicated
+  T fu, fw;
+  int thr;
+
+  __device__ __forceinline__ static int rows_start(int lg_, int n) {
+    const int rem = n - P * (M - 1);
+    return lg_ * (M - 1) + (lg_ < rem ? lg_ : rem);
+  }
+
+  // Src provides g(j), c(j), f(j) of THIS lane's system
+  template <class Src>
+  __device__ __forceinline__ bool setup(const Src& src, int N, T h) {
+    lane = threadIdx.x & 63;
+    lg = lane & (P - 1);
+    gid = lane / P;
+    const int n = N - 2;
+    const int rem = n - P * (M - 1);
+    has_last = lg < rem;
+    const int a = rows_start(lg, n);
+    const T ih2 = T(1) / (h * h);
+    T sc = T(1);
+    T gcur = src.g(a + 1);
+    T e_lo = T(0.5) * (src.g(a) + gcur) * ih2;
+    T vhi = -T(1e300), vlo = -T(1e300), vna = T(0), sum_c = T(0), sum_f = T(0);
+    bool bad = false;
+    const T e_first = e_lo;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const bool act = (i < M - 1) || has_last;
+      if (act) {
+        const int j = a + i + 1;
+        const T gnext = src.g(j + 1);
+        const T e_hi = T(0.5) * (gcur + gnext) * ih2;
+        const T cj = src.c(j), fj = src.f(j);
+        const T d = cj - (e_lo + e_hi);
+        const T s2 = sc * sc;
+        D[i] = d * s2; Ph[i] = fj * s2;
+        const T rf = T(1) / fj;
+        vhi = xmax(vhi, cj * rf);
+        vlo = xmax(vlo, d * rf);
+        vna = xmax(vna, (xabs(d) + e_lo + e_hi) * rf);
+        sum_c += cj; sum_f += fj;
+        bad = bad || !(fj > T(0)) || !(e_hi > T(0)) || !finite_of(cj);
+        sc = T(1) / (e_hi * sc);
+        gcur = gnext; e_lo = e_hi;
+      } else {
+        D[i] = T(0); Ph[i] = T(0);
+      }
+    }
+    kap = sc; ikap = T(1) / sc;
+    bad = bad || !(e_first > T(0));
+    // e_0 lives in the group's first lane, e_n in its last lane
+    const T ends = GP::sum((lg == 0 ? e_first : T(0)) + (lg == P - 1 ? e_lo : T(0)), lane);   // e_0 + e_n
+    const T sc_all = GP::sum(sum_c, lane), sf_all = GP::sum(sum_f, lane);
+    normA = GP::max(vna, lane);
+    hi = GP::max(vhi, lane);
+    lo = xmax(GP::max(vlo, lane), (sc_all - ends) / sf_all);
+    hi += T(8) * Eps<T>::v * normA;
+    lo -= T(8) * Eps<T>::v * normA;
+    return GP::sum_i(bad ? 1 : 0, lane) != 0;   // per group
+  }
+
+  // forward sweep; returns the group's Sturm count (eigenvalues > sig), group-replicated
+  __device__ __forceinline__ int sweep_fwd(T sig) {
+    T fA = T(1), fAp = T(0), fB = T(0), fBp = T(1);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const T tf = xfma(-sig, Ph[i], D[i]);
+      if ((i < M - 1) || has_last) {
+        const T nA = xfma(-tf, fA, -fAp), nB = xfma(-tf, fB, -fBp);
+        fAp = fA; fA = nA; fBp = fB; fB = nB;
+      }
+    }
+    M2<T> F;
+    F.a = fA * kap; F.b = fB * kap; F.c = fAp * ikap; F.d = fBp * ikap; F.e = 0;
+    renorm(F);
+    const M2<T> Q = GP::scan_fwd(F, lane);
+    T u0 = dpp_t<0x138, 0xF>(T(1), Q.a);   // wave_shr:1
+    T um = dpp_t<0x138, 0xF>(T(0), Q.c);
+    int eu = dpp_i<0x138, 0xF>(0, Q.e);
+    if constexpr (P < 64) { const bool first = (lg == 0); u0 = first ? T(1) : u0; um = first ? T(0) : um; eu = first ? 0 : eu; }
+    Eu = eu;
+    zu_m1 = um;
+    T zc = u0, zp = um;
+    int count = 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const T t = xfma(-sig, Ph[i], D[i]);
+      const bool act = (i < M - 1) || has_last;
+      zu[i] = act ? zc : T(0);
+      const T zn = xfma(-t, zc, -zp);
+      count += (act && (signbit_of(zn) != signbit_of(zc))) ? 1 : 0;
+      if (act) { zp = zc; zc = zn; }
+    }
+    return GP::sum_i(count, lane);
+  }
+
+  __device__ __forceinline__ void sweep_bwd(T sig) {
+    T bA = T(1), bAn = T(0), bB = T(0), bBn = T(1);
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      const T tb = xfma(-sig, Ph[i], D[i]);
+      if ((i < M - 1) || has_last) {
+        const T nA = xfma(-tb, bA, -bAn), nB = xfma(-tb, bB, -bBn);
+        bAn = bA; bA = nA; bBn = bB; bB = nB;
+      }
+    }
+    M2<T> B;
+    B.a = bA * kap; B.b = bB * ikap; B.c = bAn * kap; B.d = bBn * ikap; B.e = 0;
+    renorm(B);
+    const M2<T> Q = GP::scan_bwd(B, lane);
+    T wp = dpp_t<0x130, 0xF>(T(1), Q.a);   // wave_shl:1
+    T wq = dpp_t<0x130, 0xF>(T(0), Q.c);
+    int ew = dpp_i<0x130, 0xF>(0, Q.e);
+    if constexpr (P < 64) { const bool last = (lg == P - 1); wp = last ? T(1) : wp; wq = last ? T(0) : wq; ew = last ? 0 : ew; }
+    Ew = ew;
+    T wc = wp * kap, wn = wq * ikap;
+    zw_p1 = wn;
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      const T t = xfma(-sig, Ph[i], D[i]);
+      const bool act = (i < M - 1) || has_last;
+      zw[i] = act ? wc : wn;
+      const T z2 = xfma(-t, wc, -wn);
+      if (act) { wn = wc; wc = z2; }
+    }
+  }
+
+  // twisted estimate per group (see WaveSolver::twisted); returns rho, group-replicated
+  __device__ __forceinline__ T twisted(T sig) {
+    T best = T(0);
+    int bi = 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const T a = xabs(Ph[i] * (zu[i] * zw[i]));      // f-weighted |u w|: any row with a large product will do
+      const bool better = a > best;
+      best = better ? a : best; bi = better ? i : bi;
+    }
+    const int ex = fexp(best);
+    T key = (best > T(0) && finite_of(best)) ? T(ex + Eu + Ew) + xldexp(best, -ex) : -T(1e30);
+    int Lk;   // group-replicated lane id of the twist row's owner
+    if constexpr (sizeof(T) == 8) {
+      key = __hiloint2double(__double2hiint(key), (__double2loint(key) & ~63) | lane);
+      Lk = __double2loint(GP::max(key, lane)) & 63;
+    } else {
+      key = __int_as_float((__float_as_int(key) & ~63) | lane);
+      Lk = __float_as_int(GP::max(key, lane)) & 63;
+    }
+    // per group: fetch the entries around (Lk, ik) through scalar reads, keep them in this group's lanes
+    T zu_k = T(1), zw_k = T(1), t_k = T(0), um1 = T(0), wp1 = T(0);
+    int ik = 0, Euk = 0, Ewk = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int sLk = readlane_i(Lk, g * P);
+      const int sik = readlane_i(bi, sLk);
+      T a_zu = T(1), a_zw = T(1), a_t = T(0), a_um1 = T(0), a_wp1 = T(0);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        if (i == sik) {
+          a_zu = readlane_t(zu[i], sLk); a_zw = readlane_t(zw[i], sLk);
+          a_t = readlane_t(xfma(-sig, Ph[i], D[i]), sLk);
+          a_um1 = readlane_t(i == 0 ? zu_m1 : zu[i > 0 ? i - 1 : 0], sLk);
+          a_wp1 = readlane_t(i == M - 1 ? zw_p1 : zw[i < M - 1 ? i + 1 : M - 1], sLk);
+        }
+      }
+      const int a_Eu = readlane_i(Eu, sLk), a_Ew = readlane_i(Ew, sLk);
+      const bool mine = (gid == g);
+      zu_k = mine ? a_zu : zu_k; zw_k = mine ? a_zw : zw_k; t_k = mine ? a_t : t_k;
+      um1 = mine ? a_um1 : um1; wp1 = mine ? a_wp1 : wp1;
+      ik = mine ? sik : ik; Euk = mine ? a_Eu : Euk; Ewk = mine ? a_Ew : Ewk;
+    }
+    const T uw = zu_k * zw_k;
+    const T num = xfma(um1, zw_k, xfma(t_k, uw, wp1 * zu_k));
+    // rho = sig + gamma_k / sum(f x^2) with x = s z / (s_k z_k): the scaling s_k cancels,
+    //   gamma_k = num / (s_k^2 u w),  sum f x^2 = sum(Ph zhat^2) / s_k^2,  zhat = z / z_k
+    int du = Eu - Euk, dw = Ew - Ewk;
+    du = du > 1000 ? 1000 : (du < -2000 ? -2000 : du);
+    dw = dw > 1000 ? 1000 : (dw < -2000 ? -2000 : dw);
+    fu = xldexp(T(1) / zu_k, du);
+    fw = xldexp(T(1) / zw_k, dw);
+    thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const T xu = zu[i] * fu, xw = zw[i] * fw;
+      const T x = (i <= thr) ? xu : xw;
+      if ((i < M - 1) || has_last) acc = xfma(Ph[i] * x, x, acc);
+    }
+    const T tot = GP::sum(acc, lane);
+    return sig + num / (uw * tot);
+  }
+
+  // eigenvector entries of this lane's rows up to a common factor per group (normalised by the caller);
+  // the diagonal scaling s is rebuilt here from g (s_0 = 1, s_{i+1} = 1/(e_{i+1} s_i))
+  template <class Src>
+  __device__ __forceinline__ void assemble(const Src& src, int N, T h, T (&x)[M]) {
+    const int a = rows_start(lg, N - 2);
+    const T ih2 = T(1) / (h * h);
+    T sc = T(1);
+    T gcur = src.g(a + 1);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const bool act = (i < M - 1) || has_last;
+      const T xu = sc * zu[i] * fu, xw = sc * zw[i] * fw;
+      x[i] = act ? ((i <= thr) ? xu : xw) : T(0);
+      if (act) {
+        const T gnext = src.g(a + i + 2);
+        sc = T(1) / (T(0.5) * (gcur + gnext) * ih2 * sc);
+        gcur = gnext;
+      }
+    }
+  }
+
+  // per-group safeguarded Newton / bisection with count-certified brackets (WaveSolver::solve, vectorised
+  // over the groups of the wave).  `bad` groups are parked as done.  Returns lam (group-replicated).
+  __device__ __forceinline__ T solve(bool bad, int& iters_out, int& status_out) {
+    const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
+    T sig = hi, rej = -T(1), lam = hi;
+    T off_up = tol, off_dn = tol, rho_trust = hi;
+    int aimed = 0, it = 0;
+    bool done = bad;
+    constexpr int kMaxIt = 200;
+    int guard = 0;
+    while (__any(!done) && guard < kMaxIt) {
+      ++guard;
+      const int C = sweep_fwd(sig);
+      const bool act = !done;
+      if (act) {
+        ++it;
+        if (C == 0) hi = xmin(hi, sig); else lo = xmax(lo, sig);
+      }
+      const bool cert = act && (aimed != 0);
+      if (act) {
+        if (aimed > 0 && C != 0) off_up *= T(2);
+        if (aimed < 0 && C == 0) off_dn *= T(2);
+        aimed = 0;
+      }
+      const bool collapsed = act && ((hi - lo) <= T(4) * tol);
+      const bool want = act && (collapsed || (!cert && ((C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej)))));
+      // a parked group re-evaluates its frozen shift so that its last full sweep stays valid
+      const bool anywant = __any(want) != 0;
+      T rho = sig;
+      bool ok = false;
+      if (anywant) {
+        sweep_bwd(sig);
+        const T r = twisted(sig);
+        if (want) { rho = r; ok = finite_of(r); }
+      }
+      if (cert && !want) { rho = rho_trust; ok = true; }
+      bool moved = false;
+      if (act) {
+        if (collapsed) {
+          lam = (ok && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi);
+          done = true;
+        } else if (ok) {
+          const bool near = cert || xabs(rho - sig) <= T(4096) * tol;
+          if (near) rho_trust = rho;
+          T nxt = rho;
+          bool have = false;
+          if (near) {
+            const T up = xmax(rho, lo), dn = xmin(rho, hi);
+            if (hi > up + T(2) * off_up) { nxt = up + off_up; have = true; aimed = 1; }
+            else if (lo < dn - T(2) * off_dn) { nxt = dn - off_dn; have = true; aimed = -1; }
+            have = have && (nxt > lo) && (nxt < hi);
+            if (!have) aimed = 0;
+          } else if (rho > lo && rho < hi) {
+            have = true;
+          }
+          if (have) { sig = nxt; moved = true; }
+          else if (C == 0 && !near) rej = hi - lo;
+        }
+        if (!done && !moved) sig = T(0.5) * (lo + hi);
+      }
+    }
+    // a group that was parked by another group's full sweep is consistent; one whose last evaluation was
+    // forward-only cannot exist: it finishes only in a collapsed (= full) step.  Bad groups: one full sweep.
+    if (__any(bad)) { sweep_fwd(sig); sweep_bwd(sig); twisted(sig); }
+    iters_out = it;
+    status_out = bad ? 2 : (done ? 0 : 1);
+    if (!done) lam = sig;
+    return lam;
+  }
+};
+
+}  // namespace ibs

@@ -281,6 +281,70 @@ __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const
 }
 
 // ---------------------------------------------------------------- Sturm count at given shifts
+// The bandwidth kernel of the path ("batched Sturm/tridiag sweep"): one forward sweep per system, no
+// scaling set-up, no divisions.  Works on the un-normalised three-term recurrence
+//     u[r+1] = -(d[r] - sig f[r]) u[r] - e[r]^2 u[r-1]
+// (signs only matter, so the 2x2 scan carries no exponent).  Each array is streamed through a per-wave
+// LDS row with 16-byte coalesced loads and handed to the lanes as contiguous chunks.
+// A wave's row of N values held in registers as KP 16-byte pieces per lane (coalesced: lane l owns pieces
+// l, l+64, ...), loaded from the first 16-byte aligned element on; the (at most one) head and tail elements
+// are loaded singly.  All three coefficient rows are put in flight before any of them is consumed.
+template <typename T, int KP>
+struct RowRegs {
+  double2 v[KP];
+  T head_v, tail_v;
+  int head;
+  __device__ __forceinline__ void load(const T* __restrict__ src, int N, int lane) {
+    static_assert(sizeof(T) == 8, "f64 rows");
+    head = (reinterpret_cast<uintptr_t>(src) & 15) ? 1 : 0;
+    const int npair = (N - head) / 2;
+    const double2* s2 = reinterpret_cast<const double2*>(src + head);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int p = lane + k * kWave;
+      v[k] = (p < npair) ? s2[p] : double2{0.0, 0.0};
+    }
+    head_v = src[0];
+    tail_v = src[N - 1];
+  }
+  __device__ __forceinline__ void store(T* dst, int N, int lane) const {
+    const int npair = (N - head) / 2;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int p = lane + k * kWave;
+      if (p < npair) { dst[head + 2 * p] = v[k].x; dst[head + 2 * p + 1] = v[k].y; }
+    }
+    if (lane == 0) { dst[0] = head_v; dst[N - 1] = tail_v; }
+  }
+};
+// LDS rows are private to a wave: ordering inside the wave is all that is needed
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T>
+struct M2s { T a, b, c, d; };
+template <typename T>
+__device__ __forceinline__ M2s<T> muls(const M2s<T>& A, const M2s<T>& B, bool norm) {
+  M2s<T> R;
+  R.a = xfma(A.a, B.a, A.b * B.c); R.b = xfma(A.a, B.b, A.b * B.d);
+  R.c = xfma(A.c, B.a, A.d * B.c); R.d = xfma(A.c, B.b, A.d * B.d);
+  if (norm) {
+    const int ex = fexp(xmax(xmax(xabs(R.a), xabs(R.b)), xmax(xabs(R.c), xabs(R.d))));
+    R.a = xldexp(R.a, -ex); R.b = xldexp(R.b, -ex); R.c = xldexp(R.c, -ex); R.d = xldexp(R.d, -ex);
+  }
+  return R;
+}
+template <typename T, int CTRL, int ROWMASK>
+__device__ __forceinline__ M2s<T> dpp_fetch_s(const M2s<T>& s) {
+  M2s<T> r;
+  r.a = dppz_t<CTRL, ROWMASK>(s.a); r.b = dppz_t<CTRL, ROWMASK>(s.b);
+  r.c = dppz_t<CTRL, ROWMASK>(s.c); r.d = dppz_t<CTRL, ROWMASK>(s.d);
+  return r;
+}
+
 template <typename T, int M>
 __global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, const T* __restrict__ g,
                                                      const T* __restrict__ c, const T* __restrict__ f, long ld,
@@ -292,15 +356,78 @@ __global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, con
   const long sys = (long)blockIdx.x * wpb + wave;
   const bool valid = sys < n_sys;
   const long sysc = valid ? sys : (n_sys - 1);
-  T* gs = smem + (size_t)wave * 3 * N;
-  T* cs = gs + N; T* fs = cs + N;
-  const T* gg = g + sysc * ld; const T* cg = c + sysc * ld; const T* fg = f + sysc * ld;
-  for (int j = lane; j < N; j += kWave) { gs[j] = gg[j]; cs[j] = cg[j]; fs[j] = fg[j]; }
-  __syncthreads();
-  SrcGCF<T> src{gs, cs, fs};
-  WaveSolver<T, M> ws;
-  ws.setup(src, N, h);
-  const int cnt = ws.sweep_fwd(shift[sysc]);
+  T* row = smem + (size_t)wave * N;
+  const int n = N - 2;
+  const int rem = n - kWave * (M - 1);
+  const bool has_last = lane < rem;
+  const int a = WaveSolver<T, M>::rows_start(lane, n);
+  const T ih2 = T(1) / (h * h);
+  const T sig = shift[sysc];
+  T t[M], e2[M];
+  constexpr int KP = M / 2 + 1;      // 16-byte pieces per lane: ceil(ceil(N/2)/64) <= M/2 + 1
+  RowRegs<T, KP> rg, rc, rf;
+  rg.load(g + sysc * ld, N, lane);
+  rc.load(c + sysc * ld, N, lane);
+  rf.load(f + sysc * ld, N, lane);
+  // g -> e = half-grid g / h^2 (utils.py:1574-1576)
+  rg.store(row, N, lane);
+  wave_lds_sync();
+  {
+    T gprev = row[a], gcur = row[a + 1];
+    T e_lo = T(0.5) * (gprev + gcur) * ih2;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      if ((i < M - 1) || has_last) {
+        const T gnext = row[a + i + 2];
+        const T e_hi = T(0.5) * (gcur + gnext) * ih2;
+        e2[i] = e_lo * e_lo;
+        t[i] = -(e_lo + e_hi);          // d = c - (e_lo + e_hi), c added below
+        gcur = gnext; e_lo = e_hi;
+      } else { e2[i] = T(0); t[i] = T(0); }
+    }
+  }
+  wave_lds_sync();
+  rc.store(row, N, lane);
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+    if ((i < M - 1) || has_last) t[i] += row[a + i + 1];
+  wave_lds_sync();
+  rf.store(row, N, lane);
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+    if ((i < M - 1) || has_last) t[i] = xfma(-sig, row[a + i + 1], t[i]);   // t = d - sig f
+  // chunk transfer matrix: (u_a, u_{a-1}) -> (u_{a+cnt}, u_{a+cnt-1})
+  T fA = T(1), fAp = T(0), fB = T(0), fBp = T(1);
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    if ((i < M - 1) || has_last) {
+      const T nA = xfma(-t[i], fA, -(e2[i] * fAp)), nB = xfma(-t[i], fB, -(e2[i] * fBp));
+      fAp = fA; fA = nA; fBp = fB; fB = nB;
+    }
+  }
+  M2s<T> P{fA, fB, fAp, fBp};
+  P = muls(P, M2s<T>{T(1), T(0), T(0), T(1)}, true);
+  {
+    const int l16 = lane & 15, rw = lane >> 4;
+    { const M2s<T> F = dpp_fetch_s<T, 0x111, 0xF>(P); if (l16 >= 1) P = muls(P, F, false); }
+    { const M2s<T> F = dpp_fetch_s<T, 0x112, 0xF>(P); if (l16 >= 2) P = muls(P, F, true); }
+    { const M2s<T> F = dpp_fetch_s<T, 0x114, 0xF>(P); if (l16 >= 4) P = muls(P, F, false); }
+    { const M2s<T> F = dpp_fetch_s<T, 0x118, 0xF>(P); if (l16 >= 8) P = muls(P, F, true); }
+    { const M2s<T> F = dpp_fetch_s<T, 0x142, 0xA>(P); if (rw & 1) P = muls(P, F, false); }
+    { const M2s<T> F = dpp_fetch_s<T, 0x143, 0xC>(P); if (rw >= 2) P = muls(P, F, true); }
+  }
+  T zc = dpp_t<0x138, 0xF>(T(1), P.a), zp = dpp_t<0x138, 0xF>(T(0), P.c);   // incoming (u_a, u_{a-1})
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    const bool act = (i < M - 1) || has_last;
+    const T zn = xfma(-t[i], zc, -(e2[i] * zp));
+    const bool flip = act && (signbit_of(zn) != signbit_of(zc));
+    cnt += __popcll(__ballot(flip));
+    if (act) { zp = zc; zc = zn; }
+  }
   if (valid && lane == 0) count_out[sys] = cnt;
 }
 
@@ -333,7 +460,7 @@ static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
 template <typename T>
 static hipError_t launch_sturm(const SturmArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
-  const size_t lds = (size_t)wpb * 3 * a.N * sizeof(T);
+  const size_t lds = (size_t)wpb * a.N * sizeof(T);
   const long nblk = (a.n_sys + wpb - 1) / wpb;
   auto kern = k_sturm_count<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

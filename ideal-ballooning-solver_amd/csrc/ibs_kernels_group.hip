@@ -1,0 +1,202 @@
+// Sub-wave kernels: G = 64/P systems per wavefront (ibs_group.hpp).  One translation unit per (P, M):
+// compiled with -DIBS_P=<32|16> -DIBS_M=<rows per lane>.  Used by the C-ABI layer for large batches of
+// short grids; results are the same quantities as the P = 64 kernels of ibs_kernels.hip.
+#include <type_traits>
+#include "ibs_group.hpp"
+#include "ibs_launch.hpp"
+
+#if !defined(IBS_M) || !defined(IBS_P)
+#error "compile with -DIBS_P=<lanes per system> -DIBS_M=<rows per lane>"
+#endif
+
+namespace ibs {
+
+template <typename T>
+struct SrcGlobal {   // raw (g, c, f) straight from global memory: a lane's chunk is M contiguous values
+  const T* gs; const T* cs; const T* fs;
+  __device__ __forceinline__ T g(int j) const { return gs[j]; }
+  __device__ __forceinline__ T c(int j) const { return cs[j]; }
+  __device__ __forceinline__ T f(int j) const { return fs[j]; }
+};
+
+template <typename T>
+struct SrcGeoG {     // as SrcGeo (ibs_kernels.hip): 7 derived arrays of the line in LDS, theta0 per lane
+  const T* A1; const T* A3; const T* C0; const T* C1; const T* G0; const T* G1; const T* G2;
+  T th0, two_th0, th0sq;
+  __device__ __forceinline__ T gd(int j) const { return G0[j] + two_th0 * G1[j] + th0sq * G2[j]; }
+  __device__ __forceinline__ T g(int j) const { return A1[j] * gd(j); }
+  __device__ __forceinline__ T c(int j) const { return C0[j] + th0 * C1[j]; }
+  __device__ __forceinline__ T f(int j) const { return A3[j] * gd(j); }
+  __device__ __forceinline__ T gdp(int j) const { return T(2) * G1[j] + two_th0 * G2[j]; }
+  __device__ __forceinline__ T g_t(int j) const { return A1[j] * gdp(j); }
+  __device__ __forceinline__ T c_t(int j) const { return C1[j]; }
+  __device__ __forceinline__ T f_t(int j) const { return A3[j] * gdp(j); }
+};
+
+// eigenvector -> X (LDS, this lane's system) -> growth rate; utils.py:1601-1621 (+1666-1680 when HF)
+template <typename T, int M, int P, class Src, bool HF>
+__device__ __forceinline__ void finish_g(GroupSolver<T, M, P>& ws, const Src& src, int N, T h, T* Xs, T lam,
+                                         int iters, int status, long sys, bool valid, T* lam_out, T* gam_out,
+                                         T* X_out, T* dX_out, T* dth0_out, int* info_out) {
+  using GP = Grp<P>;
+  const int lane = ws.lane, lg = ws.lg;
+  const int n = N - 2;
+  T x[M];
+  ws.assemble(src, N, h, x);
+  T m = T(0);
+#pragma unroll
+  for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
+  m = GP::max(m, lane);
+  const int a = GroupSolver<T, M, P>::rows_start(lg, n);
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+    if ((i < M - 1) || ws.has_last) Xs[a + i + 1] = x[i] / m;
+  if (lg == 0) { Xs[0] = T(0); Xs[N - 1] = T(0); }
+  __syncthreads();
+  const T ih = T(1) / h;
+  T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
+  for (int j = lg; j < N; j += P) {
+    const T X = Xs[j];
+    const T dX = fd_derivative(Xs, j, N, ih);
+    const T w = T(simpson_w(j, N));
+    const T X2 = X * X, dX2 = dX * dX;
+    y0 += w * (src.c(j) * X2 - src.g(j) * dX2);
+    y1 += w * (src.f(j) * X2);
+    if constexpr (HF) { hc += w * (src.c_t(j) * X2); hg += w * (src.g_t(j) * dX2); hf += w * (src.f_t(j) * X2); }
+    if (valid && X_out) X_out[sys * N + j] = X;
+    if (valid && dX_out) dX_out[sys * N + j] = dX;
+  }
+  y0 = GP::sum(y0, lane); y1 = GP::sum(y1, lane);
+  const T gam = y0 / y1;
+  if constexpr (HF) {
+    if (dth0_out) {
+      hc = GP::sum(hc, lane); hg = GP::sum(hg, lane); hf = GP::sum(hf, lane);
+      const T jac = hc / y1 - hg / y1 - gam * hf / y1;
+      if (lg == 0 && valid) dth0_out[sys] = jac;
+    }
+  }
+  if (lg == 0 && valid) {
+    if (lam_out) lam_out[sys] = lam;
+    if (gam_out) gam_out[sys] = gam;
+    if (info_out) info_out[sys] = iters | (status << 16);
+  }
+}
+
+// raw (g, c, f): wave w of block b solves systems (b*wpb + w)*G .. +G-1; dynamic LDS = wpb * G * N * sizeof(T) (X only)
+template <typename T, int M, int P>
+__global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, const T* __restrict__ g,
+                                                     const T* __restrict__ c, const T* __restrict__ f, long ld,
+                                                     T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  constexpr int G = 64 / P;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int gid = lane / P;
+  const long sys = ((long)blockIdx.x * wpb + wave) * G + gid;
+  const bool valid = sys < n_sys;
+  const long sysc = valid ? sys : (n_sys - 1);
+  T* Xs = smem + ((size_t)wave * G + gid) * N;
+  SrcGlobal<T> src{g + sysc * ld, c + sysc * ld, f + sysc * ld};
+  GroupSolver<T, M, P> ws;
+  const bool bad = ws.setup(src, N, h);
+  int iters = 0, status = 0;
+  const T lam = ws.solve(bad, iters, status);
+  finish_g<T, M, P, SrcGlobal<T>, false>(ws, src, N, h, Xs, lam, iters, status, sysc, valid, lam_out, gam_out, X_out,
+                                         dX_out, nullptr, info_out);
+}
+
+// geometry-fed scan: block = wpb waves of one line part; wave w solves theta0 indices (part*wpb + w)*G .. +G-1
+template <typename T, int M, int P>
+__global__ void __launch_bounds__(scan_max_threads_g(M), 2) k_gamma_scan_g(
+    int n_lines, int n_theta0, int N, T h, const T* __restrict__ bmag, const T* __restrict__ gradpar,
+    const T* __restrict__ cvdrift, const T* __restrict__ cvdrift0, const T* __restrict__ gds2,
+    const T* __restrict__ gds21, const T* __restrict__ gds22, long ld, const T* __restrict__ dPdrho,
+    const T* __restrict__ theta0, T* gam_out, T* lam_out, T* X_out, T* dX_out, T* dth0_out, int* info_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  constexpr int G = 64 / P;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int gid = lane / P;
+  const int per_blk = wpb * G;
+  const int nparts = (n_theta0 + per_blk - 1) / per_blk;
+  int line, part;
+  {   // XCD-aware block -> (line, part) map, see k_gamma_scan
+    const int b = blockIdx.x;
+    const int chunk = b / (8 * nparts), r = b - chunk * 8 * nparts;
+    const int lines_here = min(8, n_lines - chunk * 8);
+    line = chunk * 8 + r % lines_here;
+    part = r / lines_here;
+  }
+  T* A1 = smem; T* A3 = A1 + N; T* C0 = A3 + N; T* C1 = C0 + N; T* G0 = C1 + N; T* G1 = G0 + N; T* G2 = G1 + N;
+  T* Xs = G2 + N + ((size_t)wave * G + gid) * N;
+  {
+    const long off = (long)line * ld;
+    const T mdP = -dPdrho[line];
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const T B = bmag[off + j], gp = xabs(gradpar[off + j]);
+      const T inv = T(1) / (gp * B);
+      A1[j] = gp / B; A3[j] = inv / (B * B);
+      C0[j] = mdP * cvdrift[off + j] * inv; C1[j] = mdP * cvdrift0[off + j] * inv;
+      G0[j] = gds2[off + j]; G1[j] = gds21[off + j]; G2[j] = gds22[off + j];
+    }
+  }
+  __syncthreads();
+  const int it0 = (part * wpb + wave) * G + gid;
+  const bool valid = it0 < n_theta0;
+  const int it0c = valid ? it0 : (n_theta0 - 1);
+  const T th0 = theta0[it0c];
+  SrcGeoG<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
+  GroupSolver<T, M, P> ws;
+  const bool bad = ws.setup(src, N, h);
+  int iters = 0, status = 0;
+  const T lam = ws.solve(bad, iters, status);
+  const long sys = (long)line * n_theta0 + it0c;
+  finish_g<T, M, P, SrcGeoG<T>, true>(ws, src, N, h, Xs, lam, iters, status, sys, valid, lam_out, gam_out, X_out,
+                                      dX_out, dth0_out, info_out);
+}
+
+template <typename T>
+static hipError_t launch_gcf_g(const GcfArgs<T>& a, hipStream_t st) {
+  constexpr int G = 64 / IBS_P;
+  const int wpb = a.wpb;
+  const size_t lds = (size_t)wpb * G * a.N * sizeof(T);
+  const long nwaves = (a.n_sys + G - 1) / G;
+  const long nblk = (nwaves + wpb - 1) / wpb;
+  auto kern = k_solve_gcf_g<T, IBS_M, IBS_P>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
+                     a.lam, a.gam, a.X, a.dX, a.info);
+  return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_scan_g(const ScanArgs<T>& a, hipStream_t st) {
+  constexpr int G = 64 / IBS_P;
+  const int wpb = a.wpb;
+  const size_t lds = (size_t)(7 + wpb * G) * a.N * sizeof(T);
+  auto kern = k_gamma_scan_g<T, IBS_M, IBS_P>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const int per_blk = wpb * G;
+  dim3 grid((unsigned)(((a.n_theta0 + per_blk - 1) / per_blk) * a.n_lines));
+  hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
+                     a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
+                     a.dX, a.dth0, a.info);
+  return hipGetLastError();
+}
+
+#define IBS_CAT3_(a, b, c) a##b##_##c
+#define IBS_CAT3(a, b, c) IBS_CAT3_(a, b, c)
+struct IBS_CAT3(RegistrarG, IBS_P, IBS_M) {
+  IBS_CAT3(RegistrarG, IBS_P, IBS_M)() {
+    LaunchTable& t = launch_table();
+    constexpr int pi = (IBS_P == 32) ? 0 : 1;
+    t.gcf_f64_g[pi][IBS_M] = &launch_gcf_g<double>;
+    t.scan_f64_g[pi][IBS_M] = &launch_scan_g<double>;
+  }
+};
+static IBS_CAT3(RegistrarG, IBS_P, IBS_M) IBS_CAT3(registrar_g_instance_, IBS_P, IBS_M);
+
+}  // namespace ibs

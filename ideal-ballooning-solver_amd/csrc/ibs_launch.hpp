@@ -36,10 +36,14 @@ struct LaunchTable {
   hipError_t (*scan_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
   hipError_t (*sturm_f64[kMaxM + 1])(const SturmArgs<double>&, hipStream_t);
   hipError_t (*grad_f64[kMaxM + 1])(const GradArgs<double>&, hipStream_t);
+  // sub-wave variants (ibs_group.hpp): index 0 -> 32 lanes per system, 1 -> 16 lanes per system
+  hipError_t (*gcf_f64_g[2][kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
+  hipError_t (*scan_f64_g[2][kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
 };
 LaunchTable& launch_table();
 
 // threads per block the scan kernel is compiled for (register budget: 5M doubles per lane)
 constexpr int scan_max_threads(int M) { return M <= 16 ? 512 : 256; }
+constexpr int scan_max_threads_g(int M) { return M <= 8 ? 512 : 256; }   // sub-wave kernels (ibs_group.hpp)
 
 }  // namespace ibs

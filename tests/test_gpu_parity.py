@@ -278,3 +278,49 @@ def test_config3_shape_ncsx_1025_tiled(ctx, bo):
     r = ctx.gamma_scan(th[1] - th[0], *a, dP, t0)
     gam_c, lam_c, _ = co.gamma_scan(th[1] - th[0], *a, dP, t0)
     assert r["nbad"] == 0 and np.abs(r["gam"] - gam_c).max() < TOL and np.abs(r["lam"] - lam_c).max() < TOL
+
+
+@pytest.mark.parametrize("N,P", [(513, 32), (385, 32), (257, 16), (129, 16), (641, 32)])
+def test_subwave_variants_match_full_wave(ctx, bo, N, P):
+    """32 / 16 lanes per system (ibs_group.hpp) against the one-wave-per-system kernels and the oracle;
+    (641, 32) is outside the 32-lane range and must silently use the full-wave kernel."""
+    rng = np.random.default_rng(N + P)
+    n_sys = 37                                                  # not a multiple of the systems per wave
+    params = np.stack([rng.uniform(0.2, 2, n_sys), rng.uniform(0.1, 1.2, n_sys), rng.uniform(0, 1.5, n_sys)], 1)
+    th, g, c = salpha_batch(bo, N, params)
+    f = g * (1 + 0.3 * np.cos(th))[None]
+    h = th[1] - th[0]
+    os.environ["IBS_FORCE_P"] = "64"
+    try:
+        ref = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
+        os.environ["IBS_FORCE_P"] = str(P)
+        r = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
+    finally:
+        os.environ.pop("IBS_FORCE_P", None)
+    assert r["nbad"] == 0 and ((r["info"] >> 16) == 0).all()
+    assert np.abs(r["lam"] - ref["lam"]).max() < 1e-10 and np.abs(r["gam"] - ref["gam"]).max() < 1e-10
+    assert np.abs(r["X"] - ref["X"]).max() < 1e-7 and np.abs(r["dX"] - ref["dX"]).max() < 1e-6
+    for k in (0, 17, 36):
+        go, lo, Xo, dXo = bo.solve_gcf(th, g[k], c[k], f[k])
+        assert abs(r["gam"][k] - go) < 1e-10 and abs(r["lam"][k] - lo) < 1e-10
+
+
+def test_subwave_scan_matches_full_wave(ctx, bo):
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    geo = g3["geo_513"]
+    th = bo.theta_grid(513)
+    a = [np.ascontiguousarray(geo[:, k, :]) for k in range(7)]
+    t0 = np.linspace(0, np.pi / 2, 8)
+    os.environ["IBS_FORCE_P"] = "64"
+    try:
+        ref = ctx.gamma_scan(th[1] - th[0], *a, g3["dPdrho_513"], t0, want_X=True, want_dtheta0=True)
+        os.environ["IBS_FORCE_P"] = "32"
+        r = ctx.gamma_scan(th[1] - th[0], *a, g3["dPdrho_513"], t0, want_X=True, want_dtheta0=True, want_info=True)
+        r5 = ctx.gamma_scan(th[1] - th[0], *a, g3["dPdrho_513"], t0[:5])     # 5 theta0: falls back to full waves
+    finally:
+        os.environ.pop("IBS_FORCE_P", None)
+    assert r["nbad"] == 0
+    assert np.abs(r["gam"] - ref["gam"]).max() < 1e-10 and np.abs(r["lam"] - ref["lam"]).max() < 1e-10
+    assert np.abs(r["dgam_dtheta0"] - ref["dgam_dtheta0"]).max() < 1e-9
+    assert np.abs(r["X"] - ref["X"]).max() < 1e-7
+    assert np.abs(r5["gam"] - ref["gam"][:, :5]).max() < 1e-10

@@ -1,0 +1,20 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch, ibs_amd
+ctx = ibs_amd.Context(0); dev = torch.device('cuda', 0)
+for N in (257, 513, 1025):
+    n = (1 << 18) * 513 // N
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    g = torch.exp(torch.rand((n, N), dtype=torch.float64, device=dev, generator=gen) * 3 - 1)
+    c = torch.rand((n, N), dtype=torch.float64, device=dev, generator=gen) * 6 - 2.5
+    f = torch.exp(torch.rand((n, N), dtype=torch.float64, device=dev, generator=gen) * 3)
+    sh = torch.zeros(n, dtype=torch.float64, device=dev)
+    h = 8 * np.pi / (N - 1)
+    ctx.sturm_count(h, g, c, f, sh); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b in ev:
+        a.record(); ctx.sturm_count(h, g, c, f, sh); b.record()
+    torch.cuda.synchronize()
+    ms = np.median([a.elapsed_time(b) for a, b in ev])
+    byts = n * (3 * N + 1) * 8 + n * 4
+    print('N=%d n=%d  %.3f ms  %.1f GB/s  (%.1f%% of 8 TB/s)  %.3g sweeps/s' % (N, n, ms, byts / ms / 1e6, byts / ms / 1e6 / 80, n / ms * 1e3))

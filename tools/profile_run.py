@@ -20,3 +20,5 @@ torch.cuda.synchronize()
 n = int(os.environ.get("IBS_STRESS_N", "262144"))
 s = bench.stress(ctx, dev, n, "smooth", reps=2)
 print("stress", s["solves_per_s"], flush=True)
+w = bench.sturm_sweep(ctx, dev, n, reps=2)
+print("sturm", w["sweeps_per_s"], flush=True)
