@@ -13,6 +13,15 @@
 #include "ibs_wave.hpp"
 
 namespace ibs {
+struct GeoArgs {
+  int n_surf, mnmax, mnmax_nyq, n_lines, N;
+  const double *xm, *xn, *xm_nyq, *xn_nyq;
+  const double* tab_mn; const double* tab_nyq; const double* scal;
+  const int* line_surf; const double* line_alpha; const double* theta;
+  long ld; double* geo; double* dPdrho;
+};
+hipError_t launch_geometry(const GeoArgs& a, hipStream_t st);   // ibs_geometry.hip
+
 LaunchTable& launch_table() {
   static LaunchTable t{};
   return t;
@@ -393,6 +402,52 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
   }
   a.geo = geo; a.theta0 = theta0; a.val = val; a.jac = jac; a.info = info ? info : d_info;
   HIPCHK(fn(a, ctx->stream));
+  return 0;
+}
+
+int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm,
+                               const double* xn, const double* xm_nyq, const double* xn_nyq, const double* tab_mn,
+                               const double* tab_nyq, const double* scal, int32_t n_lines, const int32_t* line_surf,
+                               const double* line_alpha, int32_t N, const double* theta, int64_t ld, double* geo,
+                               double* dPdrho, int32_t mem) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_surf <= 0 || mnmax <= 0 || mnmax_nyq <= 0 || n_lines < 0 || N < 2 || ld < N || !xm || !xn || !xm_nyq || !xn_nyq ||
+      !tab_mn || !tab_nyq || !scal || !line_surf || !line_alpha || !theta || !geo)
+    return fail(IBS_ERR_ARG, "bad arguments");
+  if (n_lines == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  ibs::GeoArgs a{};
+  a.n_surf = n_surf; a.mnmax = mnmax; a.mnmax_nyq = mnmax_nyq; a.n_lines = n_lines; a.N = N; a.ld = ld;
+  if (mem == IBS_MEM_HOST) {
+    for (int i = 0; i < n_lines; ++i)
+      if (line_surf[i] < 0 || line_surf[i] >= n_surf) return fail(IBS_ERR_ARG, "line_surf[%d]=%d out of range", i, line_surf[i]);
+    const size_t n_mn = (size_t)n_surf * 6 * mnmax, n_nyq = (size_t)n_surf * 7 * mnmax_nyq, n_geo = (size_t)8 * n_lines * ld;
+    size_t need = pad256(n_mn * 8) + pad256(n_nyq * 8) + 2 * pad256((size_t)mnmax * 8) + 2 * pad256((size_t)mnmax_nyq * 8) +
+                  pad256((size_t)n_surf * 48) + pad256((size_t)n_lines * 4) + 2 * pad256((size_t)n_lines * 8) +
+                  pad256((size_t)N * 8) + pad256(n_geo * 8) + 8192;
+    if (int r = ensure_ws(ctx, need)) return r;
+    Arena ar(ctx);
+    auto up = [&](const void* src, size_t bytes, void* dst) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
+    double* d_xm = ar.take<double>(mnmax); double* d_xn = ar.take<double>(mnmax);
+    double* d_xmq = ar.take<double>(mnmax_nyq); double* d_xnq = ar.take<double>(mnmax_nyq);
+    double* d_mn = ar.take<double>(n_mn); double* d_nyq = ar.take<double>(n_nyq); double* d_sc = ar.take<double>((size_t)n_surf * 6);
+    int* d_ls = ar.take<int>(n_lines); double* d_la = ar.take<double>(n_lines); double* d_th = ar.take<double>(N);
+    double* d_geo = ar.take<double>(n_geo); double* d_dP = ar.take<double>(n_lines);
+    HIPCHK(up(xm, (size_t)mnmax * 8, d_xm)); HIPCHK(up(xn, (size_t)mnmax * 8, d_xn));
+    HIPCHK(up(xm_nyq, (size_t)mnmax_nyq * 8, d_xmq)); HIPCHK(up(xn_nyq, (size_t)mnmax_nyq * 8, d_xnq));
+    HIPCHK(up(tab_mn, n_mn * 8, d_mn)); HIPCHK(up(tab_nyq, n_nyq * 8, d_nyq)); HIPCHK(up(scal, (size_t)n_surf * 48, d_sc));
+    HIPCHK(up(line_surf, (size_t)n_lines * 4, d_ls)); HIPCHK(up(line_alpha, (size_t)n_lines * 8, d_la)); HIPCHK(up(theta, (size_t)N * 8, d_th));
+    a.xm = d_xm; a.xn = d_xn; a.xm_nyq = d_xmq; a.xn_nyq = d_xnq; a.tab_mn = d_mn; a.tab_nyq = d_nyq; a.scal = d_sc;
+    a.line_surf = d_ls; a.line_alpha = d_la; a.theta = d_th; a.geo = d_geo; a.dPdrho = d_dP;
+    HIPCHK(ibs::launch_geometry(a, ctx->stream));
+    HIPCHK(hipMemcpyAsync(geo, d_geo, n_geo * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (dPdrho) HIPCHK(hipMemcpyAsync(dPdrho, d_dP, (size_t)n_lines * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  a.xm = xm; a.xn = xn; a.xm_nyq = xm_nyq; a.xn_nyq = xn_nyq; a.tab_mn = tab_mn; a.tab_nyq = tab_nyq; a.scal = scal;
+  a.line_surf = line_surf; a.line_alpha = line_alpha; a.theta = theta; a.geo = geo; a.dPdrho = dPdrho;
+  HIPCHK(ibs::launch_geometry(a, ctx->stream));
   return 0;
 }
 

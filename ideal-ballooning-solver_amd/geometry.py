@@ -1,0 +1,63 @@
+"""Field-line geometry producer.
+
+Host part: `SurfaceTables` = data-only counterpart of the reference's `vmec_splines` (utils.py:37-158)
+plus the per-surface spline evaluation at the top of `vmec_fieldlines` (utils.py:311-357).  It takes the
+plain wout tables (what `simsopt.mhd.vmec.Vmec.wout` exposes; SIMSOPT itself is not needed) and yields the
+Fourier coefficient vectors of each requested surface.  Radial splines are 1-D host work (scipy FITPACK,
+like the reference); everything per grid point runs on the GPU (`Context.fieldline_geometry`).
+"""
+import numpy as np
+
+NAMES_MN = ("rmnc", "zmns", "lmns", "d_rmnc_d_s", "d_zmns_d_s", "d_lmns_d_s")
+NAMES_NYQ = ("gmnc", "bmnc", "d_bmnc_d_s", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc")
+
+
+class SurfaceTables:
+    """per-surface inputs of the geometry kernel, packed as the C ABI wants them (include/ibs.h)"""
+
+    def __init__(self, s, xm, xn, xm_nyq, xn_nyq, tab_mn, tab_nyq, iota, d_iota_d_s, d_pressure_d_s, phiedge, Aminor_p):
+        self.s = np.ascontiguousarray(s, dtype=np.float64)
+        self.xm, self.xn = (np.ascontiguousarray(a, dtype=np.float64) for a in (xm, xn))
+        self.xm_nyq, self.xn_nyq = (np.ascontiguousarray(a, dtype=np.float64) for a in (xm_nyq, xn_nyq))
+        self.tab_mn = np.ascontiguousarray(tab_mn, dtype=np.float64)        # (n_surf, 6, mnmax)
+        self.tab_nyq = np.ascontiguousarray(tab_nyq, dtype=np.float64)      # (n_surf, 7, mnmax_nyq)
+        n = len(self.s)
+        self.scal = np.ascontiguousarray(np.stack([self.s, iota, d_iota_d_s, d_pressure_d_s,
+                                                   np.full(n, float(phiedge)), np.full(n, float(Aminor_p))], axis=1))
+        assert self.tab_mn.shape == (n, 6, len(self.xm)) and self.tab_nyq.shape == (n, 7, len(self.xm_nyq))
+
+    @classmethod
+    def from_arrays(cls, d):
+        """from a dict holding the per-surface vectors by name (e.g. tests/golden/G8_surface_tables.npz)"""
+        return cls(d["s"], d["xm"], d["xn"], d["xm_nyq"], d["xn_nyq"],
+                   np.stack([d[k] for k in NAMES_MN], axis=1), np.stack([d[k] for k in NAMES_NYQ], axis=1),
+                   d["iota"], d["d_iota_d_s"], d["d_pressure_d_s"], float(d["phiedge"]), float(d["Aminor_p"]))
+
+    @classmethod
+    def from_wout(cls, wout, svals):
+        """wout: mapping with rmnc, zmns, lmns, gmnc, bmnc, bsupvmnc, bsubsmns, bsubumnc, bsubvmnc stored
+        (mn, ns) as in simsopt's Vmec.wout, pres, iotas, phi (ns,), xm, xn, xm_nyq, xn_nyq, Aminor_p, ns."""
+        from scipy.interpolate import InterpolatedUnivariateSpline as Spl
+        ns = int(wout["ns"])
+        s_full = np.linspace(0, 1, ns)                     # vmec.s_full_grid
+        s_half = s_full[1:] - 0.5 * (s_full[1] - s_full[0])  # vmec.s_half_grid
+        svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))
+
+        def ev(tab, half, deriv=False):
+            tab = np.asarray(tab, dtype=np.float64)
+            res = np.empty((len(svals), tab.shape[0]))
+            for j in range(tab.shape[0]):
+                sp = Spl(s_half, tab[j, 1:]) if half else Spl(s_full, tab[j, :])   # utils.py:58-107
+                res[:, j] = (sp.derivative() if deriv else sp)(svals)
+            return res
+
+        mn = np.stack([ev(wout["rmnc"], False), ev(wout["zmns"], False), ev(wout["lmns"], True),
+                       ev(wout["rmnc"], False, True), ev(wout["zmns"], False, True), ev(wout["lmns"], True, True)], axis=1)
+        nyq = np.stack([ev(wout["gmnc"], True), ev(wout["bmnc"], True), ev(wout["bmnc"], True, True),
+                        ev(wout["bsupvmnc"], True), ev(wout["bsubsmns"], False), ev(wout["bsubumnc"], True),
+                        ev(wout["bsubvmnc"], True)], axis=1)
+        pres = Spl(s_half, np.asarray(wout["pres"], dtype=np.float64)[1:])          # utils.py:112
+        iota = Spl(s_half, np.asarray(wout["iotas"], dtype=np.float64)[1:])         # utils.py:118
+        return cls(svals, wout["xm"], wout["xn"], wout["xm_nyq"], wout["xn_nyq"], mn, nyq, iota(svals),
+                   iota.derivative()(svals), pres.derivative()(svals), float(np.asarray(wout["phi"])[-1]),
+                   float(wout["Aminor_p"]))

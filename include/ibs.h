@@ -82,6 +82,24 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
                        const double* theta0, double del_alpha, double* val, double* jac, int32_t* info,
                        int32_t mem);
 
+/* Field-line geometry on the device: the eight arrays of ball_scan.py:251-261 for
+ * n_lines field lines (surface index, alpha) on the theta_PEST grid theta[N].
+ * Replaces: the per-line arithmetic of vmec_fieldlines, utils.py:359-720 (theta_pest -> theta_vmec secant
+ * solve :391-416, Fourier synthesis :420-468, metric algebra :474-720); the radial splines of
+ * utils.py:37-158 / :311-357 stay on the host and provide, per surface,
+ *   tab_mn  [n_surf][6][mnmax]      rmnc zmns lmns d_rmnc_d_s d_zmns_d_s d_lmns_d_s
+ *   tab_nyq [n_surf][7][mnmax_nyq]  gmnc bmnc d_bmnc_d_s bsupvmnc bsubsmns bsubumnc bsubvmnc
+ *   scal    [n_surf][6]             s iota d_iota_d_s d_pressure_d_s phiedge Aminor_p
+ * and the mode numbers xm, xn [mnmax], xm_nyq, xn_nyq [mnmax_nyq] (xn includes nfp).
+ *   geo [8][n_lines][ld]: bmag gradpar_theta_pest cvdrift cvdrift0 gds2 gds21 gds22 gbdrift
+ *   dPdrho[n_lines] (optional): -0.5 mean((cvdrift - gbdrift) bmag^2), ball_scan.py:262.
+ * The first seven planes of geo and dPdrho are exactly the inputs of ibs_gamma_scan_f64. */
+int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm,
+                               const double* xn, const double* xm_nyq, const double* xn_nyq, const double* tab_mn,
+                               const double* tab_nyq, const double* scal, int32_t n_lines, const int32_t* line_surf,
+                               const double* line_alpha, int32_t N, const double* theta, int64_t ld, double* geo,
+                               double* dPdrho, int32_t mem);
+
 /* Number of eigenvalues of (T, F) strictly above shift[i] for each system (Sturm sequence).
  * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0). */
 int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,

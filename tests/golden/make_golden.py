@@ -336,8 +336,35 @@ def make_G7():
          s_og=np.linspace(0.05, 0.995, 48), s_op=np.linspace(0.01, 0.995, 48))
 
 
+def make_G8():
+    """Inputs of the field-line geometry (row F1): (a) the wout tables vmec_splines reads (utils.py:46-135),
+    copied as numbers from tests/comparn_w_COBRAVMEC/wout_NCSX_op.nc; (b) the spline-evaluated Fourier
+    coefficient vectors and profile scalars at four surfaces exactly as vmec_fieldlines forms them
+    (utils.py:311-357).  Outputs to pin against: the geometry arrays already stored in G3."""
+    v = DuckVmec(os.path.join(REF, "tests/comparn_w_COBRAVMEC/wout_NCSX_op.nc"))
+    w = v.wout
+    wout = {k: getattr(w, k) for k in ("rmnc", "zmns", "lmns", "gmnc", "bmnc", "bsupumnc", "bsupvmnc", "bsubsmns",
+                                       "bsubumnc", "bsubvmnc", "pres", "chi", "iotas", "phi", "xm", "xn", "xm_nyq",
+                                       "xn_nyq")}
+    wout.update(Aminor_p=np.array(w.Aminor_p), nfp=np.array(w.nfp), ns=np.array(w.ns))
+    save("G8_wout_ncsx_op.npz", **wout)
+    vs = ncsx_splines()
+    out = {}
+    svals = np.array([0.5, 0.7, 0.85, 0.95])
+    names_mn = ("rmnc", "zmns", "lmns", "d_rmnc_d_s", "d_zmns_d_s", "d_lmns_d_s")
+    names_nyq = ("gmnc", "bmnc", "d_bmnc_d_s", "bsupumnc", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc")
+    for nm in names_mn + names_nyq:
+        out[nm] = np.array([[spl(s) for spl in getattr(vs, nm)] for s in svals])
+    out["iota"] = vs.iota(svals)
+    out["d_iota_d_s"] = vs.d_iota_d_s(svals)
+    out["d_pressure_d_s"] = vs.d_pressure_d_s(svals)
+    out["pressure"] = vs.pressure(svals)
+    save("G8_surface_tables.npz", s=svals, xm=vs.xm, xn=vs.xn, xm_nyq=vs.xm_nyq, xn_nyq=vs.xn_nyq,
+         phiedge=np.array(vs.phiedge), Aminor_p=np.array(vs.Aminor_p), nfp=np.array(vs.nfp), **out)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7"]
+    todo = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
     for name in todo:
         t = time.time()
         globals()["make_" + name]()

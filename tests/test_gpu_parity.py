@@ -324,3 +324,37 @@ def test_subwave_scan_matches_full_wave(ctx, bo):
     assert np.abs(r["dgam_dtheta0"] - ref["dgam_dtheta0"]).max() < 1e-9
     assert np.abs(r["X"] - ref["X"]).max() < 1e-7
     assert np.abs(r5["gam"] - ref["gam"][:, :5]).max() < 1e-10
+
+
+def test_F1_fieldline_geometry_kernel(ctx, bo):
+    """device geometry (utils.py:359-720) against the arrays the reference produced (G3) and the oracle"""
+    import ibs_amd
+    import torch
+    from oracle import geometry_oracle as go
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    ref = dict(np.load(os.path.join(G, "G8_surface_tables.npz")))
+    tabs = ibs_amd.SurfaceTables.from_arrays(ref)
+    for N in (513, 1025):
+        th = bo.theta_grid(N)
+        lines = g3["lines_%d" % N]
+        surf = [int(np.argmin(np.abs(ref["s"] - s))) for s, a in lines]
+        r = ctx.fieldline_geometry(tabs, surf, lines[:, 1], th)
+        geo_ref = g3["geo_%d" % N]                                   # (n_lines, 8, N)
+        for q in range(8):
+            scale = np.abs(geo_ref[:, q]).max(axis=1, keepdims=True)
+            assert (np.abs(r["geo"][q] - geo_ref[:, q]) / scale).max() < 1e-10, q
+        assert np.abs(r["dPdrho"] - g3["dPdrho_%d" % N]).max() < 1e-12
+    # tables built by the data-only vmec_splines counterpart from the raw wout arrays
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    tabs2 = ibs_amd.SurfaceTables.from_wout(wout, ref["s"])
+    assert np.abs(tabs2.tab_mn - tabs.tab_mn).max() < 1e-12 and np.abs(tabs2.tab_nyq - tabs.tab_nyq).max() < 1e-11
+    # device-resident chain: geometry kernel -> scan kernel without leaving HBM
+    th = bo.theta_grid(513)
+    lines = g3["lines_513"]
+    surf = [int(np.argmin(np.abs(ref["s"] - s))) for s, a in lines]
+    dev = torch.device("cuda:0")
+    rd = ctx.fieldline_geometry(tabs, surf, lines[:, 1], th, device=dev)
+    t0 = torch.from_numpy(g3["theta0"]).to(dev)
+    sc = ctx.gamma_scan(th[1] - th[0], *[rd["geo"][k] for k in range(7)], rd["dPdrho"], t0)
+    assert np.abs(sc["gam"].cpu().numpy() - g3["gam_tight_513"]).max() < 1e-9
+    assert np.abs(sc["gam"].cpu().numpy() - g3["gam_513"]).max() < TOL
