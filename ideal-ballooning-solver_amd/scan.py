@@ -61,8 +61,15 @@ class BallooningScan:
     """Coarse (alpha, theta0) scan -> argmax -> L-BFGS-B refinement -> final solve, per surface."""
 
     def __init__(self, ctx, fieldlines, theta, rho_arr, nalpha=24, ntheta0=15, del_alpha=0.004,
-                 rank=0, world=1, dist=None, gather_device=None):
+                 rank=0, world=1, dist=None, gather_device=None, tables=None, device=None):
+        """fieldlines: host geometry callable (see module docstring), or None together with
+        tables=SurfaceTables (row F1): then rho_arr must equal tables.s and the geometry is produced on
+        `device` by the HIP geometry kernel and consumed there (nothing but scalars returns to the host)."""
         self.ctx = ctx
+        self.tables = tables
+        self.device = device
+        if tables is not None:
+            fieldlines = self._device_fieldlines_host
         self.fieldlines = fieldlines
         self.theta = np.asarray(theta, dtype=np.float64)
         self.h = float((self.theta[-1] - self.theta[0]) / (len(self.theta) - 1))
@@ -73,8 +80,24 @@ class BallooningScan:
         self.rank, self.world, self.dist, self.gather_device = rank, world, dist, gather_device
         self.own = shard_surfaces(len(self.rho_arr), rank, world)
 
+    def _device_fieldlines_host(self, s, alphas):
+        """geometry kernel behind the host-callable interface (used by the final solve / tests)"""
+        js = int(np.argmin(np.abs(self.tables.s - s)))
+        alphas = np.atleast_1d(np.asarray(alphas, dtype=np.float64))
+        r = self.ctx.fieldline_geometry(self.tables, [js] * len(alphas), alphas, self.theta)
+        return np.ascontiguousarray(np.transpose(r["geo"], (1, 0, 2)))
+
     # -- A5: coarse scan of the surfaces this rank owns, one launch
     def coarse(self):
+        if self.tables is not None and self.device is not None and self.own:
+            import torch
+            na = len(self.alpha_scan)
+            surf = np.repeat([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own], na)
+            r = self.ctx.fieldline_geometry(self.tables, surf, np.tile(self.alpha_scan, len(self.own)), self.theta,
+                                            device=self.device)
+            t0 = torch.from_numpy(self.theta0_scan).to(self.device)
+            out = self.ctx.gamma_scan(self.h, *[r["geo"][k] for k in range(7)], r["dPdrho"], t0)
+            return out["gam"].cpu().numpy().reshape(len(self.own), na, len(self.theta0_scan))
         geos = [np.asarray(self.fieldlines(self.rho_arr[k], self.alpha_scan)) for k in self.own]
         if not geos:
             return np.zeros((0, len(self.alpha_scan), len(self.theta0_scan)))

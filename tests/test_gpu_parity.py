@@ -358,3 +358,27 @@ def test_F1_fieldline_geometry_kernel(ctx, bo):
     sc = ctx.gamma_scan(th[1] - th[0], *[rd["geo"][k] for k in range(7)], rd["dPdrho"], t0)
     assert np.abs(sc["gam"].cpu().numpy() - g3["gam_tight_513"]).max() < 1e-9
     assert np.abs(sc["gam"].cpu().numpy() - g3["gam_513"]).max() < TOL
+
+
+def test_driver_with_device_geometry_reproduces_reference_scan(ctx, bo):
+    """ball_scan.py:248-295 on one NCSX_op surface with the geometry produced on the GPU: the coarse
+    24 x 15 table and its argmax against the reference trace (G5), then a refinement step."""
+    import ibs_amd
+    import torch
+    g5 = np.load(os.path.join(G, "G5_scan_trace.npz"))
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    s = float(g5["s"])
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, [s])
+    th = bo.theta_grid(513)
+    scan = ibs_amd.BallooningScan(ctx, None, th, [s], tables=tabs, device=torch.device("cuda:0"))
+    tab = scan.coarse()[0]
+    assert np.abs(tab - g5["gam_table"]).max() < TOL
+    a0, t0, sig, ij = ibs_amd.pick_start(tab, scan.alpha_scan, scan.theta0_scan)
+    assert ij == tuple(int(v) for v in g5["argmax"])
+    # objective + gradient at the reference's first L-BFGS-B evaluation point
+    x0 = g5["trace"][0]
+    val, jac = scan.obj_w_grad((x0[0], x0[1]), s)
+    assert abs(val - x0[2]) < TOL and np.abs(jac - x0[3:5]).max() < 1e-7
+    t_opt, a_opt, gam_opt, res = scan.refine(s, a0, t0)
+    assert gam_opt >= tab.max() - 1e-9
+    assert abs(gam_opt - float(g5["gam_opt"])) < 2e-6          # same local maximum as the reference run
