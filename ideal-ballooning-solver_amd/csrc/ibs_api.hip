@@ -19,6 +19,8 @@ struct GeoArgs {
   const double* tab_mn; const double* tab_nyq; const double* scal;
   const int* line_surf; const double* line_alpha; const double* theta;
   long ld; double* geo; double* dPdrho;
+  int nrows_mn, nrows_nyq; const int* rows_mn; const int* rows_nyq;
+  double dn_mn, dn_nyq;
 };
 hipError_t launch_geometry(const GeoArgs& a, hipStream_t st);   // ibs_geometry.hip
 
@@ -409,8 +411,11 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
                                const double* xn, const double* xm_nyq, const double* xn_nyq, const double* tab_mn,
                                const double* tab_nyq, const double* scal, int32_t n_lines, const int32_t* line_surf,
                                const double* line_alpha, int32_t N, const double* theta, int64_t ld, double* geo,
-                               double* dPdrho, int32_t mem) {
+                               double* dPdrho, int32_t nrows_mn, const int32_t* rows_mn, int32_t nrows_nyq,
+                               const int32_t* rows_nyq, double dn_mn, double dn_nyq, int32_t mem) {
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (nrows_mn < 0 || nrows_nyq < 0 || (nrows_mn > 0 && !rows_mn) || (nrows_nyq > 0 && !rows_nyq))
+    return fail(IBS_ERR_ARG, "bad row tables");
   if (n_surf <= 0 || mnmax <= 0 || mnmax_nyq <= 0 || n_lines < 0 || N < 2 || ld < N || !xm || !xn || !xm_nyq || !xn_nyq ||
       !tab_mn || !tab_nyq || !scal || !line_surf || !line_alpha || !theta || !geo)
     return fail(IBS_ERR_ARG, "bad arguments");
@@ -424,7 +429,7 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
     const size_t n_mn = (size_t)n_surf * 6 * mnmax, n_nyq = (size_t)n_surf * 7 * mnmax_nyq, n_geo = (size_t)8 * n_lines * ld;
     size_t need = pad256(n_mn * 8) + pad256(n_nyq * 8) + 2 * pad256((size_t)mnmax * 8) + 2 * pad256((size_t)mnmax_nyq * 8) +
                   pad256((size_t)n_surf * 48) + pad256((size_t)n_lines * 4) + 2 * pad256((size_t)n_lines * 8) +
-                  pad256((size_t)N * 8) + pad256(n_geo * 8) + 8192;
+                  pad256((size_t)N * 8) + pad256(n_geo * 8) + pad256((size_t)nrows_mn * 8) + pad256((size_t)nrows_nyq * 8) + 8192;
     if (int r = ensure_ws(ctx, need)) return r;
     Arena ar(ctx);
     auto up = [&](const void* src, size_t bytes, void* dst) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
@@ -439,6 +444,11 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
     HIPCHK(up(line_surf, (size_t)n_lines * 4, d_ls)); HIPCHK(up(line_alpha, (size_t)n_lines * 8, d_la)); HIPCHK(up(theta, (size_t)N * 8, d_th));
     a.xm = d_xm; a.xn = d_xn; a.xm_nyq = d_xmq; a.xn_nyq = d_xnq; a.tab_mn = d_mn; a.tab_nyq = d_nyq; a.scal = d_sc;
     a.line_surf = d_ls; a.line_alpha = d_la; a.theta = d_th; a.geo = d_geo; a.dPdrho = d_dP;
+    if (nrows_mn > 0 && nrows_nyq > 0) {
+      int* d_r1 = ar.take<int>((size_t)2 * nrows_mn); int* d_r2 = ar.take<int>((size_t)2 * nrows_nyq);
+      HIPCHK(up(rows_mn, (size_t)nrows_mn * 8, d_r1)); HIPCHK(up(rows_nyq, (size_t)nrows_nyq * 8, d_r2));
+      a.nrows_mn = nrows_mn; a.nrows_nyq = nrows_nyq; a.rows_mn = d_r1; a.rows_nyq = d_r2; a.dn_mn = dn_mn; a.dn_nyq = dn_nyq;
+    }
     HIPCHK(ibs::launch_geometry(a, ctx->stream));
     HIPCHK(hipMemcpyAsync(geo, d_geo, n_geo * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (dPdrho) HIPCHK(hipMemcpyAsync(dPdrho, d_dP, (size_t)n_lines * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -447,6 +457,7 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
   }
   a.xm = xm; a.xn = xn; a.xm_nyq = xm_nyq; a.xn_nyq = xn_nyq; a.tab_mn = tab_mn; a.tab_nyq = tab_nyq; a.scal = scal;
   a.line_surf = line_surf; a.line_alpha = line_alpha; a.theta = theta; a.geo = geo; a.dPdrho = dPdrho;
+  if (nrows_mn > 0 && nrows_nyq > 0) { a.nrows_mn = nrows_mn; a.nrows_nyq = nrows_nyq; a.rows_mn = rows_mn; a.rows_nyq = rows_nyq; a.dn_mn = dn_mn; a.dn_nyq = dn_nyq; }
   HIPCHK(ibs::launch_geometry(a, ctx->stream));
   return 0;
 }

@@ -12,6 +12,24 @@ NAMES_MN = ("rmnc", "zmns", "lmns", "d_rmnc_d_s", "d_zmns_d_s", "d_lmns_d_s")
 NAMES_NYQ = ("gmnc", "bmnc", "d_bmnc_d_s", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc")
 
 
+def mode_rows(xm, xn, dn=None, max_len=64):
+    """runs of modes with equal m and n advancing by the common step dn (VMEC's ordering: dn = nfp) as int32
+    (nrows, 2) = {first, count}, plus dn.  Any ordering is valid: runs simply get shorter (down to 1)."""
+    xm = np.asarray(xm); xn = np.asarray(xn)
+    if dn is None:
+        d = np.diff(xn)[np.diff(xm) == 0]
+        dn = float(np.median(d)) if len(d) else 1.0
+    rows = []
+    k, n = 0, len(xm)
+    while k < n:
+        e = k + 1
+        while e < n and e - k < max_len and xm[e] == xm[k] and abs((xn[e] - xn[e - 1]) - dn) <= 1e-12 * max(1.0, abs(dn)):
+            e += 1
+        rows.append((k, e - k))
+        k = e
+    return np.ascontiguousarray(rows, dtype=np.int32), dn
+
+
 class SurfaceTables:
     """per-surface inputs of the geometry kernel, packed as the C ABI wants them (include/ibs.h)"""
 
@@ -25,6 +43,8 @@ class SurfaceTables:
         self.scal = np.ascontiguousarray(np.stack([self.s, iota, d_iota_d_s, d_pressure_d_s,
                                                    np.full(n, float(phiedge)), np.full(n, float(Aminor_p))], axis=1))
         assert self.tab_mn.shape == (n, 6, len(self.xm)) and self.tab_nyq.shape == (n, 7, len(self.xm_nyq))
+        self.rows_mn, self.dn_mn = mode_rows(self.xm, self.xn)
+        self.rows_nyq, self.dn_nyq = mode_rows(self.xm_nyq, self.xn_nyq)
 
     @classmethod
     def from_arrays(cls, d):

@@ -159,7 +159,7 @@ class Context:
                                            pinfo, ar.mem), "ibs_obj_w_grad_f64")
         return (val, jac, info) if want_info else (val, jac)
 
-    def fieldline_geometry(self, tables, line_surf, line_alpha, theta, device=None):
+    def fieldline_geometry(self, tables, line_surf, line_alpha, theta, device=None, use_rows=True):
         """geometry of the field lines (tables.s[line_surf[i]], line_alpha[i]) on the grid theta (row F1).
         Returns dict(geo=(8, n_lines, N), dPdrho=(n_lines,)); geo[0..6] + dPdrho feed gamma_scan directly.
         device=None: numpy in / numpy out (staged);  device=torch.device(...): results stay in HBM."""
@@ -171,28 +171,34 @@ class Context:
         if ls.size and (ls.min() < 0 or ls.max() >= len(tables.s)):
             raise IbsError("line_surf out of range")
         host = [tables.xm, tables.xn, tables.xm_nyq, tables.xn_nyq, tables.tab_mn, tables.tab_nyq, tables.scal]
+        rows = [tables.rows_mn, tables.rows_nyq] if use_rows else [np.zeros((0, 2), np.int32)] * 2
         if device is None:
             geo = np.empty((8, n_lines, N)); dP = np.empty(n_lines)
             p = lambda a: C.c_void_p(a.ctypes.data)
             check(self._lib.ibs_fieldline_geometry_f64(self._h, len(tables.s), len(tables.xm), len(tables.xm_nyq),
                                                        *[p(a) for a in host], n_lines, p(ls), p(la), N, p(th), N, p(geo),
-                                                       p(dP), MEM_HOST), "ibs_fieldline_geometry_f64")
+                                                       p(dP), len(rows[0]), p(rows[0]), len(rows[1]), p(rows[1]),
+                                                       float(tables.dn_mn), float(tables.dn_nyq), MEM_HOST), "ibs_fieldline_geometry_f64")
             return dict(geo=geo, dPdrho=dP)
         import torch
         key = id(tables)
         cache = getattr(self, "_tab_cache", {})
         if key not in cache:      # tables are uploaded once and stay resident
-            cache[key] = [torch.from_numpy(a).to(device) for a in host]
+            cache[key] = [torch.from_numpy(a).to(device) for a in host + [tables.rows_mn, tables.rows_nyq]]
             self._tab_cache = cache
-        dev = cache[key]
+        dev = cache[key][:7]
+        d_rows = cache[key][7:]
         d_ls, d_la, d_th = (torch.from_numpy(a).to(device) for a in (ls, la, th))
         geo = torch.empty((8, n_lines, N), dtype=torch.float64, device=device)
         dP = torch.empty((n_lines,), dtype=torch.float64, device=device)
         self._stream_from_torch(geo)
         p = lambda t: C.c_void_p(t.data_ptr())
+        nr = (len(tables.rows_mn), len(tables.rows_nyq)) if use_rows else (0, 0)
         check(self._lib.ibs_fieldline_geometry_f64(self._h, len(tables.s), len(tables.xm), len(tables.xm_nyq),
                                                    *[p(t) for t in dev], n_lines, p(d_ls), p(d_la), N, p(d_th), N, p(geo),
-                                                   p(dP), MEM_DEVICE), "ibs_fieldline_geometry_f64")
+                                                   p(dP), nr[0], p(d_rows[0]), nr[1], p(d_rows[1]), float(tables.dn_mn), float(tables.dn_nyq),
+                                                   MEM_DEVICE),
+              "ibs_fieldline_geometry_f64")
         self._keep = (d_ls, d_la, d_th)
         return dict(geo=geo, dPdrho=dP)
 

@@ -93,12 +93,16 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
  * and the mode numbers xm, xn [mnmax], xm_nyq, xn_nyq [mnmax_nyq] (xn includes nfp).
  *   geo [8][n_lines][ld]: bmag gradpar_theta_pest cvdrift cvdrift0 gds2 gds21 gds22 gbdrift
  *   dPdrho[n_lines] (optional): -0.5 mean((cvdrift - gbdrift) bmag^2), ball_scan.py:262.
+ *   rows_mn [nrows_mn][2], rows_nyq [nrows_nyq][2] (optional, nrows = 0 to omit): {first mode, count} of each
+ *   run of modes with equal m and n advancing by the common step dn_mn / dn_nyq (= nfp in VMEC's own
+ *   ordering); enables the rotation-recurrence kernel (no sincos per mode).
  * The first seven planes of geo and dPdrho are exactly the inputs of ibs_gamma_scan_f64. */
 int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm,
                                const double* xn, const double* xm_nyq, const double* xn_nyq, const double* tab_mn,
                                const double* tab_nyq, const double* scal, int32_t n_lines, const int32_t* line_surf,
                                const double* line_alpha, int32_t N, const double* theta, int64_t ld, double* geo,
-                               double* dPdrho, int32_t mem);
+                               double* dPdrho, int32_t nrows_mn, const int32_t* rows_mn, int32_t nrows_nyq,
+                               const int32_t* rows_nyq, double dn_mn, double dn_nyq, int32_t mem);
 
 /* Number of eigenvalues of (T, F) strictly above shift[i] for each system (Sturm sequence).
  * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0). */

@@ -338,12 +338,13 @@ def test_F1_fieldline_geometry_kernel(ctx, bo):
         th = bo.theta_grid(N)
         lines = g3["lines_%d" % N]
         surf = [int(np.argmin(np.abs(ref["s"] - s))) for s, a in lines]
-        r = ctx.fieldline_geometry(tabs, surf, lines[:, 1], th)
         geo_ref = g3["geo_%d" % N]                                   # (n_lines, 8, N)
-        for q in range(8):
-            scale = np.abs(geo_ref[:, q]).max(axis=1, keepdims=True)
-            assert (np.abs(r["geo"][q] - geo_ref[:, q]) / scale).max() < 1e-10, q
-        assert np.abs(r["dPdrho"] - g3["dPdrho_%d" % N]).max() < 1e-12
+        for use_rows in (True, False):          # rotation-recurrence kernel and the one-sincos-per-mode kernel
+            r = ctx.fieldline_geometry(tabs, surf, lines[:, 1], th, use_rows=use_rows)
+            for q in range(8):
+                scale = np.abs(geo_ref[:, q]).max(axis=1, keepdims=True)
+                assert (np.abs(r["geo"][q] - geo_ref[:, q]) / scale).max() < 1e-10, (q, use_rows)
+            assert np.abs(r["dPdrho"] - g3["dPdrho_%d" % N]).max() < 1e-12
     # tables built by the data-only vmec_splines counterpart from the raw wout arrays
     wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
     tabs2 = ibs_amd.SurfaceTables.from_wout(wout, ref["s"])
