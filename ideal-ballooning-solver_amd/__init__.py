@@ -8,3 +8,4 @@ from .solver import Context, ScanPlan, default_context  # noqa: F401
 from .operators import gamma_ball_full, dPdrho_of, uniform_spacing, make_obj_w_grad  # noqa: F401
 from .scan import BallooningScan, shard_surfaces, gather_surfaces, pick_start, append_history, GEO_ORDER  # noqa: F401
 from .geometry import SurfaceTables  # noqa: F401
+from .objective import ballooning_objective, dof_fd_gradient, dof_steps, shard_dofs, allreduce_dof_vector  # noqa: F401

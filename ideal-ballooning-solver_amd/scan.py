@@ -126,10 +126,88 @@ class BallooningScan:
         r = self.ctx.gamma_scan(self.h, *[geo[k][None] for k in range(7)], np.array([dP]), np.array([t]))
         return t, a, float(np.asarray(r["gam"])[0, 0]), res
 
+    # -- F2: all owned surfaces refined in lockstep; every evaluation of every surface is ONE batched launch
+    def batched_obj_w_grad(self, surf_idx, X):
+        """objective and gradient at X[k] = (alpha, theta0) of surface surf_idx[k] for all k at once
+        (device geometry for the 3 n lines, then the fused obj_w_grad kernel).  Returns (val (n,), jac (n, 2))."""
+        n = len(surf_idx)
+        d = self.del_alpha
+        al = np.stack([X[:, 0] - 0.5 * d, X[:, 0], X[:, 0] + 0.5 * d], axis=1).reshape(-1)
+        r = self.ctx.fieldline_geometry(self.tables, np.repeat(surf_idx, 3), al, self.theta, device=self.device)
+        N = len(self.theta)
+        geo = r["geo"].view(8, n, 3, N).permute(1, 2, 0, 3).contiguous()
+        import torch
+        t0 = torch.from_numpy(np.ascontiguousarray(X[:, 1])).to(self.device)
+        val, jac = self.ctx.obj_w_grad(self.h, geo, t0, d)
+        return val.cpu().numpy(), jac.cpu().numpy()
+
+    def refine_batched(self, starts, maxiter=30, ftol=5.0e-11, gtol=2.0e-8):
+        """bounded quasi-Newton (projected BFGS, Armijo backtracking) on (alpha, theta0) in
+        [0, pi] x [0, pi/2] for every owned surface at once -- the batched counterpart of the per-surface
+        scipy L-BFGS-B call of ball_scan.py:307-314 (same bounds, tolerances and iteration cap).
+        starts: (n, 2).  Returns (x_opt (n, 2), f_opt (n,) = -gam, n_evals)."""
+        lo = np.array([0.0, 0.0]); hi = np.array([np.pi, 0.5 * np.pi])
+        surf = np.array([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own])
+        n = len(surf)
+        x = np.clip(np.asarray(starts, dtype=np.float64).reshape(n, 2), lo, hi)
+        f, g = self.batched_obj_w_grad(surf, x)
+        nev = 1
+        H = np.tile(np.eye(2), (n, 1, 1))
+        active = np.ones(n, dtype=bool)
+
+        def proj_grad(x, g):
+            pg = g.copy()
+            pg[(x <= lo) & (g > 0)] = 0.0
+            pg[(x >= hi) & (g < 0)] = 0.0
+            return pg
+
+        for it in range(maxiter):
+            pg = proj_grad(x, g)
+            active &= np.max(np.abs(pg), axis=1) > gtol
+            if not active.any():
+                break
+            dvec = -np.einsum("kij,kj->ki", H, pg)
+            bad = np.einsum("ki,ki->k", dvec, pg) >= 0          # not a descent direction: steepest descent
+            dvec[bad] = -pg[bad]
+            # first trial step: at most 0.3 rad, never beyond the box
+            nrm = np.maximum(np.max(np.abs(dvec), axis=1), 1e-300)
+            t = np.minimum(1.0, 0.3 / nrm)
+            xn = x.copy(); fn = f.copy(); gn = g.copy()
+            todo = active.copy()
+            for ls in range(12):
+                xt = np.clip(x + t[:, None] * dvec, lo, hi)
+                idx = np.nonzero(todo)[0]
+                ft, gt = self.batched_obj_w_grad(surf[idx], xt[idx])
+                nev += 1
+                ok = ft <= f[idx] + 1e-4 * np.einsum("ki,ki->k", pg[idx], xt[idx] - x[idx])
+                acc = idx[ok]
+                xn[acc] = xt[acc]; fn[acc] = ft[ok]; gn[acc] = gt[ok]
+                todo[acc] = False
+                t[idx[~ok]] *= 0.35
+                if not todo.any():
+                    break
+            active &= ~todo                                      # line search failed: stop that surface
+            sk = xn - x; yk = gn - g
+            sy = np.einsum("ki,ki->k", sk, yk)
+            for k in np.nonzero(active & (sy > 1e-14))[0]:       # BFGS update of the inverse Hessian
+                rho = 1.0 / sy[k]
+                V = np.eye(2) - rho * np.outer(sk[k], yk[k])
+                H[k] = V @ H[k] @ V.T + rho * np.outer(sk[k], sk[k])
+            small = np.abs(f - fn) <= ftol * np.maximum(np.maximum(np.abs(f), np.abs(fn)), 1.0)
+            x, f, g = xn, fn, gn
+            active &= ~small
+        return x, f, nev
+
     def run(self, refine=True):
         """returns (theta0_arr, alpha_arr, gam_arr), each (nsurfs,), identical on every rank"""
         tabs = self.coarse()
         rows = []
+        if refine and self.tables is not None and self.device is not None and self.own:
+            starts = np.array([pick_start(tab, self.alpha_scan, self.theta0_scan)[:2] for tab in tabs])
+            xo, fo, _ = self.refine_batched(starts)
+            local = np.stack([xo[:, 1], xo[:, 0], -fo], axis=1)
+            full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device)
+            return full[:, 0], full[:, 1], full[:, 2]
         for k, tab in zip(self.own, tabs):
             a0, t0, sigma0, ij = pick_start(tab, self.alpha_scan, self.theta0_scan)
             if refine:

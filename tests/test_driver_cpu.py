@@ -102,3 +102,47 @@ def test_history_files_follow_reference_append_semantics(tmp_path):
     assert out["ball_gam"].shape == (2, 3) and np.array_equal(np.load(tmp_path / "ball_gam3.npy")[1], 2 * g)
     out = ibs_amd.append_history(str(tmp_path), 3, 2, 3 * g, g, g)
     assert out["ball_theta0"].shape == (3, 3)
+
+
+def test_objective_and_dof_gradient_follow_reference_formulas():
+    rng = np.random.default_rng(0)
+    ndof, nsurf = 6, 5
+    gam = rng.uniform(-6e-4, 4e-4, size=(ndof + 1, nsurf))
+    f_other = rng.uniform(0.5, 1.0, size=ndof + 1)
+    f0 = ibs_amd.ballooning_objective(f_other, gam, gamma_thresh=-2e-4, prefac=50.0)
+    for i in range(ndof + 1):      # sims_runner_NCSX.py:254-257 written out
+        assert abs(f0[i] - (f_other[i] + 50.0 * sum(max(g + 2e-4, 0.0) for g in gam[i]))) < 1e-15
+    x0 = rng.uniform(-0.2, 0.2, size=ndof)
+    isabs = np.array([0, 1, 0, 0, 1, 0, 0])
+    steps = ibs_amd.dof_steps(x0, isabs)
+    assert steps[1] == 1e-3 and abs(steps[2] - 2e-3 * x0[1]) < 1e-18
+    df = ibs_amd.dof_fd_gradient(f0, steps)
+    assert df.shape == (ndof,)
+    assert abs(df[2] - (f0[3] - f0[0]) / steps[3] * 0.5 / np.sqrt(f0[0])) < 1e-12
+
+
+def _worker_dof(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    own = ibs_amd.shard_dofs(7, rank, world)
+    full = ibs_amd.allreduce_dof_vector([10.0 + k for k in own], own, 7, world, dist)
+    q.put((rank, full.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_dof_allreduce():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_dof, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == [10.0 + k for k in range(7)]

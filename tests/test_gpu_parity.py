@@ -383,3 +383,25 @@ def test_driver_with_device_geometry_reproduces_reference_scan(ctx, bo):
     t_opt, a_opt, gam_opt, res = scan.refine(s, a0, t0)
     assert gam_opt >= tab.max() - 1e-9
     assert abs(gam_opt - float(g5["gam_opt"])) < 2e-6          # same local maximum as the reference run
+
+
+def test_F2_batched_refinement_matches_per_surface_lbfgsb(ctx, bo):
+    """all surfaces refined in lockstep (one batched launch per evaluation) against the per-surface
+    scipy L-BFGS-B path of ball_scan.py:307-314"""
+    import ibs_amd
+    import torch
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    svals = np.array([0.6, 0.8483, 0.9])
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
+    th = bo.theta_grid(513)
+    scan = ibs_amd.BallooningScan(ctx, None, th, svals, nalpha=12, ntheta0=8, tables=tabs, device=torch.device("cuda:0"))
+    tabs_c = scan.coarse()
+    starts = np.array([ibs_amd.pick_start(t, scan.alpha_scan, scan.theta0_scan)[:2] for t in tabs_c])
+    xo, fo, nev = scan.refine_batched(starts)
+    assert nev < 120
+    for k, s in enumerate(svals):
+        t_opt, a_opt, gam_opt, res = scan.refine(s, starts[k, 0], starts[k, 1])
+        assert -fo[k] >= tabs_c[k].max() - 1e-9                        # never below the coarse maximum
+        assert abs(-fo[k] - gam_opt) < 5e-7, (k, -fo[k], gam_opt)       # same local maximum
+    t0, al, gam = scan.run()
+    assert np.abs(gam + fo).max() < 1e-12
