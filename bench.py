@@ -165,6 +165,35 @@ def sturm_sweep(ctx, device, n_sys, reps=5):
                               kernel="k_sturm_count<double,8>", bytes_per_sweep=bytes_per))
 
 
+def warm_rescan(ctx, device, h, geo7, dP_d, th0_d, reps=20):
+    """config-4 pattern (FD gradient over boundary DOFs, sims_runner_NCSX.py:151-276): the batch of a
+    DOF-perturbed equilibrium (geometry changed by rel 2e-3, create_dict.py:70) re-scanned with the base
+    equilibrium's eigenvalues as warm start."""
+    import torch
+    base = ctx.gamma_scan(h, *geo7, dP_d, th0_d)
+    pert = [g.clone() for g in geo7]
+    for k in (4, 5, 6):
+        pert[k] *= 1.002
+    pert[2] *= 0.999
+    cold = ctx.gamma_scan(h, *pert, dP_d, th0_d, want_info=True)
+    width = float(3 * (cold["lam"] - base["lam"]).abs().max().item())
+    warm = ctx.gamma_scan(h, *pert, dP_d, th0_d, want_info=True, lam_guess=base["lam"], guess_width=width)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        ctx.gamma_scan(h, *pert, dP_d, th0_d, lam_guess=base["lam"], guess_width=width)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+    n = cold["lam"].numel()
+    return dict(workload="re-scan of a DOF-perturbed batch (rel 2e-3) warm-started from the base scan, same shape as the step",
+                solves_per_s=n / (ms * 1e-3), ms_per_launch_incl_host=ms,
+                sweeps_cold=float((cold["info"] & 0xffff).double().mean().item()),
+                sweeps_warm=float((warm["info"] & 0xffff).double().mean().item()),
+                max_abs_dgam_warm_vs_cold=float((warm["gam"] - cold["gam"]).abs().max().item()), guess_width=width)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +293,7 @@ def main():
             out["stress"] = stress(ctx, device, args.stress_systems, "smooth")
             out["stress_rough"] = stress(ctx, device, max(args.stress_systems // 4, 1024), "rough")
             out["sturm_sweep"] = sturm_sweep(ctx, device, args.stress_systems)
+            out["warm_rescan"] = warm_rescan(ctx, device, h, geo7, dP_d, th0_d)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -268,12 +268,14 @@ int ibs_solve_gcf_f32(ibs_ctx* ctx, int64_t n_sys, int32_t N, float h, const flo
   return solve_gcf_impl<float>(ctx, n_sys, N, h, g, c, f, ld, lam, gam, X, dX, info, mem, ibs::launch_table().gcf_f32);
 }
 
-int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
-                       const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
-                       const double* gds2, const double* gds21, const double* gds22, int64_t ld,
-                       const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
-                       double* dX, double* dth0, int32_t* info, int32_t mem) {
+static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
+                           const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
+                           const double* gds2, const double* gds21, const double* gds22, int64_t ld,
+                           const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
+                           double* dX, double* dth0, int32_t* info, int32_t mem, const double* lam_guess,
+                           double guess_width) {
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (lam_guess && !(guess_width > 0)) return fail(IBS_ERR_ARG, "guess_width must be > 0");
   if (n_lines < 0 || n_theta0 < 0 || !bmag || !gradpar || !cvdrift || !cvdrift0 || !gds2 || !gds21 || !gds22 ||
       !dPdrho || !theta0 || ld < N)
     return fail(IBS_ERR_ARG, "bad arguments (n_lines=%d n_theta0=%d ld=%lld N=%d)", n_lines, n_theta0, (long long)ld, N);
@@ -288,7 +290,7 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
   int G = 1, cap = ibs::scan_max_threads(M) / 64;
   {
     const int P = pick_lanes(ctx, N, (long)n_lines * n_theta0);
-    if (P != 64 && n_theta0 % (64 / P) == 0) {
+    if (P != 64 && n_theta0 % (64 / P) == 0 && !lam_guess) {
       const int Mg = (N - 2 + P - 1) / P;
       auto fg = ibs::launch_table().scan_f64_g[P == 32 ? 0 : 1][Mg];
       if (fg) { fn = fg; M = Mg; G = 64 / P; cap = ibs::scan_max_threads_g(Mg) / 64; }
@@ -316,7 +318,7 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
   const size_t n_sys = (size_t)n_lines * n_theta0;
   if (mem == IBS_MEM_HOST) {
     const size_t in_elems = (size_t)n_lines * ld, out_elems = n_sys * N;
-    size_t need = 7 * pad256(in_elems * 8) + pad256(n_lines * 8) + pad256(n_theta0 * 8) + 3 * pad256(n_sys * 8) +
+    size_t need = 7 * pad256(in_elems * 8) + pad256(n_lines * 8) + pad256(n_theta0 * 8) + 4 * pad256(n_sys * 8) +
                   2 * pad256(out_elems * 8) + pad256(n_sys * 4) + 8192;
     if (int r = ensure_ws(ctx, need)) return r;
     Arena ar(ctx);
@@ -334,6 +336,11 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
     int* d_info = ar.take<int>(n_sys); int* d_nbad = ar.take<int>(1);
     a.bmag = dev[0]; a.gradpar = dev[1]; a.cvdrift = dev[2]; a.cvdrift0 = dev[3]; a.gds2 = dev[4]; a.gds21 = dev[5]; a.gds22 = dev[6];
     a.dPdrho = ddP; a.theta0 = dt0; a.gam = dgam; a.lam = dlam; a.X = dX_; a.dX = ddX; a.dth0 = dth0 ? dd : nullptr; a.info = d_info;
+    if (lam_guess) {
+      double* dguess = ar.take<double>(n_sys);
+      HIPCHK(hipMemcpyAsync(dguess, lam_guess, n_sys * 8, hipMemcpyHostToDevice, ctx->stream));
+      a.lam_guess = dguess; a.guess_width = guess_width;
+    }
     HIPCHK(fn(a, ctx->stream));
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
@@ -350,8 +357,28 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
   }
   a.bmag = bmag; a.gradpar = gradpar; a.cvdrift = cvdrift; a.cvdrift0 = cvdrift0; a.gds2 = gds2; a.gds21 = gds21; a.gds22 = gds22;
   a.dPdrho = dPdrho; a.theta0 = theta0; a.gam = gam; a.lam = lam; a.X = X; a.dX = dX; a.dth0 = dth0; a.info = info;
+  a.lam_guess = lam_guess; a.guess_width = guess_width;
   HIPCHK(fn(a, ctx->stream));
   return 0;
+}
+
+int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
+                       const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
+                       const double* gds2, const double* gds21, const double* gds22, int64_t ld,
+                       const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
+                       double* dX, double* dth0, int32_t* info, int32_t mem) {
+  return gamma_scan_impl(ctx, n_lines, n_theta0, N, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, ld, dPdrho,
+                         theta0, gam, lam, X, dX, dth0, info, mem, nullptr, 0.0);
+}
+
+int ibs_gamma_scan_warm_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
+                            const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
+                            const double* gds2, const double* gds21, const double* gds22, int64_t ld,
+                            const double* dPdrho, const double* theta0, const double* lam_guess, double guess_width,
+                            double* gam, double* lam, double* X, double* dX, double* dth0, int32_t* info, int32_t mem) {
+  if (!lam_guess) return fail(IBS_ERR_ARG, "lam_guess is null");
+  return gamma_scan_impl(ctx, n_lines, n_theta0, N, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, ld, dPdrho,
+                         theta0, gam, lam, X, dX, dth0, info, mem, lam_guess, guess_width);
 }
 
 int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const double* geo, int64_t ld,

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
                                                      const T* __restrict__ gds22, long ld,
                                                      const T* __restrict__ dPdrho, const T* __restrict__ theta0,
                                                      T* gam_out, T* lam_out, T* X_out, T* dX_out, T* dth0_out,
-                                                     int* info_out) {
+                                                     int* info_out, const T* __restrict__ lam_guess, T guess_width) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -214,10 +214,10 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
   const bool bad = ws.setup(src, N, h);
-  T lam = T(0);
-  if (!bad) lam = ws.solve(inf);
-  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   const long sys = (long)line * n_theta0 + it0c;
+  T lam = T(0);
+  if (!bad) lam = lam_guess ? ws.solve(inf, true, lam_guess[sys], guess_width) : ws.solve(inf);
+  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   finish<T, M, SrcGeo<T>, true>(ws, src, N, h, Xs, lam, inf, sys, valid ? lam_out : nullptr,
                                 valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
                                 valid ? dth0_out : nullptr, valid ? info_out : nullptr);
@@ -454,7 +454,7 @@ static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   dim3 grid((unsigned)(((a.n_theta0 + wpb - 1) / wpb) * a.n_lines));
   hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
                      a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
-                     a.dX, a.dth0, a.info);
+                     a.dX, a.dth0, a.info, a.lam_guess, a.guess_width);
   return hipGetLastError();
 }
 template <typename T>

@@ -18,6 +18,7 @@ struct ScanArgs {
   const T *bmag, *gradpar, *cvdrift, *cvdrift0, *gds2, *gds21, *gds22; long ld;
   const T *dPdrho, *theta0;
   T *gam, *lam, *X, *dX, *dth0; int* info; int wpb;
+  const T* lam_guess; T guess_width;     // optional warm start ([n_lines][n_theta0], absolute width); null = cold
 };
 template <typename T>
 struct SturmArgs {

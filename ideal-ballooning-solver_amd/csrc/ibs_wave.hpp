@@ -415,10 +415,19 @@ struct WaveSolver {
 #ifdef IBS_TRACE
   T* trace = nullptr;   // debug builds only (tools/trace_solve.hip): 5 values per iteration
 #endif
-  __device__ __forceinline__ T solve(SolveInfo& inf) {
+  // Optional warm start: `guess` is an estimate of lam_max from a nearby problem (previous optimizer
+  // iteration, DOF-perturbed equilibrium: sims_runner_NCSX.py:151-276 re-scans 72 perturbed equilibria),
+  // `width` its expected error.  The first shift is guess + width; if the count says lam_max is still
+  // above, the shift walks up geometrically until the count certifies an upper bound.
+  __device__ __forceinline__ T solve(SolveInfo& inf, bool warm = false, T guess = T(0), T width = T(0)) {
     // f64: 64 ulp of ||A||;  f32: 8 ulp (the counts themselves are only good to ~eps32*||A||)
     const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
     T sig = hi, rej = -T(1), lam = hi;
+    bool expand = false;
+    T wstep = T(0);
+    if (warm && finite_of(guess) && width > T(0) && guess + width < hi && guess + width > lo) {
+      sig = guess + width; expand = true; wstep = T(4) * width;
+    }
     T off_up = tol, off_dn = tol;   // how far beyond the estimate the next certificate is placed
     T rho_trust = hi;
     int aimed = 0;                  // +1 / -1: the last proposal was an upper / lower certificate attempt
@@ -429,6 +438,10 @@ struct WaveSolver {
       const int C = sweep_fwd(sig);
       ++it;
       if (C == 0) hi = xmin(hi, sig); else lo = xmax(lo, sig);
+      if (expand) {                       // warm start: walk up until the count certifies an upper bound
+        if (C != 0 && sig + wstep < hi) { sig += wstep; wstep *= T(4); continue; }
+        expand = false;
+      }
       // a failed certificate attempt means the estimate is off by more than the offset: widen it
       const bool cert = (aimed != 0);     // this sweep was a certificate attempt around rho_trust
       if (aimed > 0 && C != 0) off_up *= T(2);

@@ -112,7 +112,7 @@ class Context:
 
     # ---- geometry x theta0 scan ---------------------------------------------------------------
     def gamma_scan(self, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, dPdrho, theta0,
-                   want_X=False, want_dtheta0=False, want_info=False):
+                   want_X=False, want_dtheta0=False, want_info=False, lam_guess=None, guess_width=None):
         """geometry arrays: (n_lines, N); dPdrho: (n_lines,); theta0: (n_theta0,).
         Returns dict(gam, lam[, X, dX][, dgam_dtheta0]) shaped (n_lines, n_theta0[, N])."""
         ar = _Args()
@@ -129,8 +129,14 @@ class Context:
         dX, pdX = ar.out((n_lines, n_t0, N), ref, want=want_X)
         dth, pdth = ar.out((n_lines, n_t0), ref, want=want_dtheta0)
         info, pinfo = ar.out((n_lines, n_t0), ref, dtype=np.int32, want=want_info)
-        rc = check(self._lib.ibs_gamma_scan_f64(self._h, n_lines, n_t0, N, float(h), *ptrs, N, pdP, pt0,
-                                                pgam, plam, pX, pdX, pdth, pinfo, ar.mem), "ibs_gamma_scan_f64")
+        if lam_guess is not None:
+            pg = ar.inp(lam_guess)
+            rc = check(self._lib.ibs_gamma_scan_warm_f64(self._h, n_lines, n_t0, N, float(h), *ptrs, N, pdP, pt0, pg,
+                                                         float(guess_width), pgam, plam, pX, pdX, pdth, pinfo, ar.mem),
+                       "ibs_gamma_scan_warm_f64")
+        else:
+            rc = check(self._lib.ibs_gamma_scan_f64(self._h, n_lines, n_t0, N, float(h), *ptrs, N, pdP, pt0,
+                                                    pgam, plam, pX, pdX, pdth, pinfo, ar.mem), "ibs_gamma_scan_f64")
         out = dict(gam=gam, lam=lam, nbad=rc)
         if want_X:
             out.update(X=X, dX=dX)

@@ -72,6 +72,17 @@ int ibs_gamma_scan_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t 
                        const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
                        double* dX, double* dgam_dtheta0, int32_t* info, int32_t mem);
 
+/* Same scan, warm-started: lam_guess[n_lines][n_theta0] holds the eigenvalues of a nearby problem (the
+ * previous optimizer iteration, or the base equilibrium when one of the DOF-perturbed equilibria of
+ * sims_runner_NCSX.py:151-276 is re-scanned) and guess_width their expected absolute change.  The result
+ * is certified exactly as in the cold scan (a wrong guess costs sweeps, never correctness). */
+int ibs_gamma_scan_warm_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
+                            const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
+                            const double* gds2, const double* gds21, const double* gds22, int64_t ld,
+                            const double* dPdrho, const double* theta0, const double* lam_guess, double guess_width,
+                            double* gam, double* lam, double* X, double* dX, double* dgam_dtheta0, int32_t* info,
+                            int32_t mem);
+
 /* Objective and Hellmann-Feynman ("adjoint") gradient at n_pts points (alpha, theta0).
  * Replaces: utils.py:1632-1728 obj_w_grad, given the geometry of the three field lines
  * (alpha - del_alpha/2, alpha, alpha + del_alpha/2) that utils.py:1641-1646 obtains from vmec_fieldlines.

@@ -405,3 +405,26 @@ def test_F2_batched_refinement_matches_per_surface_lbfgsb(ctx, bo):
         assert abs(-fo[k] - gam_opt) < 5e-7, (k, -fo[k], gam_opt)       # same local maximum
     t0, al, gam = scan.run()
     assert np.abs(gam + fo).max() < 1e-12
+
+
+def test_warm_started_rescan_is_certified_and_cheaper(ctx, bo):
+    """re-scan of a DOF-perturbed equilibrium (sims_runner_NCSX.py:151-276 pattern) warm-started from the
+    base scan: same certified result as a cold scan, fewer sweeps; a bad guess only costs sweeps"""
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    geo = g3["geo_513"].copy()
+    th = bo.theta_grid(513)
+    t0 = np.linspace(0, np.pi / 2, 8)
+    a = [np.ascontiguousarray(geo[:, k, :]) for k in range(7)]
+    base = ctx.gamma_scan(th[1] - th[0], *a, g3["dPdrho_513"], t0, want_info=True)
+    pert = [x.copy() for x in a]
+    pert[4] *= 1.002; pert[5] *= 1.002; pert[6] *= 1.002; pert[2] *= 0.999          # rel 2e-3 (create_dict.py:70)
+    cold = ctx.gamma_scan(th[1] - th[0], *pert, g3["dPdrho_513"], t0, want_info=True)
+    warm = ctx.gamma_scan(th[1] - th[0], *pert, g3["dPdrho_513"], t0, want_info=True,
+                          lam_guess=base["lam"], guess_width=2e-5)
+    assert warm["nbad"] == 0 and np.abs(warm["gam"] - cold["gam"]).max() < 1e-10
+    assert np.abs(warm["lam"] - cold["lam"]).max() < 1e-10
+    it_c = (cold["info"] & 0xffff).mean(); it_w = (warm["info"] & 0xffff).mean()
+    assert it_w < 0.75 * it_c, (it_w, it_c)
+    bad = ctx.gamma_scan(th[1] - th[0], *pert, g3["dPdrho_513"], t0, want_info=True,
+                         lam_guess=base["lam"] - 0.05, guess_width=1e-6)
+    assert np.abs(bad["gam"] - cold["gam"]).max() < 1e-10
