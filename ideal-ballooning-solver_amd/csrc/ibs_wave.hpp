@@ -46,6 +46,20 @@ __device__ __forceinline__ bool signbit_of(float a) { return __float_as_int(a) <
 __device__ __forceinline__ bool finite_of(double a) { return xabs(a) <= 1.7976931348623157e308; }
 __device__ __forceinline__ bool finite_of(float a) { return xabs(a) <= 3.4028234e38f; }
 
+// reciprocal for well-scaled operands (no denormal / overflow handling): hardware seed + two Newton steps.
+// Used only where the result steers the iteration (Newton step length, vector normalisation), never in the
+// certified quantities.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; };
@@ -106,11 +120,25 @@ struct M2 {
   int e;         // true matrix = this * 2^e
 };
 
+// Power-of-two renormalisation to max-entry in [0.5, 1).  The exponent is taken from the bits of the largest
+// entry and applied as a MULTIPLY by an exactly representable 2^-ex (integer-built): v_ldexp_f64 /
+// v_frexp_exp are not full-rate FP64 instructions, v_mul_f64 is.
+__device__ __forceinline__ double pow2_scale_of(double m, int& ex_out) {
+  const int eb = (__double2hiint(m) >> 20) & 0x7ff;        // biased exponent of m >= 0 (0 for m = 0)
+  ex_out = eb - 1022;                                      // m = mant * 2^ex_out, mant in [0.5, 1)
+  return __hiloint2double((2045 - eb) << 20, 0);           // 2^-(ex_out)
+}
+__device__ __forceinline__ float pow2_scale_of(float m, int& ex_out) {
+  const int eb = (__float_as_int(m) >> 23) & 0xff;
+  ex_out = eb - 126;
+  return __int_as_float((253 - eb) << 23);
+}
 template <typename T>
 __device__ __forceinline__ void renorm(M2<T>& R) {
-  T m = xmax(xmax(xabs(R.a), xabs(R.b)), xmax(xabs(R.c), xabs(R.d)));
-  int ex = fexp(m);
-  R.a = xldexp(R.a, -ex); R.b = xldexp(R.b, -ex); R.c = xldexp(R.c, -ex); R.d = xldexp(R.d, -ex);
+  const T m = xmax(xmax(xabs(R.a), xabs(R.b)), xmax(xabs(R.c), xabs(R.d)));
+  int ex;
+  const T sc = pow2_scale_of(m, ex);
+  R.a *= sc; R.b *= sc; R.c *= sc; R.d *= sc;
   R.e += ex;
 }
 // R = A * B (A applied after B).  NORM: renormalise to max-entry in [0.5, 1)
@@ -377,13 +405,13 @@ struct WaveSolver {
     }
     const T uw = zu_k * zw_k;
     const T num = xfma(um1, zw_k, xfma(t_k, uw, wp1 * zu_k));   // row-k residual of the twisted vector (x u_k w_k)
-    const T gam_k = num / (S_k * S_k * uw);
+    const T gam_k = num * fast_rcp(S_k * S_k * uw);
     const int Euk = readlane_i(Eu, Lk), Ewk = readlane_i(Ew, Lk);
     int du = Eu - Euk, dw = Ew - Ewk;
     du = du > 1000 ? 1000 : (du < -2000 ? -2000 : du);
     dw = dw > 1000 ? 1000 : (dw < -2000 ? -2000 : dw);
-    fu = xldexp(T(1) / (S_k * zu_k), du);
-    fw = xldexp(T(1) / (S_k * zw_k), dw);
+    fu = xldexp(fast_rcp(S_k * zu_k), du);
+    fw = xldexp(fast_rcp(S_k * zw_k), dw);
     thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
     T acc = T(0);
 #pragma unroll
@@ -393,7 +421,7 @@ struct WaveSolver {
       if ((i < M - 1) || has_last) acc = xfma(Ph[i] * x, x, acc);
     }
     const T tot = wave_sum(acc);
-    return sig + gam_k / tot;
+    return sig + gam_k * fast_rcp(tot);
   }
 
   // eigenvector entries of this lane's rows (twisted, x_k = 1) from the last sweep/twisted() call
