@@ -141,16 +141,24 @@ __device__ __forceinline__ void renorm(M2<T>& R) {
   R.a *= sc; R.b *= sc; R.c *= sc; R.d *= sc;
   R.e += ex;
 }
-// R = A * B (A applied after B).  NORM: renormalise to max-entry in [0.5, 1)
+// A <- A * B (A applied after B), in place.  NORM: renormalise to max-entry in [0.5, 1).
+// Written so that each row needs one temporary only (the scan steps run under an exec mask and every
+// extra temporary costs a masked register copy).
+template <typename T, bool NORM>
+__device__ __forceinline__ void mul_inplace(M2<T>& A, const M2<T>& B) {
+  const T na = xfma(A.a, B.a, A.b * B.c);
+  A.b = xfma(A.a, B.b, A.b * B.d);
+  A.a = na;
+  const T nc = xfma(A.c, B.a, A.d * B.c);
+  A.d = xfma(A.c, B.b, A.d * B.d);
+  A.c = nc;
+  A.e += B.e;
+  if (NORM) renorm(A);
+}
 template <typename T, bool NORM>
 __device__ __forceinline__ M2<T> mul(const M2<T>& A, const M2<T>& B) {
-  M2<T> R;
-  R.a = xfma(A.a, B.a, A.b * B.c);
-  R.b = xfma(A.a, B.b, A.b * B.d);
-  R.c = xfma(A.c, B.a, A.d * B.c);
-  R.d = xfma(A.c, B.b, A.d * B.d);
-  R.e = A.e + B.e;
-  if (NORM) renorm(R);
+  M2<T> R = A;
+  mul_inplace<T, NORM>(R, B);
   return R;
 }
 // neighbour fetch for the scans: lanes without a valid source receive garbage/zero and are masked
@@ -186,31 +194,31 @@ __device__ __forceinline__ M2<T> lane_bcast(const M2<T>& s, int src_lane) {  // 
 template <typename T>
 __device__ __forceinline__ M2<T> scan_fwd(M2<T> P, int lane) {
   const int l16 = lane & 15, row = lane >> 4;
-  { const M2<T> F = dpp_fetch<T, 0x111, 0xF>(P); if (l16 >= 1) P = mul<T, false>(P, F); }   // row_shr:1
-  { const M2<T> F = dpp_fetch<T, 0x112, 0xF>(P); if (l16 >= 2) P = mul<T, true>(P, F); }    // row_shr:2
-  { const M2<T> F = dpp_fetch<T, 0x114, 0xF>(P); if (l16 >= 4) P = mul<T, false>(P, F); }   // row_shr:4
-  { const M2<T> F = dpp_fetch<T, 0x118, 0xF>(P); if (l16 >= 8) P = mul<T, true>(P, F); }    // row_shr:8
-  { const M2<T> F = dpp_fetch<T, 0x142, 0xA>(P); if (row & 1) P = mul<T, false>(P, F); }    // row_bcast:15 -> rows 1,3
-  { const M2<T> F = dpp_fetch<T, 0x143, 0xC>(P); if (row >= 2) P = mul<T, true>(P, F); }    // row_bcast:31 -> rows 2,3
+  { const M2<T> F = dpp_fetch<T, 0x111, 0xF>(P); if (l16 >= 1) mul_inplace<T, false>(P, F); }   // row_shr:1
+  { const M2<T> F = dpp_fetch<T, 0x112, 0xF>(P); if (l16 >= 2) mul_inplace<T, true>(P, F); }    // row_shr:2
+  { const M2<T> F = dpp_fetch<T, 0x114, 0xF>(P); if (l16 >= 4) mul_inplace<T, false>(P, F); }   // row_shr:4
+  { const M2<T> F = dpp_fetch<T, 0x118, 0xF>(P); if (l16 >= 8) mul_inplace<T, true>(P, F); }    // row_shr:8
+  { const M2<T> F = dpp_fetch<T, 0x142, 0xA>(P); if (row & 1) mul_inplace<T, false>(P, F); }    // row_bcast:15 -> rows 1,3
+  { const M2<T> F = dpp_fetch<T, 0x143, 0xC>(P); if (row >= 2) mul_inplace<T, true>(P, F); }    // row_bcast:31 -> rows 2,3
   return P;
 }
 // inclusive suffix product over lanes:  Q_L = B_L * B_{L+1} * ... * B_63
 template <typename T>
 __device__ __forceinline__ M2<T> scan_bwd(M2<T> Q, int lane) {
   const int l16 = lane & 15, row = lane >> 4;
-  { const M2<T> F = dpp_fetch<T, 0x101, 0xF>(Q); if (l16 < 15) Q = mul<T, false>(Q, F); }   // row_shl:1
-  { const M2<T> F = dpp_fetch<T, 0x102, 0xF>(Q); if (l16 < 14) Q = mul<T, true>(Q, F); }    // row_shl:2
-  { const M2<T> F = dpp_fetch<T, 0x104, 0xF>(Q); if (l16 < 12) Q = mul<T, false>(Q, F); }   // row_shl:4
-  { const M2<T> F = dpp_fetch<T, 0x108, 0xF>(Q); if (l16 < 8) Q = mul<T, true>(Q, F); }     // row_shl:8
+  { const M2<T> F = dpp_fetch<T, 0x101, 0xF>(Q); if (l16 < 15) mul_inplace<T, false>(Q, F); }   // row_shl:1
+  { const M2<T> F = dpp_fetch<T, 0x102, 0xF>(Q); if (l16 < 14) mul_inplace<T, true>(Q, F); }    // row_shl:2
+  { const M2<T> F = dpp_fetch<T, 0x104, 0xF>(Q); if (l16 < 12) mul_inplace<T, false>(Q, F); }   // row_shl:4
+  { const M2<T> F = dpp_fetch<T, 0x108, 0xF>(Q); if (l16 < 8) mul_inplace<T, true>(Q, F); }     // row_shl:8
   // rows 0,2 <- first lane of rows 1,3 (their row totals); then rows 0,1 <- lane 32 (rows 2+3)
   {
     const M2<T> t16 = lane_bcast(Q, 16), t48 = lane_bcast(Q, 48);
     M2<T> F;
     F.a = row == 0 ? t16.a : t48.a; F.b = row == 0 ? t16.b : t48.b;
     F.c = row == 0 ? t16.c : t48.c; F.d = row == 0 ? t16.d : t48.d; F.e = row == 0 ? t16.e : t48.e;
-    if ((row & 1) == 0) Q = mul<T, false>(Q, F);
+    if ((row & 1) == 0) mul_inplace<T, false>(Q, F);
   }
-  { const M2<T> F = lane_bcast(Q, 32); if (row < 2) Q = mul<T, true>(Q, F); }
+  { const M2<T> F = lane_bcast(Q, 32); if (row < 2) mul_inplace<T, true>(Q, F); }
   return Q;
 }
 
@@ -267,19 +275,19 @@ struct WaveSolver {
         const T d = cj - (e_lo + e_hi);
         const T s2 = sc * sc;
         S[i] = sc; D[i] = d * s2; Ph[i] = fj * s2;
-        const T rf = T(1) / fj;
+        const T rf = fast_rcp(fj);          // bounds only (margins added below)
         vhi = xmax(vhi, cj * rf);
         vlo = xmax(vlo, d * rf);
         vna = xmax(vna, (xabs(d) + e_lo + e_hi) * rf);
         sum_c += cj; sum_f += fj;
         bad = bad || !(fj > T(0)) || !(e_hi > T(0)) || !finite_of(cj);
-        sc = T(1) / (e_hi * sc);
+        sc = fast_rcp(e_hi * sc);           // e s_i s_{i+1} = 1 to rounding (two Newton steps on the hardware seed)
         gcur = gnext; e_lo = e_hi;
       } else {
         S[i] = T(0); D[i] = T(0); Ph[i] = T(0);
       }
     }
-    kap = sc; ikap = T(1) / sc;
+    kap = sc; ikap = fast_rcp(sc);
     bad = bad || !(e_first > T(0));
     // wave-level bounds:  lam_max <= max c/f (Gershgorin);  lam_max >= any Rayleigh quotient
     const T e0 = readlane_t(e_first, 0);
