@@ -11,6 +11,7 @@
 // arrive through scalar loads; the work is FP64 sin/cos evaluation, i.e. compute bound.
 #include <hip/hip_runtime.h>
 #include "ibs_launch.hpp"
+#include <cstdlib>
 
 namespace ibs {
 
@@ -164,6 +165,24 @@ struct RowStart {
 // Same arithmetic with the mode lists walked row by row (all modes of one m): inside a row the angle
 // m theta - n phi decreases by a constant dn*phi per mode, so (cos, sin) advance by one plane rotation
 // (4 flops) instead of a sincos.  Rows hold <= 2 ntor + 1 <= ~30 modes: the rotation error stays ~1e-15.
+// LPP lanes cooperate on one grid point: lane `sub` takes modes sub, sub+LPP, ... of every row and the partial
+// sums are combined by an in-register butterfly.  LPP = 8 turns the long per-point dependency chain of small
+// batches into 8x more, 8x shorter threads; LPP = 1 is the throughput form for large batches.
+template <int LPP>
+__device__ __forceinline__ double group_sum(double v) {
+  if constexpr (LPP >= 2)
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  if constexpr (LPP >= 4)
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xF, 0xF, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  if constexpr (LPP >= 8)
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x141, 0xF, 0xF, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+
+template <int LPP>
 __global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
   // the surface's mode tables are staged once per block in LDS (all lanes read the same entry: broadcast,
   // conflict-free); from global memory each entry would be a dependent scalar-cache miss
@@ -184,8 +203,10 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
     for (int k = threadIdx.x; k < 7 * a.mnmax_nyq; k += blockDim.x) tnq[k] = g_nq[k];
   }
   __syncthreads();
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.N) return;
+  const int sub = threadIdx.x % LPP;
+  const int j_raw = (blockIdx.x * blockDim.x + threadIdx.x) / LPP;
+  const bool live = j_raw < a.N;           // lanes past the end keep computing (on the last point) so that the
+  const int j = live ? j_raw : a.N - 1;    // butterflies stay full; they just do not store
   const double* sc = a.scal + 6 * js;
   const double s = sc[0], iota = sc[1], diota = sc[2], dp = sc[3], phiedge = sc[4], L = sc[5];
   const double alpha = a.line_alpha[line];
@@ -196,8 +217,9 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
   const double* drmnc = lmns + a.mnmax; const double* dzmns = drmnc + a.mnmax; const double* dlmns = dzmns + a.mnmax;
   // the per-mode step dn (= nfp for VMEC tables) is the same in every row: its rotation is set up once
   const double dn_mn = a.dn_mn, dn_nyq = a.dn_nyq;
-  double sd, cd;
-  sincos(dn_mn * phi, &sd, &cd);
+  double sd, cd, ss0, cs0;
+  sincos(LPP * dn_mn * phi, &sd, &cd);          // per-lane step: LPP modes
+  sincos(sub * dn_mn * phi, &ss0, &cs0);         // this lane's offset inside a row
   auto resid = [&](double tv) {
     double acc = 0.0;
     RowStart rs;
@@ -206,18 +228,23 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
       const int k0 = a.rows_mn[2 * r], cnt = a.rows_mn[2 * r + 1];
       double sa, ca;
       rs.start(xm_s[k0], xn_s[k0], ca, sa);
-      for (int k = k0; k < k0 + cnt; ++k) {
+      { const double c2 = ca * cs0 + sa * ss0, s2 = sa * cs0 - ca * ss0; ca = c2; sa = s2; }
+      for (int k = k0 + sub; k < k0 + cnt; k += LPP) {
         acc += lmns[k] * sa;
         const double c2 = ca * cd + sa * sd, s2 = sa * cd - ca * sd;   // angle -= dn*phi
         ca = c2; sa = s2;
       }
     }
-    return tp - (tv + acc);
+    return tp - (tv + group_sum<LPP>(acc));
   };
   // secant iteration (superlinear): once a step is below 1e-9 the next one lands at rounding level, so
   // exactly one more update is taken and the loop ends (a test on the rounding-level step never fires)
-  double p0 = tp, p1 = tp + 0.1;
-  double q0 = resid(p0), q1 = resid(p1);
+  // second secant point: one fixed-point step theta_p + resid(theta_p) (already O(lambda^2) close) instead
+  // of the reference's theta_p + 0.1; the root is the same, two evaluations fewer on average
+  double p0 = tp;
+  double q0 = resid(p0);
+  double p1 = tp + q0;
+  double q1 = resid(p1);
   bool last = false;
   for (int it = 0; it < 40; ++it) {
     const double den = q1 - q0;
@@ -237,7 +264,8 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
     const int k0 = a.rows_mn[2 * r], cnt = a.rows_mn[2 * r + 1];
     double sa, ca;
     rs.start(xm_s[k0], xn_s[k0], ca, sa);
-    for (int k = k0; k < k0 + cnt; ++k) {
+    { const double c2 = ca * cs0 + sa * ss0, s2 = sa * cs0 - ca * ss0; ca = c2; sa = s2; }
+    for (int k = k0 + sub; k < k0 + cnt; k += LPP) {
       const double m = xm_s[k], n = xn_s[k];
       R += rmnc[k] * ca; R_s += drmnc[k] * ca; R_t -= rmnc[k] * m * sa; R_p += rmnc[k] * n * sa;
       Z_s += dzmns[k] * sa; Z_t += zmns[k] * m * ca; Z_p -= zmns[k] * n * ca;
@@ -251,13 +279,17 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
   const double* bsupv = dbmnc + a.mnmax_nyq; const double* bsubs = bsupv + a.mnmax_nyq;
   const double* bsubu = bsubs + a.mnmax_nyq; const double* bsubv = bsubu + a.mnmax_nyq;
   double sqg = 0, modB = 0, B_s = 0, B_t = 0, B_p = 0, Bsup_phi = 0, Bsub_s = 0, Bsub_t = 0, Bsub_p = 0;
-  if (dn_nyq != dn_mn) sincos(dn_nyq * phi, &sd, &cd);
+  if (dn_nyq != dn_mn) { sincos(LPP * dn_nyq * phi, &sd, &cd); sincos(sub * dn_nyq * phi, &ss0, &cs0); }
+  R = group_sum<LPP>(R); R_s = group_sum<LPP>(R_s); R_t = group_sum<LPP>(R_t); R_p = group_sum<LPP>(R_p);
+  Z_s = group_sum<LPP>(Z_s); Z_t = group_sum<LPP>(Z_t); Z_p = group_sum<LPP>(Z_p);
+  l_s = group_sum<LPP>(l_s); l_t = group_sum<LPP>(l_t); l_p = group_sum<LPP>(l_p);
   rs.init(tv, phi);
   for (int r = 0; r < a.nrows_nyq; ++r) {
     const int k0 = a.rows_nyq[2 * r], cnt = a.rows_nyq[2 * r + 1];
     double sa, ca;
     rs.start(xmq_s[k0], xnq_s[k0], ca, sa);
-    for (int k = k0; k < k0 + cnt; ++k) {
+    { const double c2 = ca * cs0 + sa * ss0, s2 = sa * cs0 - ca * ss0; ca = c2; sa = s2; }
+    for (int k = k0 + sub; k < k0 + cnt; k += LPP) {
       const double m = xmq_s[k], n = xnq_s[k];
       sqg += gmnc[k] * ca; modB += bmnc[k] * ca; B_s += dbmnc[k] * ca;
       B_t -= bmnc[k] * m * sa; B_p += bmnc[k] * n * sa;
@@ -266,6 +298,10 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
       ca = c2; sa = s2;
     }
   }
+  sqg = group_sum<LPP>(sqg); modB = group_sum<LPP>(modB); B_s = group_sum<LPP>(B_s); B_t = group_sum<LPP>(B_t);
+  B_p = group_sum<LPP>(B_p); Bsup_phi = group_sum<LPP>(Bsup_phi); Bsub_s = group_sum<LPP>(Bsub_s);
+  Bsub_t = group_sum<LPP>(Bsub_t); Bsub_p = group_sum<LPP>(Bsub_p);
+  if (!live || sub != 0) return;
   GEO_TAIL
 }
 
@@ -287,12 +323,21 @@ __global__ void __launch_bounds__(256) k_line_dPdrho(int n_lines, int N, long ld
 
 hipError_t launch_geometry(const GeoArgs& a, hipStream_t st) {
   dim3 grid((a.N + 255) / 256, a.n_lines);
+  // lanes per point: measured (tools/bench_geo.py) 1 is best or within 15 % of best from 128 x 513 points up:
+  // the kernel is VALU bound, splitting a point over lanes only adds row-start work.  IBS_GEO_LPP overrides.
   const size_t lds = (size_t)(8 * a.mnmax + 9 * a.mnmax_nyq) * sizeof(double);
   if (a.nrows_mn > 0 && a.nrows_nyq > 0 && lds <= 150 * 1024) {
-    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fieldline_geometry_rows),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(k_fieldline_geometry_rows, grid, dim3(256), lds, st, a);
+    int lpp = 1;
+    if (const char* e = getenv("IBS_GEO_LPP")) lpp = atoi(e);
+    auto go = [&](auto kern, int l) {
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e1 != hipSuccess) return e1;
+      hipLaunchKernelGGL(kern, dim3((a.N * l + 255) / 256, a.n_lines), dim3(256), lds, st, a);
+      return hipSuccess;
+    };
+    hipError_t e2 = lpp == 8 ? go(k_fieldline_geometry_rows<8>, 8) : lpp == 4 ? go(k_fieldline_geometry_rows<4>, 4)
+                  : lpp == 2 ? go(k_fieldline_geometry_rows<2>, 2) : go(k_fieldline_geometry_rows<1>, 1);
+    if (e2 != hipSuccess) return e2;
   } else {
     hipLaunchKernelGGL(k_fieldline_geometry, grid, dim3(256), 0, st, a);
   }
