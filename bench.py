@@ -223,8 +223,8 @@ def main():
     h, geo7, dP_d, th0_d, base, dP, theta0 = build_workload(rank, device)
     plan = ibs_amd.ScanPlan(ctx, h, geo7, dP_d, th0_d, N_SURF)
     n_solves = N_SURF * N_ALPHA * N_THETA0
-    gathered = torch.empty((world, N_SURF, 2), dtype=torch.float64, device=device) if world > 1 else None
-    local_pack = torch.empty((N_SURF, 2), dtype=torch.float64, device=device)
+    use_dist = dist.is_available() and dist.is_initialized()
+    gathered = torch.empty((world, N_SURF, 2), dtype=torch.float64, device=device) if use_dist else None
 
     def step(ev=None):
         if ev is not None:
@@ -233,13 +233,11 @@ def main():
         if ev is not None:
             ev[1].record()
         plan.argmax()
-        if world > 1:       # replaces comm_lead.Gather x3 (ball_scan.py:345-347): (lam_max, flat index) per surface
-            local_pack[:, 0] = plan.best_val
-            local_pack[:, 1] = plan.best_idx.double()
-            dist.all_gather_into_tensor(gathered, local_pack)
+        if use_dist:        # replaces comm_lead.Gather x3 (ball_scan.py:345-347): (lam_max, flat index) per surface
+            dist.all_gather_into_tensor(gathered, plan.pack)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -252,7 +250,7 @@ def main():
         step(evs[k])
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -275,7 +273,7 @@ def main():
             "dtype": "f64", "data": "synthetic (NCSX_op-derived field-line geometry, perturbed per line)",
             "config": {"workload": "configs[1] D3D-shape: 16 surfaces x 8 alpha x 8 theta0 = 1024 solves/step/GPU, "
                                    "N_zeta=512 (513 points), geometry-fed scan + per-surface argmax"
-                                   + (" + RCCL all-gather" if world > 1 else ""),
+                                   + (" + RCCL all-gather" if use_dist else ""),
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
                        "nonconverged": nbad},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -295,7 +293,7 @@ def main():
             out["sturm_sweep"] = sturm_sweep(ctx, device, args.stress_systems)
             out["warm_rescan"] = warm_rescan(ctx, device, h, geo7, dP_d, th0_d)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

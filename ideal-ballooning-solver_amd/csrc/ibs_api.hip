@@ -113,7 +113,7 @@ __global__ void k_count_status(long n, const int* info, int* out) {
 }
 
 // first-argmax per surface (ball_scan.py:283-295 tie rule: lowest row-major index wins)
-__global__ void __launch_bounds__(256) k_surface_argmax(int n_per, const double* gam, int* idx, double* val) {
+__global__ void __launch_bounds__(256) k_surface_argmax(int n_per, const double* gam, int* idx, double* val, double* pack) {
   __shared__ double sv[4];
   __shared__ int si[4];
   const double* g = gam + (size_t)blockIdx.x * n_per;
@@ -135,8 +135,9 @@ __global__ void __launch_bounds__(256) k_surface_argmax(int n_per, const double*
   if (threadIdx.x == 0) {
     for (int k = 1; k < 4; ++k)
       if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
-    idx[blockIdx.x] = bi;
-    val[blockIdx.x] = best;
+    if (idx) idx[blockIdx.x] = bi;
+    if (val) val[blockIdx.x] = best;
+    if (pack) { pack[2 * blockIdx.x] = best; pack[2 * blockIdx.x + 1] = (double)bi; }   // one buffer for the all-gather
   }
 }
 
@@ -541,14 +542,24 @@ int ibs_surface_argmax_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per, const do
     Arena ar(ctx);
     double* dg = ar.take<double>(ne); double* dv = ar.take<double>(n_surf); int* di = ar.take<int>(n_surf);
     HIPCHK(hipMemcpyAsync(dg, gam, ne * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, dg, di, dv);
+    hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, dg, di, dv, (double*)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(idx, di, (size_t)n_surf * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(val, dv, (size_t)n_surf * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
   }
-  hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, gam, idx, val);
+  hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, gam, idx, val, (double*)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ibs_surface_argmax_pack_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per, const double* gam, double* pack) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_surf < 0 || n_per <= 0 || !gam || !pack) return fail(IBS_ERR_ARG, "bad arguments");
+  if (n_surf == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, gam, (int*)nullptr, (double*)nullptr, pack);
   HIPCHK(hipGetLastError());
   return 0;
 }

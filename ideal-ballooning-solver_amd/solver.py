@@ -250,7 +250,8 @@ class ScanPlan:
 
     geometry tensors: (n_lines, N) torch.cuda float64, lines ordered surface-major
     (n_lines = n_surf * n_alpha).  Results live in .gam (n_lines, n_theta0), .lam, .best_val (n_surf,),
-    .best_idx (n_surf,) -- index into the flattened (alpha, theta0) table of the surface."""
+    .best_idx (n_surf,) -- index into the flattened (alpha, theta0) table of the surface; both are views of
+    .pack (n_surf, 2) float64, the buffer the per-surface all-gather sends."""
 
     def __init__(self, ctx, h, geo7, dPdrho, theta0, n_surf, want_dtheta0=False):
         import torch
@@ -270,15 +271,15 @@ class ScanPlan:
         self.lam = torch.empty((n_lines, n_t0), dtype=t64, device=dev)
         self.dth0 = torch.empty((n_lines, n_t0), dtype=t64, device=dev) if want_dtheta0 else None
         self.info = torch.empty((n_lines, n_t0), dtype=torch.int32, device=dev)
-        self.best_val = torch.empty((n_surf,), dtype=t64, device=dev)
-        self.best_idx = torch.empty((n_surf,), dtype=torch.int32, device=dev)
+        self.pack = torch.empty((n_surf, 2), dtype=t64, device=dev)      # (lam_max, flat index) per surface
+        self.best_val = self.pack[:, 0]
+        self.best_idx = self.pack[:, 1]
         ctx._stream_from_torch(self.geo[0])
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
         self._scan_args = (ctx._h, n_lines, n_t0, N, float(h), *[p(g) for g in self.geo], N, p(self.dP), p(self.t0),
                            p(self.gam), p(self.lam), C.c_void_p(None), C.c_void_p(None), p(self.dth0), p(self.info),
                            MEM_DEVICE)
-        self._amax_args = (ctx._h, n_surf, (n_lines // n_surf) * n_t0, p(self.gam), p(self.best_idx), p(self.best_val),
-                           MEM_DEVICE)
+        self._amax_args = (ctx._h, n_surf, (n_lines // n_surf) * n_t0, p(self.gam), p(self.pack))
 
     def scan(self):
         rc = self.lib.ibs_gamma_scan_f64(*self._scan_args)
@@ -286,9 +287,9 @@ class ScanPlan:
             check(rc, "ibs_gamma_scan_f64")
 
     def argmax(self):
-        rc = self.lib.ibs_surface_argmax_f64(*self._amax_args)
+        rc = self.lib.ibs_surface_argmax_pack_f64(*self._amax_args)
         if rc < 0:
-            check(rc, "ibs_surface_argmax_f64")
+            check(rc, "ibs_surface_argmax_pack_f64")
 
     def __call__(self):
         self.scan()

@@ -125,6 +125,10 @@ int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const 
 int ibs_surface_argmax_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per_surf, const double* gam,
                            int32_t* idx, double* val, int32_t mem);
 
+/* Same reduction on device pointers, written as pack[n_surf][2] = (value, index as double): the one buffer the
+ * per-surface all-gather sends (replaces the three comm_lead.Gather of ball_scan.py:345-347). */
+int ibs_surface_argmax_pack_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per_surf, const double* gam, double* pack);
+
 #ifdef __cplusplus
 }
 #endif

@@ -428,3 +428,20 @@ def test_warm_started_rescan_is_certified_and_cheaper(ctx, bo):
     bad = ctx.gamma_scan(th[1] - th[0], *pert, g3["dPdrho_513"], t0, want_info=True,
                          lam_guess=base["lam"] - 0.05, guess_width=1e-6)
     assert np.abs(bad["gam"] - cold["gam"]).max() < 1e-10
+
+
+def test_scan_plan_packed_argmax(ctx, bo):
+    """the pre-marshalled step (scan + packed per-surface argmax) used by bench.py"""
+    import ibs_amd
+    import torch
+    g5 = np.load(os.path.join(G, "G5_scan_trace.npz"))
+    dev = torch.device("cuda:0")
+    th = bo.theta_grid(513)
+    geo7 = [torch.from_numpy(np.ascontiguousarray(g5["geo"][:, k, :])).to(dev) for k in range(7)]
+    plan = ibs_amd.ScanPlan(ctx, th[1] - th[0], geo7, torch.from_numpy(g5["dPdrho"]).to(dev),
+                            torch.from_numpy(g5["theta0_scan"]).to(dev), n_surf=1)
+    plan()
+    torch.cuda.synchronize()
+    assert np.abs(plan.gam.cpu().numpy() - g5["gam_table"]).max() < TOL
+    assert divmod(int(plan.best_idx[0].item()), 15) == tuple(int(v) for v in g5["argmax"])
+    assert abs(plan.best_val[0].item() - g5["gam_table"].max()) < TOL
