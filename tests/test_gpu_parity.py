@@ -445,3 +445,51 @@ def test_scan_plan_packed_argmax(ctx, bo):
     assert np.abs(plan.gam.cpu().numpy() - g5["gam_table"]).max() < TOL
     assert divmod(int(plan.best_idx[0].item()), 15) == tuple(int(v) for v in g5["argmax"])
     assert abs(plan.best_val[0].item() - g5["gam_table"].max()) < TOL
+
+
+def test_config4_adjoint_step_emulated_dofs(ctx, bo):
+    """BASELINE config 4 (FD gradient of the ballooning objective over boundary DOFs) with the DOF
+    perturbations emulated on the NCSX_op tables (boundary rows of rmnc/zmns changed by
+    abs 1e-3 / rel 2e-3, create_dict.py:67-70): GPU pipeline (geometry -> scan -> per-surface max ->
+    objective -> forward differences, sims_runner_NCSX.py:249-261) against the same pipeline on the oracles."""
+    import ibs_amd
+    import torch
+    from oracle import geometry_oracle as go
+    wout0 = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    svals = np.array([0.6, 0.85])
+    N, na, nt = 257, 4, 3
+    th = bo.theta_grid(N)
+    alphas = np.linspace(0, np.pi, na)
+    t0s = np.linspace(0, np.pi / 2, nt)
+    dofs = [("rmnc", 3), ("zmns", 5), ("rmnc", 14)]
+    steps = [1.0]
+    wouts = [wout0]
+    for name, k in dofs:
+        w = {kk: (v.copy() if isinstance(v, np.ndarray) else v) for kk, v in wout0.items()}
+        x = w[name][k, -1]
+        step = 1e-3 if abs(x) <= 1e-2 else 2e-3 * x
+        w[name][k, :] = w[name][k, :] + step * np.linspace(0, 1, w[name].shape[1]) ** 2   # boundary change, smooth inward
+        wouts.append(w)
+        steps.append(step)
+    dev = torch.device("cuda:0")
+    gam_gpu = np.zeros((len(wouts), len(svals)))
+    gam_cpu = np.zeros_like(gam_gpu)
+    for i, w in enumerate(wouts):
+        tabs = ibs_amd.SurfaceTables.from_wout(w, svals)
+        surf = np.repeat(np.arange(len(svals)), na)
+        r = ctx.fieldline_geometry(tabs, surf, np.tile(alphas, len(svals)), th, device=dev)
+        sc = ctx.gamma_scan(th[1] - th[0], *[r["geo"][k] for k in range(7)], r["dPdrho"], torch.from_numpy(t0s).to(dev))
+        idx, val = ctx.surface_argmax(sc["gam"].reshape(len(svals), -1))
+        gam_gpu[i] = val.cpu().numpy()
+        tab_o = go.surface_tables_from_wout(w, svals)
+        for js in range(len(svals)):
+            geo = go.fieldline_geometry(tab_o, js, alphas, th)
+            dP = np.array([bo.dPdrho_of(g[2], g[7], g[0]) for g in geo])
+            gam_cpu[i, js] = bo.coarse_scan(th, geo[:, :7], dP, t0s).max()
+    assert np.abs(gam_gpu - gam_cpu).max() < TOL
+    f_other = np.full(len(wouts), 0.8)
+    f_gpu = ibs_amd.ballooning_objective(f_other, gam_gpu, gamma_thresh=-2e-3, prefac=50.0)
+    f_cpu = ibs_amd.ballooning_objective(f_other, gam_cpu, gamma_thresh=-2e-3, prefac=50.0)
+    d_gpu = ibs_amd.dof_fd_gradient(f_gpu, steps)
+    d_cpu = ibs_amd.dof_fd_gradient(f_cpu, steps)
+    assert np.abs(d_gpu).max() > 0 and np.abs(d_gpu - d_cpu).max() < 1e-4 * max(1.0, np.abs(d_cpu).max())
