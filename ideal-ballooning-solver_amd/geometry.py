@@ -57,27 +57,26 @@ class SurfaceTables:
     def from_wout(cls, wout, svals):
         """wout: mapping with rmnc, zmns, lmns, gmnc, bmnc, bsupvmnc, bsubsmns, bsubumnc, bsubvmnc stored
         (mn, ns) as in simsopt's Vmec.wout, pres, iotas, phi (ns,), xm, xn, xm_nyq, xn_nyq, Aminor_p, ns."""
-        from scipy.interpolate import InterpolatedUnivariateSpline as Spl
+        from scipy.interpolate import make_interp_spline
         ns = int(wout["ns"])
         s_full = np.linspace(0, 1, ns)                     # vmec.s_full_grid
         s_half = s_full[1:] - 0.5 * (s_full[1] - s_full[0])  # vmec.s_half_grid
         svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))
 
         def ev(tab, half, deriv=False):
+            # cubic interpolating spline with not-a-knot ends = what InterpolatedUnivariateSpline builds
+            # (utils.py:58-107), fitted for all modes at once
             tab = np.asarray(tab, dtype=np.float64)
-            res = np.empty((len(svals), tab.shape[0]))
-            for j in range(tab.shape[0]):
-                sp = Spl(s_half, tab[j, 1:]) if half else Spl(s_full, tab[j, :])   # utils.py:58-107
-                res[:, j] = (sp.derivative() if deriv else sp)(svals)
-            return res
+            sp = make_interp_spline(s_half, tab[:, 1:].T, k=3) if half else make_interp_spline(s_full, tab.T, k=3)
+            return (sp.derivative() if deriv else sp)(svals)
 
         mn = np.stack([ev(wout["rmnc"], False), ev(wout["zmns"], False), ev(wout["lmns"], True),
                        ev(wout["rmnc"], False, True), ev(wout["zmns"], False, True), ev(wout["lmns"], True, True)], axis=1)
         nyq = np.stack([ev(wout["gmnc"], True), ev(wout["bmnc"], True), ev(wout["bmnc"], True, True),
                         ev(wout["bsupvmnc"], True), ev(wout["bsubsmns"], False), ev(wout["bsubumnc"], True),
                         ev(wout["bsubvmnc"], True)], axis=1)
-        pres = Spl(s_half, np.asarray(wout["pres"], dtype=np.float64)[1:])          # utils.py:112
-        iota = Spl(s_half, np.asarray(wout["iotas"], dtype=np.float64)[1:])         # utils.py:118
+        pres = make_interp_spline(s_half, np.asarray(wout["pres"], dtype=np.float64)[1:], k=3)    # utils.py:112
+        iota = make_interp_spline(s_half, np.asarray(wout["iotas"], dtype=np.float64)[1:], k=3)   # utils.py:118
         return cls(svals, wout["xm"], wout["xn"], wout["xm_nyq"], wout["xn_nyq"], mn, nyq, iota(svals),
                    iota.derivative()(svals), pres.derivative()(svals), float(np.asarray(wout["phi"])[-1]),
                    float(wout["Aminor_p"]))
