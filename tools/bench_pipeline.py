@@ -23,3 +23,32 @@ for name, ns, na, nt0, N in (("reference batch (5 surfaces x 24 alpha x 15 theta
     print('%s: host splines %.2f s | geometry %.3f ms (%d lines) | scan %.3f ms (%d solves, %.1f sweeps) | gam max per surface[:3] %s' % (
         name, t_spl, e[0].elapsed_time(e[1]), ns * na, e[1].elapsed_time(e[2]), nsolve,
         float((sc['info'] & 0xffff).double().mean()), sc['gam'].reshape(ns, -1).max(dim=1).values[:3].cpu().numpy()))
+
+# config 4 shape: one FD-gradient step of the optimizer = 73 equilibria x 5 surfaces x 24 alpha x 15 theta0, N = 969
+n_eq, ns, na, nt0, N = 73, 5, 24, 15, 969
+svals = np.linspace(0.5, 0.95, ns); th = bo.theta_grid(N); alphas = np.linspace(0, np.pi, na)
+t0 = torch.from_numpy(np.linspace(0, np.pi / 2, nt0)).to(dev)
+t = time.time()
+tabs_all = []
+for q in range(n_eq):
+    w = dict(wout)
+    if q:
+        w["rmnc"] = wout["rmnc"].copy(); w["rmnc"][q % 200, :] *= (1 + 2e-3 * np.linspace(0, 1, wout["rmnc"].shape[1]) ** 2)
+    tabs_all.append(ibs_amd.SurfaceTables.from_wout(w, svals))
+t_spl = time.time() - t
+# one table set holding all equilibria (n_eq * ns "surfaces")
+big = ibs_amd.SurfaceTables(np.tile(svals, n_eq), tabs_all[0].xm, tabs_all[0].xn, tabs_all[0].xm_nyq, tabs_all[0].xn_nyq,
+                            np.concatenate([t_.tab_mn for t_ in tabs_all]), np.concatenate([t_.tab_nyq for t_ in tabs_all]),
+                            np.concatenate([t_.scal[:, 1] for t_ in tabs_all]), np.concatenate([t_.scal[:, 2] for t_ in tabs_all]),
+                            np.concatenate([t_.scal[:, 3] for t_ in tabs_all]), tabs_all[0].scal[0, 4], tabs_all[0].scal[0, 5])
+surf = np.repeat(np.arange(n_eq * ns), na); al = np.tile(alphas, n_eq * ns)
+for rep in range(2):
+    torch.cuda.synchronize(); t = time.time()
+    r = ctx.fieldline_geometry(big, surf, al, th, device=dev)
+    torch.cuda.synchronize(); t_geo = time.time() - t; t = time.time()
+    sc = ctx.gamma_scan(th[1] - th[0], *[r['geo'][k] for k in range(7)], r['dPdrho'], t0)
+    idx, val = ctx.surface_argmax(sc['gam'].reshape(n_eq * ns, -1))
+    torch.cuda.synchronize(); t_scan = time.time() - t
+f = ibs_amd.ballooning_objective(np.full(n_eq, 0.8), val.cpu().numpy().reshape(n_eq, ns), -2e-4, 50.0)
+print('config 4 shape (%d equilibria, %d lines, %d solves): host splines %.2f s | geometry %.1f ms | scan+argmax %.1f ms | f0[:3] %s' % (
+    n_eq, len(surf), n_eq * ns * na * nt0, t_spl, t_geo * 1e3, t_scan * 1e3, f[:3]))
