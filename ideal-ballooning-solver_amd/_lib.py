@@ -26,6 +26,7 @@ SYMBOLS = {
     "ibs_synchronize": (C.c_int, [_P]),
     "ibs_device_count": (C.c_int, []),
     "ibs_solve_gcf_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
+    "ibs_solve_gcfh_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
     "ibs_solve_gcf_f32": (C.c_int, [_P, _I64, _I32, C.c_float, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
     "ibs_gamma_scan_f64": (C.c_int, [_P, _I32, _I32, _I32, _D, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _I32]),

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) k_surface_argmax(int n_per, const double*
 template <typename T>
 int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, const T* c, const T* f, int64_t ld,
                    T* lam, T* gam, T* X, T* dX, int32_t* info, int32_t mem,
-                   hipError_t (*const* table)(const ibs::GcfArgs<T>&, hipStream_t)) {
+                   hipError_t (*const* table)(const ibs::GcfArgs<T>&, hipStream_t), const T* gh = nullptr) {
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
   if (n_sys < 0 || !g || !c || !f || ld < N) return fail(IBS_ERR_ARG, "bad arguments (n_sys=%lld ld=%lld N=%d)", (long long)n_sys, (long long)ld, N);
   if (int r = check_grid(N, (double)h)) return r;
@@ -155,7 +155,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   auto launch = table[M];
   size_t per_wave = (size_t)3 * N * sizeof(T);
   if constexpr (sizeof(T) == 8) {
-    const int P = pick_lanes(ctx, N, (long)n_sys);
+    const int P = gh ? 64 : pick_lanes(ctx, N, (long)n_sys);
     if (P != 64) {
       const int Mg = (N - 2 + P - 1) / P;
       auto fn = ibs::launch_table().gcf_f64_g[P == 32 ? 0 : 1][Mg];
@@ -173,7 +173,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   int* d_nbad = nullptr;
   if (mem == IBS_MEM_HOST) {
     const size_t in_elems = (size_t)n_sys * ld, out_elems = (size_t)n_sys * N;
-    size_t need = 3 * pad256(in_elems * sizeof(T)) + 2 * pad256(n_sys * sizeof(T)) + 2 * pad256(out_elems * sizeof(T)) +
+    size_t need = 4 * pad256(in_elems * sizeof(T)) + 2 * pad256(n_sys * sizeof(T)) + 2 * pad256(out_elems * sizeof(T)) +
                   pad256(n_sys * sizeof(int)) + 4096;
     if (int r = ensure_ws(ctx, need)) return r;
     Arena ar(ctx);
@@ -185,6 +185,11 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     HIPCHK(hipMemcpyAsync(dc, c, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(df, f, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     a.g = dg; a.c = dc; a.f = df; a.lam = dlam; a.gam = dgam; a.X = dX_; a.dX = ddX; a.info = d_info;
+    if (gh) {
+      T* dgh = ar.take<T>(in_elems);
+      HIPCHK(hipMemcpyAsync(dgh, gh, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+      a.gh = dgh;
+    }
     HIPCHK(launch(a, ctx->stream));
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
@@ -198,7 +203,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return nbad;
   }
-  a.g = g; a.c = c; a.f = f; a.lam = lam; a.gam = gam; a.X = X; a.dX = dX; a.info = info;
+  a.g = g; a.c = c; a.f = f; a.lam = lam; a.gam = gam; a.X = X; a.dX = dX; a.info = info; a.gh = gh;
   HIPCHK(launch(a, ctx->stream));
   return 0;
 }
@@ -261,6 +266,13 @@ int ibs_solve_gcf_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const do
                       const double* f, int64_t ld, double* lam, double* gam, double* X, double* dX,
                       int32_t* info, int32_t mem) {
   return solve_gcf_impl<double>(ctx, n_sys, N, h, g, c, f, ld, lam, gam, X, dX, info, mem, ibs::launch_table().gcf_f64);
+}
+
+int ibs_solve_gcfh_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* gh,
+                       const double* c, const double* f, int64_t ld, double* lam, double* gam, double* X, double* dX,
+                       int32_t* info, int32_t mem) {
+  if (!gh) return fail(IBS_ERR_ARG, "gh is null");
+  return solve_gcf_impl<double>(ctx, n_sys, N, h, g, c, f, ld, lam, gam, X, dX, info, mem, ibs::launch_table().gcf_f64, gh);
 }
 
 int ibs_solve_gcf_f32(ibs_ctx* ctx, int64_t n_sys, int32_t N, float h, const float* g, const float* c,

@@ -19,6 +19,7 @@ namespace ibs {
 // ---------------------------------------------------------------- coefficient sources (LDS-backed)
 template <typename T>
 struct SrcGCF {
+  static constexpr bool kHasGh = false;
   const T* gs; const T* cs; const T* fs;
   __device__ __forceinline__ T g(int j) const { return gs[j]; }
   __device__ __forceinline__ T c(int j) const { return cs[j]; }
@@ -30,8 +31,20 @@ struct SrcGCF {
 //   C1 = -dPdrho cvdrift0/(|gradpar| B), G0 = gds2, G1 = gds21, G2 = gds22
 // so that for a given theta0 (ball_scan.py:267-268, utils.py:1560-1562)
 //   gds2_fth = G0 + 2 theta0 G1 + theta0^2 G2,  g = A1 gds2_fth,  f = A3 gds2_fth,  c = C0 + theta0 C1
+// raw (g, c, f) with a separately supplied half-grid g (regridded non-uniform input, utils.py:1567-1576)
+template <typename T>
+struct SrcGCFH {
+  static constexpr bool kHasGh = true;
+  const T* gs; const T* cs; const T* fs; const T* ghs;   // ghs: global memory, N-1 values
+  __device__ __forceinline__ T g(int j) const { return gs[j]; }
+  __device__ __forceinline__ T c(int j) const { return cs[j]; }
+  __device__ __forceinline__ T f(int j) const { return fs[j]; }
+  __device__ __forceinline__ T gh(int k) const { return ghs[k]; }
+};
+
 template <typename T>
 struct SrcGeo {
+  static constexpr bool kHasGh = false;
   const T* A1; const T* A3; const T* C0; const T* C1; const T* G0; const T* G1; const T* G2;
   T th0, two_th0, th0sq;
   __device__ __forceinline__ T gd(int j) const { return G0[j] + two_th0 * G1[j] + th0sq * G2[j]; }
@@ -134,7 +147,8 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
 template <typename T, int M>
 __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const T* __restrict__ g,
                                                    const T* __restrict__ c, const T* __restrict__ f, long ld,
-                                                   T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out) {
+                                                   T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out,
+                                                   const T* __restrict__ gh) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -150,7 +164,9 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   SrcGCF<T> src{gs, cs, fs};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
-  const bool bad = ws.setup(src, N, h);
+  bool bad;
+  if (gh) { SrcGCFH<T> srch{gs, cs, fs, gh + sysc * ld}; bad = ws.setup(srch, N, h); }   // wave-uniform branch
+  else bad = ws.setup(src, N, h);
   __syncthreads();   // every lane has taken its f chunk: the slot can be reused for X
   T lam = T(0);
   if (!bad) lam = ws.solve(inf);
@@ -441,7 +457,7 @@ static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
-                     a.lam, a.gam, a.X, a.dX, a.info);
+                     a.lam, a.gam, a.X, a.dX, a.info, a.gh);
   return hipGetLastError();
 }
 template <typename T>

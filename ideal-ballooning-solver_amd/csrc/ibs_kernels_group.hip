@@ -13,6 +13,7 @@ namespace ibs {
 
 template <typename T>
 struct SrcGlobal {   // raw (g, c, f) straight from global memory: a lane's chunk is M contiguous values
+  static constexpr bool kHasGh = false;
   const T* gs; const T* cs; const T* fs;
   __device__ __forceinline__ T g(int j) const { return gs[j]; }
   __device__ __forceinline__ T c(int j) const { return cs[j]; }
@@ -21,6 +22,7 @@ struct SrcGlobal {   // raw (g, c, f) straight from global memory: a lane's chun
 
 template <typename T>
 struct SrcGeoG {     // as SrcGeo (ibs_kernels.hip): 7 derived arrays of the line in LDS, theta0 per lane
+  static constexpr bool kHasGh = false;
   const T* A1; const T* A3; const T* C0; const T* C1; const T* G0; const T* G1; const T* G2;
   T th0, two_th0, th0sq;
   __device__ __forceinline__ T gd(int j) const { return G0[j] + two_th0 * G1[j] + th0sq * G2[j]; }

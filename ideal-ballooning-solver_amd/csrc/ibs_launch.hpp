@@ -11,6 +11,7 @@ template <typename T>
 struct GcfArgs {
   long n_sys; int N; T h; const T* g; const T* c; const T* f; long ld;
   T* lam; T* gam; T* X; T* dX; int* info; int wpb;
+  const T* gh;      // optional half-grid g [n_sys][ld] (N-1 used); null = mean of neighbouring g
 };
 template <typename T>
 struct ScanArgs {

@@ -258,9 +258,16 @@ struct WaveSolver {
     const int a = rows_start(lane, n);
     const T ih2 = T(1) / (h * h);
     T sc = T(1);
-    T gprev = src.g(a);
-    T gcur = src.g(a + 1);
-    T e_lo = T(0.5) * (gprev + gcur) * ih2;  // e_a
+    // half-grid g between grid points k and k+1 (utils.py:1574-1576): the mean of the neighbours on a uniform
+    // grid, or a caller-supplied array when the input grid was regridded (Src::kHasGh)
+    T gcur = T(0);
+    T e_lo;
+    if constexpr (Src::kHasGh) {
+      e_lo = src.gh(a) * ih2;
+    } else {
+      gcur = src.g(a + 1);
+      e_lo = T(0.5) * (src.g(a) + gcur) * ih2;  // e_a
+    }
     T vhi = -T(1e300), vlo = -T(1e300), vna = T(0), sum_c = T(0), sum_f = T(0);
     bool bad = false;
     const T e_first = e_lo;
@@ -269,8 +276,9 @@ struct WaveSolver {
       const bool act = (i < M - 1) || has_last;
       if (act) {
         const int j = a + i + 1;  // grid point of row a+i
-        const T gnext = src.g(j + 1);
-        const T e_hi = T(0.5) * (gcur + gnext) * ih2;  // e_{a+i+1}
+        T gnext = T(0), e_hi;                           // e_{a+i+1}
+        if constexpr (Src::kHasGh) { e_hi = src.gh(j) * ih2; }
+        else { gnext = src.g(j + 1); e_hi = T(0.5) * (gcur + gnext) * ih2; }
         const T cj = src.c(j), fj = src.f(j);
         const T d = cj - (e_lo + e_hi);
         const T s2 = sc * sc;

@@ -13,33 +13,52 @@ from ._lib import IbsError
 
 
 def uniform_spacing(theta, rtol=1e-9):
-    """h of a uniform grid; the reference regrids by np.interp (utils.py:1567-1571), which is the
-    identity on uniform grids.  Non-uniform grids are rejected (not silently mis-solved)."""
+    """h of a uniform grid (the batched geometry-fed entry points need one; gamma_ball_full also accepts
+    non-uniform grids and regrids like the reference)."""
     theta = np.asarray(theta, dtype=np.float64)
     N = len(theta)
     h = (theta[-1] - theta[0]) / (N - 1)
     if np.max(np.abs(np.diff(theta) - h)) > rtol * abs(h) * N:
-        raise IbsError("theta_PEST is not uniform; non-uniform grids are not supported by the HIP path yet")
+        raise IbsError("theta grid is not uniform: the batched entry points need a uniform grid (use gamma_ball_full)")
     return float(h)
 
 
+def is_uniform(theta, rtol=1e-9):
+    theta = np.asarray(theta, dtype=np.float64)
+    h = (theta[-1] - theta[0]) / (len(theta) - 1)
+    return bool(np.max(np.abs(np.diff(theta) - h)) <= rtol * abs(h) * len(theta))
+
+
 def gamma_ball_full(dPdrho, theta_PEST, B, gradpar, cvdrift, gds2, vguess=None, sigma0=0.42, ctx=None):
-    """reference: utils.py:1550-1624.  Returns (gam, X, dX, g, c, f) with the same meaning."""
+    """reference: utils.py:1550-1624.  Returns (gam, X, dX, g, c, f) with the same meaning.
+    Uniform grids go through the fused geometry-fed kernel; a non-uniform theta_PEST is regridded exactly
+    as upstream (np.interp of g, c, f onto the uniform grid, g interpolated at the uniform half points,
+    utils.py:1567-1576 -- elementwise host glue) and solved by the raw (g, gh, c, f) kernel."""
     ctx = ctx or default_context()
-    h = uniform_spacing(theta_PEST)
+    theta = np.asarray(theta_PEST, dtype=np.float64)
     B = np.asarray(B, dtype=np.float64)
     gradpar = np.asarray(gradpar, dtype=np.float64)
     cvdrift = np.asarray(cvdrift, dtype=np.float64)
     gds2 = np.asarray(gds2, dtype=np.float64)
     N = len(B)
-    z = np.zeros((1, N))
-    r = ctx.gamma_scan(h, B[None], gradpar[None], cvdrift[None], z, gds2[None], z, z,
-                       np.array([float(dPdrho)]), np.zeros(1), want_X=True)
     gp = np.abs(gradpar)
     g = gp * gds2 / B                         # utils.py:1560
     c = -1 * dPdrho * cvdrift * 1 / (gp * B)  # utils.py:1561
     f = gds2 / B ** 2 * 1 / (gp * B)          # utils.py:1562
-    return float(r["gam"][0, 0]), r["X"][0, 0], r["dX"][0, 0], g, c, f
+    if is_uniform(theta):
+        h = uniform_spacing(theta)
+        z = np.zeros((1, N))
+        r = ctx.gamma_scan(h, B[None], gradpar[None], cvdrift[None], z, gds2[None], z, z,
+                           np.array([float(dPdrho)]), np.zeros(1), want_X=True)
+        return float(r["gam"][0, 0]), r["X"][0, 0], r["dX"][0, 0], g, c, f
+    tu = np.linspace(theta[0], theta[-1], N)                       # utils.py:1565
+    g_u, c_u, f_u = np.interp(tu, theta, g), np.interp(tu, theta, c), np.interp(tu, theta, f)   # utils.py:1567-1571
+    th_half = (tu[:-1] + tu[1:]) / 2                                # utils.py:1574
+    h = np.diff(th_half)[2]                                         # utils.py:1575
+    gh = np.zeros(N)
+    gh[:-1] = np.interp(th_half, theta, g)                          # utils.py:1576
+    r = ctx.solve_gcf(h, g_u[None], c_u[None], f_u[None], want_X=True, gh=gh[None])
+    return float(r["gam"][0]), r["X"][0], r["dX"][0], g_u, c_u, f_u
 
 
 def dPdrho_of(cvdrift, gbdrift, bmag):

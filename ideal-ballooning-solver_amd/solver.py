@@ -87,8 +87,9 @@ class Context:
         check(self._lib.ibs_synchronize(self._h), "ibs_synchronize")
 
     # ---- raw (g, c, f) systems --------------------------------------------------------------
-    def solve_gcf(self, h, g, c, f, want_X=False, want_info=False, dtype=np.float64):
-        """g, c, f: (n_sys, N).  Returns dict(lam, gam[, X, dX][, info])."""
+    def solve_gcf(self, h, g, c, f, want_X=False, want_info=False, dtype=np.float64, gh=None):
+        """g, c, f: (n_sys, N).  Returns dict(lam, gam[, X, dX][, info]).  gh (n_sys, N) optional half-grid g
+        (first N-1 columns used): see ibs_solve_gcfh_f64."""
         ar = _Args(dtype)
         n_sys, N = g.shape
         pg, pc, pf = ar.inp(g), ar.inp(c), ar.inp(f)
@@ -100,9 +101,14 @@ class Context:
         X, pX = ar.out((n_sys, N), ref, want=want_X)
         dX, pdX = ar.out((n_sys, N), ref, want=want_X)
         info, pinfo = ar.out((n_sys,), ref, dtype=np.int32, want=want_info)
-        fn = self._lib.ibs_solve_gcf_f64 if np.dtype(dtype) == np.float64 else self._lib.ibs_solve_gcf_f32
         hh = float(h)
-        rc = check(fn(self._h, n_sys, N, hh, pg, pc, pf, N, plam, pgam, pX, pdX, pinfo, ar.mem), "ibs_solve_gcf")
+        if gh is not None:
+            pgh = ar.inp(gh)
+            rc = check(self._lib.ibs_solve_gcfh_f64(self._h, n_sys, N, hh, pg, pgh, pc, pf, N, plam, pgam, pX, pdX, pinfo,
+                                                    ar.mem), "ibs_solve_gcfh_f64")
+        else:
+            fn = self._lib.ibs_solve_gcf_f64 if np.dtype(dtype) == np.float64 else self._lib.ibs_solve_gcf_f32
+            rc = check(fn(self._h, n_sys, N, hh, pg, pc, pf, N, plam, pgam, pX, pdX, pinfo, ar.mem), "ibs_solve_gcf")
         out = dict(lam=lam, gam=gam, nbad=rc)
         if want_X:
             out.update(X=X, dX=dX)

@@ -56,6 +56,12 @@ int ibs_device_count(void);
 int ibs_solve_gcf_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
                       const double* f, int64_t ld, double* lam, double* gam, double* X, double* dX,
                       int32_t* info, int32_t mem);
+/* Same with the half-grid values gh[n_sys][ld] (gh[k] between grid points k and k+1, N-1 used) supplied by the
+ * caller instead of the mean of neighbouring g: what utils.py:1567-1576 produces for a NON-uniform theta_PEST
+ * (coefficients regridded by np.interp onto the uniform grid, g interpolated at the uniform half points). */
+int ibs_solve_gcfh_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* gh,
+                       const double* c, const double* f, int64_t ld, double* lam, double* gam, double* X, double* dX,
+                       int32_t* info, int32_t mem);
 int ibs_solve_gcf_f32(ibs_ctx* ctx, int64_t n_sys, int32_t N, float h, const float* g, const float* c,
                       const float* f, int64_t ld, float* lam, float* gam, float* X, float* dX,
                       int32_t* info, int32_t mem);

@@ -493,3 +493,24 @@ def test_config4_adjoint_step_emulated_dofs(ctx, bo):
     d_gpu = ibs_amd.dof_fd_gradient(f_gpu, steps)
     d_cpu = ibs_amd.dof_fd_gradient(f_cpu, steps)
     assert np.abs(d_gpu).max() > 0 and np.abs(d_gpu - d_cpu).max() < 1e-4 * max(1.0, np.abs(d_cpu).max())
+
+
+def test_gamma_ball_full_nonuniform_grid_regrids_like_reference(ctx, bo):
+    """non-uniform theta_PEST: utils.py:1567-1576 regrid semantics (oracle = same np.interp restatement)"""
+    import ibs_amd
+    N = 257
+    tu = bo.theta_grid(N)
+    th = tu + 0.35 * (tu[1] - tu[0]) * np.sin(3 * tu)             # monotone, non-uniform, same end points
+    th[0], th[-1] = tu[0], tu[-1]
+    lam_ = 1.0 * th - 0.8 * np.sin(th)
+    gds2 = 1 + lam_ ** 2
+    cv = 0.8 * (np.cos(th) + np.sin(th) * lam_)
+    B = 1 + 0.1 * np.cos(th)
+    gp = np.ones(N)
+    out = ibs_amd.gamma_ball_full(-1.0, th, B, gp, cv, gds2, ctx=ctx)
+    ref = bo.gamma_ball_full(-1.0, th, B, gp, cv, gds2)
+    assert abs(out[0] - ref[0]) < 1e-10
+    for a, b in zip(out[1:], ref[1:]):
+        assert np.abs(a - b).max() < 1e-7
+    uni = ibs_amd.gamma_ball_full(-1.0, tu, B, gp, cv, gds2, ctx=ctx)
+    assert abs(uni[0] - out[0]) > 1e-6                             # the regrid actually matters here

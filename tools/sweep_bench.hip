@@ -7,7 +7,7 @@
 #include "ibs_wave.hpp"
 using namespace ibs;
 constexpr int M = 8;
-struct Src { const double* gs; const double* cs; const double* fs;
+struct Src { static constexpr bool kHasGh = false; const double* gs; const double* cs; const double* fs;
   __device__ double g(int j) const { return gs[j]; } __device__ double c(int j) const { return cs[j]; } __device__ double f(int j) const { return fs[j]; } };
 
 template <int MODE>

@@ -5,7 +5,7 @@
 #include <vector>
 #include "ibs_group.hpp"
 using namespace ibs;
-struct Src { const double* gs; const double* cs; const double* fs;
+struct Src { static constexpr bool kHasGh = false; const double* gs; const double* cs; const double* fs;
   __device__ double g(int j) const { return gs[j]; } __device__ double c(int j) const { return cs[j]; } __device__ double f(int j) const { return fs[j]; } };
 
 template <int MODE, int M, int P>

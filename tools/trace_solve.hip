@@ -7,7 +7,7 @@
 #include <vector>
 #include "ibs_wave.hpp"
 using namespace ibs;
-struct Src { const double* gs; const double* cs; const double* fs;
+struct Src { static constexpr bool kHasGh = false; const double* gs; const double* cs; const double* fs;
   __device__ double g(int j) const { return gs[j]; } __device__ double c(int j) const { return cs[j]; } __device__ double f(int j) const { return fs[j]; } };
 template <int M>
 __global__ void __launch_bounds__(64) k(int N, double h, const double* g, const double* c, const double* f, double* trace, double* out) {
