@@ -140,12 +140,15 @@ struct RowStart {
   double tv, phi, ctv, stv;
   double m_cur, cm, sm;       // cos/sin(m_cur * tv)
   double n_cur, cn, sn;       // cos/sin(n_cur * phi)
-  __device__ __forceinline__ void init(double tv_, double phi_) {
-    tv = tv_; phi = phi_;
+  double n_keep, cn_keep, sn_keep;   // the last non-zero first-n seen: phi is fixed per point, so this survives init(tv)
+  __device__ __forceinline__ void init_phi(double phi_) { phi = phi_; n_keep = 0.0; cn_keep = 1.0; sn_keep = 0.0; }
+  __device__ __forceinline__ void init(double tv_) {
+    tv = tv_;
     sincos(tv, &stv, &ctv);
     m_cur = 0.0; cm = 1.0; sm = 0.0;
     n_cur = 0.0; cn = 1.0; sn = 0.0;
   }
+  __device__ __forceinline__ void init(double tv_, double phi_) { init_phi(phi_); init(tv_); }
   __device__ __forceinline__ void start(double m, double n0, double& ca, double& sa) {
     if (m != m_cur) {
       const double dm = m - m_cur;
@@ -156,18 +159,58 @@ struct RowStart {
       }
       m_cur = m;
     }
-    if (n0 != n_cur) { sincos(n0 * phi, &sn, &cn); n_cur = n0; }
+    if (n0 != n_cur) {
+      if (n0 == 0.0) { cn = 1.0; sn = 0.0; }
+      else {
+        if (n0 != n_keep) { sincos(n0 * phi, &sn_keep, &cn_keep); n_keep = n0; }
+        cn = cn_keep; sn = sn_keep;
+      }
+      n_cur = n0;
+    }
     ca = cm * cn + sm * sn;      // cos(m tv - n0 phi)
     sa = sm * cn - cm * sn;      // sin(m tv - n0 phi)
   }
 };
 
 // Same arithmetic with the mode lists walked row by row (all modes of one m): inside a row the angle
-// m theta - n phi decreases by a constant dn*phi per mode, so (cos, sin) advance by one plane rotation
-// (4 flops) instead of a sincos.  Rows hold <= 2 ntor + 1 <= ~30 modes: the rotation error stays ~1e-15.
-// LPP lanes cooperate on one grid point: lane `sub` takes modes sub, sub+LPP, ... of every row and the partial
-// sums are combined by an in-register butterfly.  LPP = 8 turns the long per-point dependency chain of small
-// batches into 8x more, 8x shorter threads; LPP = 1 is the throughput form for large batches.
+// m theta - n phi decreases by a constant D = dn*phi per mode, so cos and sin follow the three-term recurrence
+//   t[k+1] = 2 cos(D) t[k] - t[k-1]        (one fma each; rows hold <= ~60 modes: error growth ~k^2 eps)
+// instead of a sincos per mode.  One thread per grid point, one field line per block row.
+//
+// The surface's tables are staged once per block in LDS (every lane reads the same entry: broadcast,
+// conflict-free) with each row padded by zero coefficients to a multiple of 4 modes, so that the inner loops
+// are unrolled with all LDS reads of a group issued before its arithmetic (an un-unrolled loop exposes the
+// full LDS latency per mode: measured 2x slower).  Layout, mode numbers already multiplied in:
+//   lm   [P]      lmns (root solve)
+//   amn  [P][10]  rmnc d_rmnc m*rmnc n*rmnc | d_zmns m*zmns n*zmns | d_lmns m*lmns n*lmns
+//   anq  [Q][10]  gmnc bmnc d_bmnc m*bmnc n*bmnc bsupv bsubs bsubu bsubv (pad)
+// so a mode costs five 16-byte LDS reads and one fma per accumulated quantity.
+constexpr int kGeoBlock = 512;      // 8 waves share one staged table set; 2 blocks per CU -> 4 waves per SIMD
+constexpr int kGeoMaxRows = 128;
+
+__device__ __forceinline__ int geo_pad4(int n) { return (n + 3) & ~3; }
+__host__ __device__ inline int geo_cap(int nmodes, int nrows) { return (nmodes + 3 * nrows + 4 + 3) & ~3; }
+
+// padded offset table of one mode set (off[r] .. off[r+1]) and the (m, first n) of each row
+__device__ __forceinline__ void geo_row_tables(int t, int nrows, const int* rows, const double* xm, const double* xn,
+                                               int* off, double* rm, double* rn) {
+  if (t >= 0 && t <= nrows) {
+    int o = 0;
+    for (int q = 0; q < t; ++q) o += geo_pad4(rows[2 * q + 1]);
+    off[t] = o;
+    if (t < nrows) { const int k0 = rows[2 * t]; rm[t] = xm[k0]; rn[t] = xn[k0]; }
+  }
+}
+// padded position -> source mode (or -1 for padding)
+__device__ __forceinline__ int geo_src_mode(int idx, int nrows, const int* off, const int* rows) {
+  int r = 0;
+  while (r < nrows && off[r + 1] <= idx) ++r;
+  if (r >= nrows) return -1;
+  const int i = idx - off[r];
+  return i < rows[2 * r + 1] ? rows[2 * r] + i : -1;
+}
+
+// sum over the LPP adjacent lanes that share one grid point (in-register butterfly, quad_perm DPP)
 template <int LPP>
 __device__ __forceinline__ double group_sum(double v) {
   if constexpr (LPP >= 2)
@@ -176,71 +219,107 @@ __device__ __forceinline__ double group_sum(double v) {
   if constexpr (LPP >= 4)
     v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xF, 0xF, true),
                           __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  if constexpr (LPP >= 8)
-    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x141, 0xF, 0xF, true),
-                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
   return v;
 }
-
 template <int LPP>
-__global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
-  // the surface's mode tables are staged once per block in LDS (all lanes read the same entry: broadcast,
-  // conflict-free); from global memory each entry would be a dependent scalar-cache miss
+__device__ __forceinline__ int row_int(int v) {
+  if constexpr (LPP == 1) return __builtin_amdgcn_readfirstlane(v); else return v;
+}
+
+// LPP = 1: one lane per grid point (throughput form).  LPP = 2, 4: the rows (m values) of both mode sets are
+// dealt round-robin to LPP adjacent lanes and the partial sums combined by a butterfly: the per-point dependency
+// chain gets LPP times shorter, which is what bounds small batches (too few waves to hide it).
+template <int LPP>
+__device__ __forceinline__ void geo_rows_body(const GeoArgs& a) {
   extern __shared__ __align__(16) unsigned char geo_smem[];
-  double* sm = reinterpret_cast<double*>(geo_smem);
   const int line = blockIdx.y;
   const int js = a.line_surf[line];
-  double* xm_s = sm; double* xn_s = xm_s + a.mnmax;
-  double* tmn = xn_s + a.mnmax;                 // 6 x mnmax
-  double* xmq_s = tmn + 6 * a.mnmax; double* xnq_s = xmq_s + a.mnmax_nyq;
-  double* tnq = xnq_s + a.mnmax_nyq;            // 7 x mnmax_nyq
+  const int nr1 = a.nrows_mn, nr2 = a.nrows_nyq;
+  const int P = geo_cap(a.mnmax, nr1), Q = geo_cap(a.mnmax_nyq, nr2);
+  double* lm_s = reinterpret_cast<double*>(geo_smem);
+  double* amn = lm_s + P;
+  double* anq = amn + 10 * P;
+  double* rm1 = anq + 10 * Q; double* rn1 = rm1 + nr1;
+  double* rm2 = rn1 + nr1; double* rn2 = rm2 + nr2;
+  int* off1 = reinterpret_cast<int*>(rn2 + nr2); int* off2 = off1 + nr1 + 1;
   {
+    const int t = threadIdx.x;
+    geo_row_tables(t, nr1, a.rows_mn, a.xm, a.xn, off1, rm1, rn1);
+    geo_row_tables(t - 256, nr2, a.rows_nyq, a.xm_nyq, a.xn_nyq, off2, rm2, rn2);     // threads 256.. (t - 256 >= 0)
+    __syncthreads();
     const double* g_mn = a.tab_mn + (size_t)js * 6 * a.mnmax;
     const double* g_nq = a.tab_nyq + (size_t)js * 7 * a.mnmax_nyq;
-    for (int k = threadIdx.x; k < a.mnmax; k += blockDim.x) { xm_s[k] = a.xm[k]; xn_s[k] = a.xn[k]; }
-    for (int k = threadIdx.x; k < 6 * a.mnmax; k += blockDim.x) tmn[k] = g_mn[k];
-    for (int k = threadIdx.x; k < a.mnmax_nyq; k += blockDim.x) { xmq_s[k] = a.xm_nyq[k]; xnq_s[k] = a.xn_nyq[k]; }
-    for (int k = threadIdx.x; k < 7 * a.mnmax_nyq; k += blockDim.x) tnq[k] = g_nq[k];
+    const int n1 = a.mnmax, n2 = a.mnmax_nyq;
+    for (int idx = t; idx < P; idx += kGeoBlock) {
+      const int k = geo_src_mode(idx, nr1, off1, a.rows_mn);
+      double* q = amn + 10 * idx;
+      if (k >= 0) {
+        const double m = a.xm[k], n = a.xn[k];
+        const double rm = g_mn[k], zm = g_mn[n1 + k], lm = g_mn[2 * n1 + k];
+        lm_s[idx] = lm;
+        q[0] = rm; q[1] = g_mn[3 * n1 + k]; q[2] = m * rm; q[3] = n * rm;
+        q[4] = g_mn[4 * n1 + k]; q[5] = m * zm; q[6] = n * zm;
+        q[7] = g_mn[5 * n1 + k]; q[8] = m * lm; q[9] = n * lm;
+      } else {
+        lm_s[idx] = 0.0;
+        for (int c = 0; c < 10; ++c) q[c] = 0.0;
+      }
+    }
+    for (int idx = t; idx < Q; idx += kGeoBlock) {
+      const int k = geo_src_mode(idx, nr2, off2, a.rows_nyq);
+      double* q = anq + 10 * idx;
+      if (k >= 0) {
+        const double m = a.xm_nyq[k], n = a.xn_nyq[k];
+        const double bm = g_nq[n2 + k];
+        q[0] = g_nq[k]; q[1] = bm; q[2] = g_nq[2 * n2 + k]; q[3] = m * bm; q[4] = n * bm;
+        q[5] = g_nq[3 * n2 + k]; q[6] = g_nq[4 * n2 + k]; q[7] = g_nq[5 * n2 + k]; q[8] = g_nq[6 * n2 + k]; q[9] = 0.0;
+      } else {
+        for (int c = 0; c < 10; ++c) q[c] = 0.0;
+      }
+    }
   }
   __syncthreads();
   const int sub = threadIdx.x % LPP;
-  const int j_raw = (blockIdx.x * blockDim.x + threadIdx.x) / LPP;
-  const bool live = j_raw < a.N;           // lanes past the end keep computing (on the last point) so that the
-  const int j = live ? j_raw : a.N - 1;    // butterflies stay full; they just do not store
+  const int j_raw = (blockIdx.x * kGeoBlock + threadIdx.x) / LPP;
+  if ((int)(blockIdx.x * kGeoBlock + (threadIdx.x & ~63u)) / LPP >= a.N) return;   // whole wave past the end of the line (no barrier follows)
+  const bool live = j_raw < a.N;
+  const int j = live ? j_raw : a.N - 1;
   const double* sc = a.scal + 6 * js;
   const double s = sc[0], iota = sc[1], diota = sc[2], dp = sc[3], phiedge = sc[4], L = sc[5];
   const double alpha = a.line_alpha[line];
   const double tp = a.theta[j];
   const double phi = (tp - alpha) / iota;
-  const double* rmnc = tmn;
-  const double* zmns = rmnc + a.mnmax; const double* lmns = zmns + a.mnmax;
-  const double* drmnc = lmns + a.mnmax; const double* dzmns = drmnc + a.mnmax; const double* dlmns = dzmns + a.mnmax;
-  // the per-mode step dn (= nfp for VMEC tables) is the same in every row: its rotation is set up once
-  const double dn_mn = a.dn_mn, dn_nyq = a.dn_nyq;
-  double sd, cd, ss0, cs0;
-  sincos(LPP * dn_mn * phi, &sd, &cd);          // per-lane step: LPP modes
-  sincos(sub * dn_mn * phi, &ss0, &cs0);         // this lane's offset inside a row
+  double sD, cD;
+  sincos(a.dn_mn * phi, &sD, &cD);
+  double two_cD = 2.0 * cD;
+  RowStart rs;
+  rs.init_phi(phi);
   auto resid = [&](double tv) {
-    double acc = 0.0;
-    RowStart rs;
-    rs.init(tv, phi);
-    for (int r = 0; r < a.nrows_mn; ++r) {
-      const int k0 = a.rows_mn[2 * r], cnt = a.rows_mn[2 * r + 1];
-      double sa, ca;
-      rs.start(xm_s[k0], xn_s[k0], ca, sa);
-      { const double c2 = ca * cs0 + sa * ss0, s2 = sa * cs0 - ca * ss0; ca = c2; sa = s2; }
-      for (int k = k0 + sub; k < k0 + cnt; k += LPP) {
-        acc += lmns[k] * sa;
-        const double c2 = ca * cd + sa * sd, s2 = sa * cd - ca * sd;   // angle -= dn*phi
-        ca = c2; sa = s2;
+    double acc0 = 0.0, acc1 = 0.0;
+    rs.init(tv);
+    for (int r = sub; r < nr1; r += LPP) {
+      const int o = row_int<LPP>(off1[r]);
+      const int ng = (row_int<LPP>(off1[r + 1]) - o) >> 2;
+      double s0, c0;
+      rs.start(rm1[r], rn1[r], c0, s0);
+      double sm1 = s0 * cD + c0 * sD;              // sin of the (virtual) previous mode: angle + D
+      const double2* Lp = reinterpret_cast<const double2*>(lm_s + o);
+      for (int g = 0; g < ng; ++g) {
+        const double2 u = Lp[2 * g], v = Lp[2 * g + 1];
+        const double s1 = fma(two_cD, s0, -sm1);
+        const double s2 = fma(two_cD, s1, -s0);
+        const double s3 = fma(two_cD, s2, -s1);
+        acc0 = fma(u.x, s0, acc0); acc1 = fma(u.y, s1, acc1);
+        acc0 = fma(v.x, s2, acc0); acc1 = fma(v.y, s3, acc1);
+        sm1 = s3; s0 = fma(two_cD, s3, -s2);
       }
     }
-    return tp - (tv + group_sum<LPP>(acc));
+    return tp - (tv + group_sum<LPP>(acc0 + acc1));
   };
   // secant iteration (superlinear): once a step is below 1e-9 the next one lands at rounding level, so
-  // exactly one more update is taken and the loop ends (a test on the rounding-level step never fires)
-  // second secant point: one fixed-point step theta_p + resid(theta_p) (already O(lambda^2) close) instead
-  // of the reference's theta_p + 0.1; the root is the same, two evaluations fewer on average
+  // exactly one more update is taken and the loop ends (a test on the rounding-level step never fires).
+  // Second point: one fixed-point step theta_p + resid(theta_p) instead of the reference's theta_p + 0.1
+  // (same root, about two evaluations fewer).
   double p0 = tp;
   double q0 = resid(p0);
   double p1 = tp + q0;
@@ -258,52 +337,77 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_rows(GeoArgs a) {
   }
   const double tv = p1;
   double R = 0, R_s = 0, R_t = 0, R_p = 0, Z_s = 0, Z_t = 0, Z_p = 0, l_s = 0, l_t = 0, l_p = 0;
-  RowStart rs;
-  rs.init(tv, phi);
-  for (int r = 0; r < a.nrows_mn; ++r) {
-    const int k0 = a.rows_mn[2 * r], cnt = a.rows_mn[2 * r + 1];
+  rs.init(tv);
+  for (int r = sub; r < nr1; r += LPP) {
+    const int o = row_int<LPP>(off1[r]);
+    const int ng = (row_int<LPP>(off1[r + 1]) - o) >> 1;
     double sa, ca;
-    rs.start(xm_s[k0], xn_s[k0], ca, sa);
-    { const double c2 = ca * cs0 + sa * ss0, s2 = sa * cs0 - ca * ss0; ca = c2; sa = s2; }
-    for (int k = k0 + sub; k < k0 + cnt; k += LPP) {
-      const double m = xm_s[k], n = xn_s[k];
-      R += rmnc[k] * ca; R_s += drmnc[k] * ca; R_t -= rmnc[k] * m * sa; R_p += rmnc[k] * n * sa;
-      Z_s += dzmns[k] * sa; Z_t += zmns[k] * m * ca; Z_p -= zmns[k] * n * ca;
-      l_s += dlmns[k] * sa; l_t += lmns[k] * m * ca; l_p -= lmns[k] * n * ca;
-      const double c2 = ca * cd + sa * sd, s2 = sa * cd - ca * sd;
-      ca = c2; sa = s2;
+    rs.start(rm1[r], rn1[r], ca, sa);
+    double sm1 = sa * cD + ca * sD, cm1 = ca * cD - sa * sD;
+    const double2* q = reinterpret_cast<const double2*>(amn + 10 * o);
+    for (int g = 0; g < ng; ++g, q += 10) {
+      const double2 q0_ = q[0], q1_ = q[1], q2_ = q[2], q3_ = q[3], q4_ = q[4];
+      const double2 q5_ = q[5], q6_ = q[6], q7_ = q[7], q8_ = q[8], q9_ = q[9];
+      const double sb = fma(two_cD, sa, -sm1), cb = fma(two_cD, ca, -cm1);
+      R = fma(q0_.x, ca, R); R_s = fma(q0_.y, ca, R_s); R_t = fma(-q1_.x, sa, R_t); R_p = fma(q1_.y, sa, R_p);
+      Z_s = fma(q2_.x, sa, Z_s); Z_t = fma(q2_.y, ca, Z_t); Z_p = fma(-q3_.x, ca, Z_p);
+      l_s = fma(q3_.y, sa, l_s); l_t = fma(q4_.x, ca, l_t); l_p = fma(-q4_.y, ca, l_p);
+      R = fma(q5_.x, cb, R); R_s = fma(q5_.y, cb, R_s); R_t = fma(-q6_.x, sb, R_t); R_p = fma(q6_.y, sb, R_p);
+      Z_s = fma(q7_.x, sb, Z_s); Z_t = fma(q7_.y, cb, Z_t); Z_p = fma(-q8_.x, cb, Z_p);
+      l_s = fma(q8_.y, sb, l_s); l_t = fma(q9_.x, cb, l_t); l_p = fma(-q9_.y, cb, l_p);
+      sm1 = sb; cm1 = cb;
+      sa = fma(two_cD, sb, -sa); ca = fma(two_cD, cb, -ca);
     }
   }
-  const double* gmnc = tnq;
-  const double* bmnc = gmnc + a.mnmax_nyq; const double* dbmnc = bmnc + a.mnmax_nyq;
-  const double* bsupv = dbmnc + a.mnmax_nyq; const double* bsubs = bsupv + a.mnmax_nyq;
-  const double* bsubu = bsubs + a.mnmax_nyq; const double* bsubv = bsubu + a.mnmax_nyq;
+  if (a.dn_nyq != a.dn_mn) {
+    sincos(a.dn_nyq * phi, &sD, &cD);
+    two_cD = 2.0 * cD;
+  }
+  if constexpr (LPP > 1) {
+    R = group_sum<LPP>(R); R_s = group_sum<LPP>(R_s); R_t = group_sum<LPP>(R_t); R_p = group_sum<LPP>(R_p);
+    Z_s = group_sum<LPP>(Z_s); Z_t = group_sum<LPP>(Z_t); Z_p = group_sum<LPP>(Z_p);
+    l_s = group_sum<LPP>(l_s); l_t = group_sum<LPP>(l_t); l_p = group_sum<LPP>(l_p);
+  }
   double sqg = 0, modB = 0, B_s = 0, B_t = 0, B_p = 0, Bsup_phi = 0, Bsub_s = 0, Bsub_t = 0, Bsub_p = 0;
-  if (dn_nyq != dn_mn) { sincos(LPP * dn_nyq * phi, &sd, &cd); sincos(sub * dn_nyq * phi, &ss0, &cs0); }
-  R = group_sum<LPP>(R); R_s = group_sum<LPP>(R_s); R_t = group_sum<LPP>(R_t); R_p = group_sum<LPP>(R_p);
-  Z_s = group_sum<LPP>(Z_s); Z_t = group_sum<LPP>(Z_t); Z_p = group_sum<LPP>(Z_p);
-  l_s = group_sum<LPP>(l_s); l_t = group_sum<LPP>(l_t); l_p = group_sum<LPP>(l_p);
-  rs.init(tv, phi);
-  for (int r = 0; r < a.nrows_nyq; ++r) {
-    const int k0 = a.rows_nyq[2 * r], cnt = a.rows_nyq[2 * r + 1];
+  rs.init(tv);
+  for (int r = sub; r < nr2; r += LPP) {
+    const int o = row_int<LPP>(off2[r]);
+    const int ng = (row_int<LPP>(off2[r + 1]) - o) >> 1;
     double sa, ca;
-    rs.start(xmq_s[k0], xnq_s[k0], ca, sa);
-    { const double c2 = ca * cs0 + sa * ss0, s2 = sa * cs0 - ca * ss0; ca = c2; sa = s2; }
-    for (int k = k0 + sub; k < k0 + cnt; k += LPP) {
-      const double m = xmq_s[k], n = xnq_s[k];
-      sqg += gmnc[k] * ca; modB += bmnc[k] * ca; B_s += dbmnc[k] * ca;
-      B_t -= bmnc[k] * m * sa; B_p += bmnc[k] * n * sa;
-      Bsup_phi += bsupv[k] * ca; Bsub_s += bsubs[k] * sa; Bsub_t += bsubu[k] * ca; Bsub_p += bsubv[k] * ca;
-      const double c2 = ca * cd + sa * sd, s2 = sa * cd - ca * sd;
-      ca = c2; sa = s2;
+    rs.start(rm2[r], rn2[r], ca, sa);
+    double sm1 = sa * cD + ca * sD, cm1 = ca * cD - sa * sD;
+    const double2* q = reinterpret_cast<const double2*>(anq + 10 * o);
+    for (int g = 0; g < ng; ++g, q += 10) {
+      const double2 q0_ = q[0], q1_ = q[1], q2_ = q[2], q3_ = q[3], q4_ = q[4];
+      const double2 q5_ = q[5], q6_ = q[6], q7_ = q[7], q8_ = q[8], q9_ = q[9];
+      const double sb = fma(two_cD, sa, -sm1), cb = fma(two_cD, ca, -cm1);
+      sqg = fma(q0_.x, ca, sqg); modB = fma(q0_.y, ca, modB); B_s = fma(q1_.x, ca, B_s);
+      B_t = fma(-q1_.y, sa, B_t); B_p = fma(q2_.x, sa, B_p);
+      Bsup_phi = fma(q2_.y, ca, Bsup_phi); Bsub_s = fma(q3_.x, sa, Bsub_s); Bsub_t = fma(q3_.y, ca, Bsub_t);
+      Bsub_p = fma(q4_.x, ca, Bsub_p);
+      sqg = fma(q5_.x, cb, sqg); modB = fma(q5_.y, cb, modB); B_s = fma(q6_.x, cb, B_s);
+      B_t = fma(-q6_.y, sb, B_t); B_p = fma(q7_.x, sb, B_p);
+      Bsup_phi = fma(q7_.y, cb, Bsup_phi); Bsub_s = fma(q8_.x, sb, Bsub_s); Bsub_t = fma(q8_.y, cb, Bsub_t);
+      Bsub_p = fma(q9_.x, cb, Bsub_p);
+      sm1 = sb; cm1 = cb;
+      sa = fma(two_cD, sb, -sa); ca = fma(two_cD, cb, -ca);
     }
   }
-  sqg = group_sum<LPP>(sqg); modB = group_sum<LPP>(modB); B_s = group_sum<LPP>(B_s); B_t = group_sum<LPP>(B_t);
-  B_p = group_sum<LPP>(B_p); Bsup_phi = group_sum<LPP>(Bsup_phi); Bsub_s = group_sum<LPP>(Bsub_s);
-  Bsub_t = group_sum<LPP>(Bsub_t); Bsub_p = group_sum<LPP>(Bsub_p);
+  if constexpr (LPP > 1) {
+    sqg = group_sum<LPP>(sqg); modB = group_sum<LPP>(modB); B_s = group_sum<LPP>(B_s); B_t = group_sum<LPP>(B_t);
+    B_p = group_sum<LPP>(B_p); Bsup_phi = group_sum<LPP>(Bsup_phi); Bsub_s = group_sum<LPP>(Bsub_s);
+    Bsub_t = group_sum<LPP>(Bsub_t); Bsub_p = group_sum<LPP>(Bsub_p);
+  }
   if (!live || sub != 0) return;
   GEO_TAIL
 }
+
+// register budget: the throughput form is held to 128 VGPRs (4 waves per SIMD hide the LDS latency); the
+// latency forms run with few waves anyway and take what they need
+__global__ void __launch_bounds__(kGeoBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_fieldline_geometry_rows(GeoArgs a) { geo_rows_body<1>(a); }
+template <int LPP>
+__global__ void __launch_bounds__(kGeoBlock) k_fieldline_geometry_rows_split(GeoArgs a) { geo_rows_body<LPP>(a); }
 
 // dPdrho of each line: -0.5 mean((cvdrift - gbdrift) bmag^2)   (ball_scan.py:262)
 __global__ void __launch_bounds__(256) k_line_dPdrho(int n_lines, int N, long ld, const double* geo, double* dPdrho) {
@@ -322,24 +426,26 @@ __global__ void __launch_bounds__(256) k_line_dPdrho(int n_lines, int N, long ld
 }
 
 hipError_t launch_geometry(const GeoArgs& a, hipStream_t st) {
-  dim3 grid((a.N + 255) / 256, a.n_lines);
-  // lanes per point: measured (tools/bench_geo.py) 1 is best or within 15 % of best from 128 x 513 points up:
-  // the kernel is VALU bound, splitting a point over lanes only adds row-start work.  IBS_GEO_LPP overrides.
-  const size_t lds = (size_t)(8 * a.mnmax + 9 * a.mnmax_nyq) * sizeof(double);
-  if (a.nrows_mn > 0 && a.nrows_nyq > 0 && lds <= 150 * 1024) {
+  const size_t lds = (size_t)(11 * geo_cap(a.mnmax, a.nrows_mn) + 10 * geo_cap(a.mnmax_nyq, a.nrows_nyq) + 2 * (a.nrows_mn + a.nrows_nyq)) * sizeof(double)
+                     + (size_t)(a.nrows_mn + a.nrows_nyq + 2) * sizeof(int);
+  if (a.nrows_mn > 0 && a.nrows_nyq > 0 && a.nrows_mn <= kGeoMaxRows && a.nrows_nyq <= kGeoMaxRows && lds <= 150 * 1024) {
+    // lanes per point: 1.  The split forms (IBS_GEO_LPP = 2, 4: rows dealt to adjacent lanes) were measured
+    // slower at every shape tried (128 x 513: 120 / 144 / 135 us; 2048 x 1025: 1.74 / 2.17 / 2.71 ms): each
+    // block stages its own 68 KB of tables and only two blocks fit a CU, so more, smaller blocks do not shorten
+    // the critical path.  Kept as an experiment switch only.
     int lpp = 1;
     if (const char* e = getenv("IBS_GEO_LPP")) lpp = atoi(e);
     auto go = [&](auto kern, int l) {
       hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e1 != hipSuccess) return e1;
-      hipLaunchKernelGGL(kern, dim3((a.N * l + 255) / 256, a.n_lines), dim3(256), lds, st, a);
+      hipLaunchKernelGGL(kern, dim3((a.N * l + kGeoBlock - 1) / kGeoBlock, a.n_lines), dim3(kGeoBlock), lds, st, a);
       return hipSuccess;
     };
-    hipError_t e2 = lpp == 8 ? go(k_fieldline_geometry_rows<8>, 8) : lpp == 4 ? go(k_fieldline_geometry_rows<4>, 4)
-                  : lpp == 2 ? go(k_fieldline_geometry_rows<2>, 2) : go(k_fieldline_geometry_rows<1>, 1);
+    hipError_t e2 = lpp == 4 ? go(k_fieldline_geometry_rows_split<4>, 4)
+                  : lpp == 2 ? go(k_fieldline_geometry_rows_split<2>, 2) : go(k_fieldline_geometry_rows, 1);
     if (e2 != hipSuccess) return e2;
   } else {
-    hipLaunchKernelGGL(k_fieldline_geometry, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_fieldline_geometry, dim3((a.N + 255) / 256, a.n_lines), dim3(256), 0, st, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -1,3 +1,4 @@
+"""Geometry kernel alone (LPP from IBS_GEO_LPP, default 1) for rocprofv3 runs: three shapes, 5 launches each."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, ibs_amd
@@ -9,11 +10,8 @@ for ns, na, N in ((16, 8, 513), (5, 24, 969), (64, 32, 1025)):
     surf = np.repeat(np.arange(ns), na); al = np.tile(np.linspace(0, np.pi, na), ns)
     for lpp in (1, 2, 4):
         os.environ['IBS_GEO_LPP'] = str(lpp)
-        ts = []
-        for rep in range(4):
-            torch.cuda.synchronize(); a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            r = None
-            import ctypes
-            a.record(); r = ctx.fieldline_geometry(tabs, surf, al, th, device=dev); b.record(); torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b))
-        print('lines %d N %d LPP %d: %.3f ms (incl. host glue)' % (ns * na, N, lpp, min(ts)))
+        for rep in range(5):
+            r = ctx.fieldline_geometry(tabs, surf, al, th, device=dev)
+    os.environ.pop('IBS_GEO_LPP')
+    torch.cuda.synchronize()
+    print('done', ns * na, N)
