@@ -153,7 +153,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   if (!table[M]) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   HIPCHK(hipSetDevice(ctx->device));
   auto launch = table[M];
-  size_t per_wave = (size_t)3 * N * sizeof(T);
+  size_t per_wave = (size_t)3 * ibs::lds_pitch(N) * sizeof(T);
   if constexpr (sizeof(T) == 8) {
     const int P = gh ? 64 : pick_lanes(ctx, N, (long)n_sys);
     if (P != 64) {
@@ -298,7 +298,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   auto fn = ibs::launch_table().scan_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   HIPCHK(hipSetDevice(ctx->device));
-  const size_t per_arr = (size_t)N * sizeof(double);
+  const size_t per_arr = (size_t)ibs::lds_pitch(N) * sizeof(double);
   if (8 * per_arr > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
   int G = 1, cap = ibs::scan_max_threads(M) / 64;
   {
@@ -405,7 +405,7 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
   auto fn = ibs::launch_table().grad_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   HIPCHK(hipSetDevice(ctx->device));
-  const size_t per_wave = (size_t)8 * N * sizeof(double);
+  const size_t per_wave = (size_t)8 * ibs::lds_pitch(N) * sizeof(double);
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
   if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);

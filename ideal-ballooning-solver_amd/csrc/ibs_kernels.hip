@@ -21,9 +21,21 @@ template <typename T>
 struct SrcGCF {
   static constexpr bool kHasGh = false;
   const T* gs; const T* cs; const T* fs;
-  __device__ __forceinline__ T g(int j) const { return gs[j]; }
-  __device__ __forceinline__ T c(int j) const { return cs[j]; }
-  __device__ __forceinline__ T f(int j) const { return fs[j]; }
+  __device__ __forceinline__ T g(int j) const { return gs[lpos(j)]; }
+  __device__ __forceinline__ T c(int j) const { return cs[lpos(j)]; }
+  __device__ __forceinline__ T f(int j) const { return fs[lpos(j)]; }
+  __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { const int q = lpos(j); g_ = gs[q]; c_ = cs[q]; f_ = fs[q]; }
+};
+
+// growth-rate stage of k_solve_gcf: g, c from the padded LDS rows, f (whose slot now holds X) from global memory
+template <typename T>
+struct SrcGCFG {
+  static constexpr bool kHasGh = false;
+  const T* gs; const T* cs; const T* fg;
+  __device__ __forceinline__ T g(int j) const { return gs[lpos(j)]; }
+  __device__ __forceinline__ T c(int j) const { return cs[lpos(j)]; }
+  __device__ __forceinline__ T f(int j) const { return fg[j]; }
+  __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { const int q = lpos(j); g_ = gs[q]; c_ = cs[q]; f_ = fg[j]; }
 };
 
 // geometry of one field line staged in LDS as 7 derived arrays (shared by all theta0 of the line):
@@ -36,10 +48,11 @@ template <typename T>
 struct SrcGCFH {
   static constexpr bool kHasGh = true;
   const T* gs; const T* cs; const T* fs; const T* ghs;   // ghs: global memory, N-1 values
-  __device__ __forceinline__ T g(int j) const { return gs[j]; }
-  __device__ __forceinline__ T c(int j) const { return cs[j]; }
-  __device__ __forceinline__ T f(int j) const { return fs[j]; }
+  __device__ __forceinline__ T g(int j) const { return gs[lpos(j)]; }
+  __device__ __forceinline__ T c(int j) const { return cs[lpos(j)]; }
+  __device__ __forceinline__ T f(int j) const { return fs[lpos(j)]; }
   __device__ __forceinline__ T gh(int k) const { return ghs[k]; }
+  __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { const int q = lpos(j); g_ = gs[q]; c_ = cs[q]; f_ = fs[q]; }
 };
 
 template <typename T>
@@ -47,16 +60,37 @@ struct SrcGeo {
   static constexpr bool kHasGh = false;
   const T* A1; const T* A3; const T* C0; const T* C1; const T* G0; const T* G1; const T* G2;
   T th0, two_th0, th0sq;
-  __device__ __forceinline__ T gd(int j) const { return G0[j] + two_th0 * G1[j] + th0sq * G2[j]; }
-  __device__ __forceinline__ T g(int j) const { return A1[j] * gd(j); }
-  __device__ __forceinline__ T c(int j) const { return C0[j] + th0 * C1[j]; }
-  __device__ __forceinline__ T f(int j) const { return A3[j] * gd(j); }
+  // (rows are padded: element j at lpos(j))
+  __device__ __forceinline__ T gd(int j) const { const int q = lpos(j); return G0[q] + two_th0 * G1[q] + th0sq * G2[q]; }
+  __device__ __forceinline__ T g(int j) const { return A1[lpos(j)] * gd(j); }
+  __device__ __forceinline__ T c(int j) const { const int q = lpos(j); return C0[q] + th0 * C1[q]; }
+  __device__ __forceinline__ T f(int j) const { return A3[lpos(j)] * gd(j); }
   // d/dtheta0 tangents (utils.py:1669-1673)
-  __device__ __forceinline__ T gdp(int j) const { return T(2) * G1[j] + two_th0 * G2[j]; }
-  __device__ __forceinline__ T g_t(int j) const { return A1[j] * gdp(j); }
-  __device__ __forceinline__ T c_t(int j) const { return C1[j]; }
-  __device__ __forceinline__ T f_t(int j) const { return A3[j] * gdp(j); }
+  __device__ __forceinline__ T gdp(int j) const { const int q = lpos(j); return T(2) * G1[q] + two_th0 * G2[q]; }
+  __device__ __forceinline__ T g_t(int j) const { return A1[lpos(j)] * gdp(j); }
+  __device__ __forceinline__ T c_t(int j) const { return C1[lpos(j)]; }
+  __device__ __forceinline__ T f_t(int j) const { return A3[lpos(j)] * gdp(j); }
+  // (g, c, f) and their theta0 tangents at one point with each LDS value read once
+  __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const {
+    const int q = lpos(j);
+    const T d = G0[q] + two_th0 * G1[q] + th0sq * G2[q];
+    g_ = A1[q] * d; c_ = C0[q] + th0 * C1[q]; f_ = A3[q] * d;
+  }
+  __device__ __forceinline__ void gcf_with_tangent(int j, T& g_, T& c_, T& f_, T& gt, T& ct, T& ft) const {
+    const int q = lpos(j);
+    const T g1 = G1[q], g2 = G2[q], a1 = A1[q], a3 = A3[q], c1 = C1[q];
+    const T d = G0[q] + two_th0 * g1 + th0sq * g2, dp = T(2) * g1 + two_th0 * g2;
+    g_ = a1 * d; c_ = C0[q] + th0 * c1; f_ = a3 * d;
+    gt = a1 * dp; ct = c1; ft = a3 * dp;
+  }
 };
+
+// LDS rows are private to a wave: ordering inside the wave is all that is needed
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 struct NoTangent {};
 
@@ -94,35 +128,61 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
   for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
   m = uniform(wave_max(m));
   const int a = WaveSolver<T, M>::rows_start(lane, n);
+  const T rm = T(1) / m;
 #pragma unroll
   for (int i = 0; i < M; ++i)
-    if ((i < M - 1) || ws.has_last) Xs[a + i + 1] = x[i] / m;      // utils.py:1605
-  if (lane == 0) { Xs[0] = T(0); Xs[N - 1] = T(0); }                // utils.py:1607-1608
-  __syncthreads();
+    if ((i < M - 1) || ws.has_last) Xs[lpos(a + i + 1)] = x[i] * rm;      // utils.py:1605 (v / max|v|)
+  if (lane == 0) { Xs[lpos(0)] = T(0); Xs[lpos(N - 1)] = T(0); }          // utils.py:1607-1608
+  wave_lds_sync();                                                  // Xs is private to this wave
+  IBS_PROBE_AT(13);
+  // dX (utils.py:1610-1616) in one branch-free form: with the neighbour indices clamped to [0, N-1],
+  //   dX = A (X[j+1] - X[j-1]) + B (X[j+2] - X[j-2]),
+  //   (A, B) = (2/3, -1/12)/h inside, (1/2, 0)/h at j = 1, N-2, (2, -1/2)/h at j = 0, N-1
+  // (the one-sided end formulas -3/2 X0 + 2 X1 - 1/2 X2 and 1/2 X[N-3] - 2 X[N-2] + 3/2 X[N-1] regrouped).
   const T ih = T(1) / h;
+  const T A_in = (T(2) / T(3)) * ih, B_in = -ih / T(12), A_e1 = T(0.5) * ih, A_e0 = T(2) * ih, B_e0 = T(-0.5) * ih;
+  bool do_hf = false;
+  if constexpr (HF) do_hf = dth0_out != nullptr;
   T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0), ac = T(0), ag = T(0), af = T(0);
-  for (int j = lane; j < N; j += kWave) {
-    const T X = Xs[j];
-    const T dX = fd_derivative(Xs, j, N, ih);
-    const T w = T(simpson_w(j, N));
-    const T X2 = X * X, dX2 = dX * dX;
-    y0 += w * (src.c(j) * X2 - src.g(j) * dX2);                      // utils.py:1618
-    y1 += w * (src.f(j) * X2);                                       // utils.py:1619
-    if constexpr (HF) {
-      hc += w * (src.c_t(j) * X2); hg += w * (src.g_t(j) * dX2); hf += w * (src.f_t(j) * X2);
+#pragma unroll 3
+  for (int j0 = 0; j0 < N; j0 += kWave) {
+    const int j = j0 + lane;
+    const bool in = j < N;
+    const int jc = in ? j : N - 1;
+    const int jm1 = jc > 0 ? jc - 1 : 0, jm2 = jc > 1 ? jc - 2 : 0;
+    const int jp1 = jc < N - 1 ? jc + 1 : N - 1, jp2 = jc < N - 2 ? jc + 2 : N - 1;
+    const T X = Xs[lpos(jc)];
+    const T d1 = Xs[lpos(jp1)] - Xs[lpos(jm1)], d2 = Xs[lpos(jp2)] - Xs[lpos(jm2)];
+    const bool end0 = (jc == 0) || (jc == N - 1), end1 = (jc == 1) || (jc == N - 2);
+    const T A = end0 ? A_e0 : (end1 ? A_e1 : A_in), B = end0 ? B_e0 : (end1 ? T(0) : B_in);
+    const T dX = xfma(A, d1, B * d2);
+    const T w = in ? (end0 ? T(1) : ((jc & 1) ? T(4) : T(2))) : T(0);      // Simpson weights (the 1/3 cancels)
+    const T X2 = w * (X * X), dX2 = w * (dX * dX);
+    T g_, c_, f_;
+    if (do_hf) {
+      if constexpr (HF) {
+        T gt, ct, ft;
+        src.gcf_with_tangent(jc, g_, c_, f_, gt, ct, ft);
+        hc = xfma(ct, X2, hc); hg = xfma(gt, dX2, hg); hf = xfma(ft, X2, hf);
+      }
+    } else {
+      src.gcf(jc, g_, c_, f_);
     }
+    y0 += c_ * X2 - g_ * dX2;                                        // utils.py:1618
+    y1 = xfma(f_, X2, y1);                                           // utils.py:1619
     if constexpr (!std::is_same<Tan, NoTangent>::value) {
       T ga, ca, fa;
-      tan->at(j, ga, ca, fa);
-      ac += w * (ca * X2); ag += w * (ga * dX2); af += w * (fa * X2);
+      tan->at(jc, ga, ca, fa);
+      ac = xfma(ca, X2, ac); ag = xfma(ga, dX2, ag); af = xfma(fa, X2, af);
     }
-    if (X_out) X_out[sys * N + j] = X;
-    if (dX_out) dX_out[sys * N + j] = dX;
+    if (X_out && in) X_out[sys * N + j] = X;
+    if (dX_out && in) dX_out[sys * N + j] = dX;
   }
+  IBS_PROBE_AT(14);
   y0 = wave_sum(y0); y1 = wave_sum(y1);
   const T gam = y0 / y1;                                             // utils.py:1621 (the 1/3 of Simpson cancels)
   if constexpr (HF) {
-    if (dth0_out) {
+    if (do_hf) {
       hc = wave_sum(hc); hg = wave_sum(hg); hf = wave_sum(hf);
       const T jac = hc / y1 - hg / y1 - gam * hf / y1;               // utils.py:1676-1680
       if (lane == 0) dth0_out[sys] = jac;
@@ -156,30 +216,31 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   const long sys = (long)blockIdx.x * wpb + wave;
   const bool valid = sys < n_sys;
   const long sysc = valid ? sys : (n_sys - 1);
-  T* gs = smem + (size_t)wave * 3 * N;
-  T* cs = gs + N; T* fs = cs + N; T* Xs = fs;
+  const int P = lds_pitch(N);
+  T* gs = smem + (size_t)wave * 3 * P;
+  T* cs = gs + P; T* fs = cs + P; T* Xs = fs;
   const T* gg = g + sysc * ld; const T* cg = c + sysc * ld; const T* fg = f + sysc * ld;
-  for (int j = lane; j < N; j += kWave) { gs[j] = gg[j]; cs[j] = cg[j]; fs[j] = fg[j]; }
-  __syncthreads();
+  for (int j = lane; j < N; j += kWave) { const int q = lpos(j); gs[q] = gg[j]; cs[q] = cg[j]; fs[q] = fg[j]; }
+  wave_lds_sync();   // the staging rows are private to this wave
   SrcGCF<T> src{gs, cs, fs};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
   bool bad;
   if (gh) { SrcGCFH<T> srch{gs, cs, fs, gh + sysc * ld}; bad = ws.setup(srch, N, h); }   // wave-uniform branch
   else bad = ws.setup(src, N, h);
-  __syncthreads();   // every lane has taken its f chunk: the slot can be reused for X
+  wave_lds_sync();   // every lane has taken its f chunk: the (wave-private) slot can be reused for X
   T lam = T(0);
   if (!bad) lam = ws.solve(inf);
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
-  src.fs = fg;       // growth-rate stage: f from global memory
-  finish<T, M, SrcGCF<T>, false>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+  const SrcGCFG<T> srcf{gs, cs, fg};       // growth-rate stage: f from global memory
+  finish<T, M, SrcGCFG<T>, false>(ws, srcf, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                  valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
                                  nullptr, valid ? info_out : nullptr);
 }
 
 // ---------------------------------------------------------------- geometry-fed theta0 scan
 // grid = n_lines * ceil(n_theta0 / wpb) blocks; block = wpb waves; wave w solves theta0 index part*wpb + w.
-// dynamic LDS = (7 + wpb) * N * sizeof(T).  Geometry arrays are [n_lines][ld].
+// dynamic LDS = (7 + wpb) * lds_pitch(N) * sizeof(T).  Geometry arrays are [n_lines][ld].
 template <typename T, int M>
 __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines, int n_theta0, int N, T h,
                                                      const T* __restrict__ bmag, const T* __restrict__ gradpar,
@@ -193,6 +254,7 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
+  IBS_PROBE_AT(0);
   // XCD-aware block -> (line, part) map.  Workgroups are dealt round-robin over the 8 XCDs, so blocks b
   // and b+8 share an L2: the `nparts` blocks that scan different theta0 of ONE line are placed 8 apart
   // and the line's geometry is fetched from HBM once per XCD instead of once per block (speed only).
@@ -206,22 +268,25 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
     part = r / lines_here;
     if (part >= nparts) return;   // cannot happen (r < lines_here*nparts is guaranteed by the grid size)
   }
-  T* A1 = smem; T* A3 = A1 + N; T* C0 = A3 + N; T* C1 = C0 + N; T* G0 = C1 + N; T* G1 = G0 + N; T* G2 = G1 + N;
-  T* Xs = G2 + N + (size_t)wave * N;
+  const int P = lds_pitch(N);
+  T* A1 = smem; T* A3 = A1 + P; T* C0 = A3 + P; T* C1 = C0 + P; T* G0 = C1 + P; T* G1 = G0 + P; T* G2 = G1 + P;
+  T* Xs = G2 + P + (size_t)wave * P;
   {
     const long off = (long)line * ld;
     const T mdP = -dPdrho[line];
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
       const T B = bmag[off + j], gp = xabs(gradpar[off + j]);
       const T inv = T(1) / (gp * B);                    // 1/(|gradpar| B)
-      A1[j] = gp / B;                                   // g = |gradpar| gds2 / B        (utils.py:1560)
-      A3[j] = inv / (B * B);                            // f = gds2/B^2 /(|gradpar| B)   (utils.py:1562)
-      C0[j] = mdP * cvdrift[off + j] * inv;             // c = -dPdrho cvdrift/(|gradpar| B) (utils.py:1561)
-      C1[j] = mdP * cvdrift0[off + j] * inv;
-      G0[j] = gds2[off + j]; G1[j] = gds21[off + j]; G2[j] = gds22[off + j];
+      const int q = lpos(j);
+      A1[q] = gp / B;                                   // g = |gradpar| gds2 / B        (utils.py:1560)
+      A3[q] = inv / (B * B);                            // f = gds2/B^2 /(|gradpar| B)   (utils.py:1562)
+      C0[q] = mdP * cvdrift[off + j] * inv;             // c = -dPdrho cvdrift/(|gradpar| B) (utils.py:1561)
+      C1[q] = mdP * cvdrift0[off + j] * inv;
+      G0[q] = gds2[off + j]; G1[q] = gds21[off + j]; G2[q] = gds22[off + j];
     }
   }
   __syncthreads();
+  IBS_PROBE_AT(1);
   const int it0 = part * wpb + wave;
   const bool valid = it0 < n_theta0;
   const int it0c = valid ? it0 : (n_theta0 - 1);
@@ -230,13 +295,16 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
   const bool bad = ws.setup(src, N, h);
+  IBS_PROBE_AT(2);
   const long sys = (long)line * n_theta0 + it0c;
   T lam = T(0);
   if (!bad) lam = lam_guess ? ws.solve(inf, true, lam_guess[sys], guess_width) : ws.solve(inf);
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  IBS_PROBE_AT(3);
   finish<T, M, SrcGeo<T>, true>(ws, src, N, h, Xs, lam, inf, sys, valid ? lam_out : nullptr,
                                 valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
                                 valid ? dth0_out : nullptr, valid ? info_out : nullptr);
+  IBS_PROBE_AT(4);
 }
 
 
@@ -261,8 +329,9 @@ __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const
   const int pt = blockIdx.x * wpb + wave;
   const bool valid = pt < n_pts;
   const int ptc = valid ? pt : (n_pts - 1);
-  T* A1 = smem + (size_t)wave * 8 * N;
-  T* A3 = A1 + N; T* C0 = A3 + N; T* C1 = C0 + N; T* G0 = C1 + N; T* G1 = G0 + N; T* G2 = G1 + N; T* Xs = G2 + N;
+  const int P = lds_pitch(N);
+  T* A1 = smem + (size_t)wave * 8 * P;
+  T* A3 = A1 + P; T* C0 = A3 + P; T* C1 = C0 + P; T* G0 = C1 + P; T* G1 = G0 + P; T* G2 = G1 + P; T* Xs = G2 + P;
   const T* pl = geo + ((long)ptc * 3 + 0) * 8 * ld;
   const T* pc = geo + ((long)ptc * 3 + 1) * 8 * ld;
   const T* pr = geo + ((long)ptc * 3 + 2) * 8 * ld;
@@ -270,11 +339,12 @@ __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const
   for (int j = lane; j < N; j += kWave) {
     const T B = pc[j], gp = xabs(pc[ld + j]);
     const T inv = T(1) / (gp * B);
-    A1[j] = gp / B; A3[j] = inv / (B * B);
-    C0[j] = -dP_c * pc[2 * ld + j] * inv; C1[j] = -dP_c * pc[3 * ld + j] * inv;
-    G0[j] = pc[4 * ld + j]; G1[j] = pc[5 * ld + j]; G2[j] = pc[6 * ld + j];
+    const int q = lpos(j);
+    A1[q] = gp / B; A3[q] = inv / (B * B);
+    C0[q] = -dP_c * pc[2 * ld + j] * inv; C1[q] = -dP_c * pc[3 * ld + j] * inv;
+    G0[q] = pc[4 * ld + j]; G1[q] = pc[5 * ld + j]; G2[q] = pc[6 * ld + j];
   }
-  __syncthreads();
+  wave_lds_sync();   // the staging rows are private to this wave
   const T th0 = theta0[ptc];
   SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
   WaveSolver<T, M> ws;
@@ -288,8 +358,7 @@ __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const
   finish<T, M, SrcGeo<T>, true, AlphaTangent<T>>(ws, src, N, h, Xs, lam, inf, ptc, nullptr, valid ? gam_out : nullptr,
                                                  nullptr, nullptr, valid ? dth0_out : nullptr,
                                                  valid ? info_out : nullptr, &tan, valid ? dalpha_out : nullptr);
-  __syncthreads();
-  if (valid && lane == 0) {
+  if (valid && lane == 0) {      // lane 0 wrote the three scratch values itself
     val_out[pt] = -gam_out[pt];                                      // utils.py:1728
     jac_out[2 * pt] = -dalpha_out[pt];
     jac_out[2 * pt + 1] = -dth0_out[pt];
@@ -333,12 +402,6 @@ struct RowRegs {
     if (lane == 0) { dst[0] = head_v; dst[N - 1] = tail_v; }
   }
 };
-// LDS rows are private to a wave: ordering inside the wave is all that is needed
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <typename T>
 struct M2s { T a, b, c, d; };
@@ -451,7 +514,7 @@ __global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, con
 template <typename T>
 static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
-  const size_t lds = (size_t)wpb * 3 * a.N * sizeof(T);
+  const size_t lds = (size_t)wpb * 3 * lds_pitch(a.N) * sizeof(T);
   const long nblk = (a.n_sys + wpb - 1) / wpb;
   auto kern = k_solve_gcf<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -463,7 +526,7 @@ static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
 template <typename T>
 static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
-  const size_t lds = (size_t)(7 + wpb) * a.N * sizeof(T);
+  const size_t lds = (size_t)(7 + wpb) * lds_pitch(a.N) * sizeof(T);
   auto kern = k_gamma_scan<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -489,7 +552,7 @@ static hipError_t launch_sturm(const SturmArgs<T>& a, hipStream_t st) {
 template <typename T>
 static hipError_t launch_grad(const GradArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
-  const size_t lds = (size_t)wpb * 8 * a.N * sizeof(T);
+  const size_t lds = (size_t)wpb * 8 * lds_pitch(a.N) * sizeof(T);
   auto kern = k_obj_w_grad<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

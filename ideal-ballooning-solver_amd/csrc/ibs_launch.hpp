@@ -45,6 +45,11 @@ struct LaunchTable {
 LaunchTable& launch_table();
 
 // threads per block the scan kernel is compiled for (register budget: 5M doubles per lane)
+// LDS rows of the wave kernels are padded by one element per 8 (element j lives at j + (j >> 3)): a lane reads a
+// contiguous chunk of ~M rows, i.e. lanes are M elements apart, and for even M (8 at N = 513) an unpadded row
+// puts 16 lanes on the same banks.  Row pitch in elements:
+constexpr int lds_pitch(int N) { return N + (N >> 3) + 1; }
+
 constexpr int scan_max_threads(int M) { return M <= 16 ? 512 : 256; }
 constexpr int scan_max_threads_g(int M) { return M <= 8 ? 512 : 256; }   // sub-wave kernels (ibs_group.hpp)
 

@@ -28,6 +28,16 @@ namespace ibs {
 
 constexpr int kWave = 64;
 
+// phase timestamps for tools/phase_probe.hip (debug builds only; the library is built without IBS_PROBE)
+#ifdef IBS_PROBE
+__device__ long long ibs_probe_buf[16 * 4096];
+#define IBS_PROBE_AT(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) ibs_probe_buf[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define IBS_PROBE_AT(k) do {} while (0)
+#endif
+
+
+
 // ---------------------------------------------------------------- scalar helpers (f64 / f32)
 __device__ __forceinline__ int fexp(double x) { return __builtin_amdgcn_frexp_exp(x); }
 __device__ __forceinline__ int fexp(float x) { return __builtin_amdgcn_frexp_expf(x); }
@@ -59,6 +69,32 @@ __device__ __forceinline__ float fast_rcp(float x) {
   float r = __builtin_amdgcn_rcpf(x);
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
+
+// cheaper variants for quantities that only PROPOSE a shift (relative error ~1e-8 is harmless there):
+// hardware seed + one Newton step
+__device__ __forceinline__ double approx_rcp(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ float approx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double approx_sqrt(double x) {      // x >= 0, well scaled
+  const double y = __builtin_amdgcn_rsq(x);
+  const double s = x * y;
+  return x > 0.0 ? __builtin_fma(0.5 * y, __builtin_fma(-s, s, x), s) : 0.0;
+}
+__device__ __forceinline__ float approx_sqrt(float x) { return __builtin_sqrtf(x); }
+
+// integer-built exponent helpers (v_frexp_exp / v_ldexp are slow-rate FP64 instructions):
+// expo_of: e with |x| in [2^e, 2^(e+1)) for normal x, a large negative number for 0 / denormals
+__device__ __forceinline__ int expo_of(double x) { const int eb = (__double2hiint(x) >> 20) & 0x7ff; return eb ? eb - 1023 : -(1 << 28); }
+__device__ __forceinline__ int expo_of(float x) { const int eb = (__float_as_int(x) >> 23) & 0xff; return eb ? eb - 127 : -(1 << 28); }
+// pow2_of<T>(k) = 2^k for k within the normal range (callers clamp)
+template <typename T> __device__ __forceinline__ T pow2_of(int k);
+template <> __device__ __forceinline__ double pow2_of<double>(int k) { return __hiloint2double((k + 1023) << 20, 0); }
+template <> __device__ __forceinline__ float pow2_of<float>(int k) { return __int_as_float((k + 127) << 23); }
+template <typename T> struct ExpLim;
+template <> struct ExpLim<double> { static constexpr int v = 1000; };
+template <> struct ExpLim<float> { static constexpr int v = 120; };
 
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
@@ -241,6 +277,8 @@ struct WaveSolver {
   int Eu, Ew;      // power-of-two exponents of this lane's forward / backward solutions
   // bounds
   T lo, hi, normA;
+  // shooting value of the last forward sweep (mantissa-like, power-of-two exponent)
+  T shoot_m; int shoot_e;
 
   // rows of this lane: [start, start+cnt)
   __device__ __forceinline__ static int rows_start(int lane, int n) {
@@ -295,6 +333,7 @@ struct WaveSolver {
         S[i] = T(0); D[i] = T(0); Ph[i] = T(0);
       }
     }
+    IBS_PROBE_AT(8);
     kap = sc; ikap = fast_rcp(sc);
     bad = bad || !(e_first > T(0));
     // wave-level bounds:  lam_max <= max c/f (Gershgorin);  lam_max >= any Rayleigh quotient
@@ -306,6 +345,7 @@ struct WaveSolver {
     lo = uniform(xmax(wave_max(vlo), (sc_all - e0 - en) / sf_all));
     hi += T(8) * Eps<T>::v * normA;
     lo -= T(8) * Eps<T>::v * normA;
+    IBS_PROBE_AT(9);
     return __any(bad) != 0;
   }
 
@@ -325,6 +365,9 @@ struct WaveSolver {
     F.a = fA * kap; F.b = fB * kap; F.c = fAp * ikap; F.d = fBp * ikap; F.e = 0;
     renorm(F);
     const M2<T> P = scan_fwd(F, lane);
+    // shooting value: the forward solution one row past the end, u_{n+1}(sig) = kap_63 * P_63.a * 2^P_63.e, is
+    // the characteristic polynomial of the pencil up to a sig-independent positive factor
+    shoot_m = readlane_t(P.a, kWave - 1); shoot_e = readlane_i(P.e, kWave - 1);
     // incoming vector: first column of the left neighbour's inclusive product; (1,0) at the left end
     const T u0 = dpp_t<0x138, 0xF>(T(1), P.a);   // wave_shr:1
     const T um = dpp_t<0x138, 0xF>(T(0), P.c);
@@ -449,91 +492,199 @@ struct WaveSolver {
     }
   }
 
-  // safeguarded Newton / bisection on the shift.  The bracket [lo, hi] is moved by Sturm counts ONLY
-  // (count(lo) >= 1, count(hi) == 0: backward-stable certificates); the Rayleigh/Newton estimate rho of
-  // the twisted vector merely proposes the next shift (in floating point it is not a rigorous bound:
-  // the recurrences are unstable where the solution decays).  The solve ends when the certified bracket
-  // is narrower than 4 tol; near convergence the proposals aim tol to the uncertified side so that two
-  // counts close the bracket.  On return the last sweep (with its twisted vector) was taken inside the
-  // final bracket, so assemble() gives the eigenvector.
+  // Root finder on the shift.  Every forward sweep returns the Sturm count C(sig) AND the shooting value
+  // p(sig) = u_{n+1}(sig) (characteristic polynomial up to a constant).  The bracket [lo, hi] is moved by counts
+  // ONLY (count(lo) >= 1, count(hi) == 0: backward-stable certificates).  Until a shift with C == 1 has been
+  // seen the bracket is bisected; from then on lo lies between lam_2 and lam_max, p has the single root lam_max
+  // in the bracket, and the next shift is proposed Brent-style from the shooting values: the root of the
+  // parabola through the two bracket ends and the most recently replaced end (Muller; secant with two points),
+  // accepted only if it lies in the 3/4 of the bracket next to the end with the smaller |p| and the step is
+  // less than half the previous one (else bisection), so the far regime (hi many eigenvalue gaps above
+  // lam_max, where interpolation crawls) costs no more than bisection.  A proposal within 4096 tol of that end
+  // that follows another interpolation step is trusted to ~tol and the missing count certificate is placed
+  // tol beyond it (the offset doubles whenever such a certificate fails), so that two counts close the bracket.
+  // The solve ends when the certified bracket is narrower than 4 tol; ONE backward sweep + twisted
+  // factorisation at the last shift then gives the eigenvector (assemble()) and the Rayleigh-quotient polish.
+  // Cost model (tools/sweep_bench.hip, 1 wave per SIMD): forward sweep 0.66 us, backward sweep + twisted 1.3 us;
+  // the earlier twisted-Newton iteration needed ~15 forward and ~10 backward/twisted per D3D-shape system,
+  // this one ~15.5 forward and one backward/twisted.
 #ifdef IBS_TRACE
-  T* trace = nullptr;   // debug builds only (tools/trace_solve.hip): 5 values per iteration
+  T* trace = nullptr;   // debug builds only (tools/trace_solve.hip): 6 values per iteration
 #endif
+  struct Pt { T x, m; int e; };      // shift, shooting value m * 2^e
+  // All quantities of the shift iteration are wave-uniform but live in VGPRs (there is no scalar FP64), and a
+  // branch on a VALU compare is compiled as a divergent one (exec masking, copies of every live value).  U()
+  // turns such a compare into a scalar condition (ballot != 0: all lanes agree), so the control flow of the
+  // iteration is scalar branches.
+  __device__ __forceinline__ static bool U(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+  __device__ __forceinline__ static int lg2_of(const Pt& p) { const int e = expo_of(p.m); return e < -(1 << 27) ? e : p.e + e; }
+  // Root of the parabola through (o, a, b) -- or of the secant through (a, b) when !use_o or the parabola has
+  // no root in the bracket -- that lies in (lo_, hi_) nearest b.  Branch-free, one reciprocal level deep:
+  // with h1 = a.x - o.x, h2 = b.x - a.x (both scaled by a power of two so that |h2| is in [1, 2)) and
+  //   QA = (f2-f1) h1 - (f1-f0) h2,  QB = QA h2 + (f2-f1) h1 (h1+h2),  H = h1 h2 (h1+h2)
+  // the parabola a z^2 + b z + f2 in z = x - b.x has a = QA/H, b = QB/H, so its roots are
+  //   z = -2 f2 H / (QB +- sqrt(QB^2 - 4 QA f2 H))  and  z = -(QB +- sqrt(..)) / (2 QA).
+  __device__ __forceinline__ static bool interpolate(const Pt& o, bool use_o, const Pt& a, const Pt& b,
+                                                     T lo_, T hi_, T& rho) {
+    constexpr int L = ExpLim<T>::v;
+    int emax = a.e > b.e ? a.e : b.e;
+    if (use_o && o.e > emax) emax = o.e;
+    auto val = [&](const Pt& p) { int d = p.e - emax; d = d < -L ? -L : d; return p.m * pow2_of<T>(d); };
+    const T x2 = b.x, f1 = val(a), f2 = val(b), f0 = val(o);
+    const T h2r = x2 - a.x;
+    int k = expo_of(h2r);
+    k = k < -L ? -L : (k > L ? L : k);
+    const T sc = pow2_of<T>(-k), back = pow2_of<T>(k);
+    const T h2 = h2r * sc, h1 = (a.x - o.x) * sc;
+    const T df21 = f2 - f1;
+    // secant
+    const T z_s = -f2 * h2 * approx_rcp(df21);
+    const T r_s = xfma(z_s, back, x2);
+    const bool in_s = finite_of(r_s) && r_s > lo_ && r_s < hi_;
+    // parabola
+    const T S = h1 + h2;
+    const T QA = xfma(df21, h1, -(f1 - f0) * h2);
+    const T QB = xfma(QA, h2, df21 * h1 * S);
+    const T H = h1 * h2 * S;
+    const T disc = xfma(QB, QB, -T(4) * QA * f2 * H);
+    const T sq = approx_sqrt(xmax(disc, T(0)));
+    const T den = QB >= T(0) ? QB + sq : QB - sq;          // the denominator of larger magnitude
+    const T z1 = -T(2) * f2 * H * approx_rcp(den);          // root nearer to b
+    const T z2 = -den * approx_rcp(T(2) * QA);              // the other root
+    const T r1 = xfma(z1, back, x2), r2 = xfma(z2, back, x2);
+    const bool par = use_o && disc >= T(0) && H != T(0);
+    const bool in1 = par && finite_of(r1) && r1 > lo_ && r1 < hi_;
+    const bool in2 = par && finite_of(r2) && r2 > lo_ && r2 < hi_;
+    const bool pick1 = in1 && (!in2 || xabs(z1) <= xabs(z2));
+    rho = pick1 ? r1 : (in2 ? r2 : r_s);
+    return in1 || in2 || in_s;
+  }
   // Optional warm start: `guess` is an estimate of lam_max from a nearby problem (previous optimizer
   // iteration, DOF-perturbed equilibrium: sims_runner_NCSX.py:151-276 re-scans 72 perturbed equilibria),
   // `width` its expected error.  The first shift is guess + width; if the count says lam_max is still
-  // above, the shift walks up geometrically until the count certifies an upper bound.
+  // above, the shift walks up geometrically until the count certifies an upper bound; the next shift is
+  // guess - width (expected count 1).
   __device__ __forceinline__ T solve(SolveInfo& inf, bool warm = false, T guess = T(0), T width = T(0)) {
     // f64: 64 ulp of ||A||;  f32: 8 ulp (the counts themselves are only good to ~eps32*||A||)
     const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
-    T sig = hi, rej = -T(1), lam = hi;
-    bool expand = false;
+    T sig = T(0.5) * (lo + hi), lam = hi;
+    bool expand = false, try_below = false;
     T wstep = T(0);
-    if (warm && finite_of(guess) && width > T(0) && guess + width < hi && guess + width > lo) {
-      sig = guess + width; expand = true; wstep = T(4) * width;
+    if (warm && U(finite_of(guess) && width > T(0) && guess + width < hi && guess + width > lo)) {
+      sig = guess + width; expand = true; wstep = T(4) * width; try_below = true;
     }
     T off_up = tol, off_dn = tol;   // how far beyond the estimate the next certificate is placed
     T rho_trust = hi;
     int aimed = 0;                  // +1 / -1: the last proposal was an upper / lower certificate attempt
+    bool lo1 = false;               // count(lo) == 1 is known: lo lies between lam_2 and lam_max
+    bool hi_f = false, old_ok = false, was_interp = false;
+    Pt Plo{lo, T(0), 0}, Phi{hi, T(0), 0}, Pold{hi, T(0), 0};
+    T sig_prev = sig;
     int it = 0;
     bool done = false;
     constexpr int kMaxIt = 200;
+#ifdef IBS_PROBE
+    long long t_sweep = 0, t_full = 0; int n_full = 0;
+#endif
     while (!done && it < kMaxIt) {
+#ifdef IBS_PROBE
+      const long long tp0 = wall_clock64();
+#endif
       const int C = sweep_fwd(sig);
+#ifdef IBS_PROBE
+      const long long tp1 = wall_clock64(); t_sweep += tp1 - tp0;
+      struct Acc { long long& t; int& n; long long t1; __device__ ~Acc() {} };
+#endif
       ++it;
-      if (C == 0) hi = xmin(hi, sig); else lo = xmax(lo, sig);
+      // every shift lies strictly inside (lo, hi), so each count moves one end of the bracket
+      if (C == 0) {
+        if (hi_f) { Pold = Phi; old_ok = true; }
+        hi = sig; Phi = Pt{sig, shoot_m, shoot_e}; hi_f = true;
+      } else {
+        if (lo1) { Pold = Plo; old_ok = true; }
+        lo = sig; lo1 = (C == 1); Plo = Pt{sig, shoot_m, shoot_e};
+      }
+      const T prevstep = xabs(sig - sig_prev);
+      sig_prev = sig;
       if (expand) {                       // warm start: walk up until the count certifies an upper bound
-        if (C != 0 && sig + wstep < hi) { sig += wstep; wstep *= T(4); continue; }
+        if (C != 0 && U(sig + wstep < hi)) { sig += wstep; wstep *= T(4); continue; }
         expand = false;
+      }
+#ifdef IBS_EXP_BISECT
+      if (true) {
+#else
+      if (!lo1) {                         // locate phase: bisection on the count alone (short path)
+#endif
+        if (U((hi - lo) <= T(4) * tol)) { done = true; break; }
+        if (try_below && U(guess - width > lo && guess - width < hi)) sig = guess - width;
+        else sig = T(0.5) * (lo + hi);
+        try_below = false;
+        continue;
       }
       // a failed certificate attempt means the estimate is off by more than the offset: widen it
       const bool cert = (aimed != 0);     // this sweep was a certificate attempt around rho_trust
       if (aimed > 0 && C != 0) off_up *= T(2);
       if (aimed < 0 && C == 0) off_dn *= T(2);
       aimed = 0;
-      const bool collapsed = (hi - lo) <= T(4) * tol;
-      // certificate attempts need only the count: the trusted estimate is reused to place the next one
-      const bool want = collapsed || (!cert && ((C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej))));
-      bool moved = false;
+      if (U((hi - lo) <= T(4) * tol)) { done = true; break; }
       T rho = sig;
-      bool ok = false;
-      if (want) {
-        sweep_bwd(sig);
-        rho = twisted(sig);
-        ok = finite_of(rho);
-      } else if (cert) {
-        rho = rho_trust;
-        ok = true;
+      bool ok = false, near = false;
+      if (cert) { rho = rho_trust; ok = true; near = true; }
+      else if (hi_f) {
+        const bool b_is_lo = lg2_of(Plo) <= lg2_of(Phi);     // b = the end with the smaller |p|
+        const Pt b = b_is_lo ? Plo : Phi;
+        const Pt a = b_is_lo ? Phi : Plo;
+        const bool use_o = old_ok && Pold.x != a.x && Pold.x != b.x;
+        T r;
+        const bool got = interpolate(Pold, use_o, a, b, lo, hi, r);
+        const T q = T(0.25) * (T(3) * a.x + b.x);
+        const bool inside = r >= xmin(q, b.x) && r <= xmax(q, b.x);
+        const T stepb = xabs(r - b.x);
+        const bool nr = was_interp && stepb <= T(4096) * tol && prevstep <= T(268435456) * tol;
+        const bool acc = got && inside && (nr || (stepb < T(0.5) * prevstep && stepb >= T(9.5367431640625e-07) * prevstep));
+        if (U(acc)) { rho = r; ok = true; near = U(nr); }
       }
 #ifdef IBS_TRACE
-      if (lane == 0 && trace && it <= 64) { T* q = trace + 5 * (it - 1); q[0] = sig; q[1] = T(C); q[2] = ok ? rho : T(-999); q[3] = lo; q[4] = hi; }
+      if (lane == 0 && trace && it <= 64) { T* q = trace + 6 * (it - 1); q[0] = sig; q[1] = T(C); q[2] = ok ? rho : T(-999); q[3] = lo; q[4] = hi; q[5] = T(wall_clock64() % 100000000); }
 #endif
-      if (collapsed) {
-        lam = (ok && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi);
-        done = true;
-      } else if (ok) {
-        // near convergence rho is trusted to ~tol: place the missing count certificate tol beyond it
-        const bool near = cert || xabs(rho - sig) <= T(4096) * tol;
-        if (near) rho_trust = rho;
-        T nxt = rho;
-        bool have = false;
+      bool moved = false, interp_now = false;
+      if (ok) {
         if (near) {
+          // rho is trusted to ~tol: place the missing count certificate tol beyond it
+          if (!cert && U(xabs(rho - rho_trust) > T(4096) * tol)) { off_up = tol; off_dn = tol; }   // fresh estimate
+          rho_trust = rho;
           const T up = xmax(rho, lo), dn = xmin(rho, hi);
-          if (hi > up + T(2) * off_up) { nxt = up + off_up; have = true; aimed = 1; }
-          else if (lo < dn - T(2) * off_dn) { nxt = dn - off_dn; have = true; aimed = -1; }
-          have = have && (nxt > lo) && (nxt < hi);
-          if (!have) aimed = 0;
-        } else if (rho > lo && rho < hi) {
-          have = true;
+          T nxt = rho;
+          if (U(hi > up + T(2) * off_up)) { nxt = up + off_up; aimed = 1; }
+          else if (U(lo < dn - T(2) * off_dn)) { nxt = dn - off_dn; aimed = -1; }
+          if (aimed != 0 && U(nxt > lo && nxt < hi)) { sig = nxt; moved = true; }
+          else aimed = 0;
+        } else {
+          sig = rho; moved = true; interp_now = true;     // interpolate() returns points inside (lo, hi) only
         }
-        if (have) { sig = nxt; moved = true; }
-        else if (C == 0 && !near) rej = hi - lo;
       }
-      if (!done && !moved) sig = T(0.5) * (lo + hi);
+      if (!moved) sig = T(0.5) * (lo + hi);
+      was_interp = interp_now;
+#ifdef IBS_PROBE
+      t_full += wall_clock64() - tp1; ++n_full;
+#endif
     }
+#ifdef IBS_PROBE
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) { long long* q = &ibs_probe_buf[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16]; q[5] = t_sweep; q[6] = t_full; q[7] = n_full; }
+#endif
     inf.iters = it;
     inf.status = done ? 0 : 1;
-    if (!done) lam = sig;
+    // eigenvector and Rayleigh-quotient polish at the last shift (inside the final bracket when done)
+    IBS_PROBE_AT(10);
+    sweep_bwd(sig);
+    IBS_PROBE_AT(11);
+    const T rho = twisted(sig);
+    IBS_PROBE_AT(12);
+    if (done) lam = (finite_of(rho) && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi);
+    else lam = sig;
+#ifdef IBS_TRACE
+    if (lane == 0 && trace && it < 64) { T* q = trace + 6 * it; q[0] = sig; q[1] = T(-1); q[2] = rho; q[3] = lo; q[4] = hi; q[5] = T(wall_clock64() % 100000000); }
+#endif
     return lam;
   }
 };
@@ -541,6 +692,17 @@ struct WaveSolver {
 // ---------------------------------------------------------------- growth-rate stage (utils.py:1601-1621)
 // X (normalised eigenfunction incl. the two zero end points) is in LDS.  N odd.
 // Optional Hellmann-Feynman sums for up to NP tangent coefficient sets (utils.py:1676-1680).
+// position of element j in a padded LDS row (see lds_pitch in ibs_launch.hpp)
+__device__ __forceinline__ int lpos(int j) { return j + (j >> 3); }
+// the same stencil on a padded row
+template <typename T>
+__device__ __forceinline__ T fd_derivative_p(const T* X, int j, int N, T ih) {
+  if (j == 0) return (T(-1.5) * X[lpos(0)] + T(2) * X[lpos(1)] - T(0.5) * X[lpos(2)]) * ih;
+  if (j == 1) return (X[lpos(2)] - X[lpos(0)]) * (T(0.5) * ih);
+  if (j == N - 2) return (X[lpos(N - 1)] - X[lpos(N - 3)]) * (T(0.5) * ih);
+  if (j == N - 1) return (T(0.5) * X[lpos(N - 3)] - T(2) * X[lpos(N - 2)]) * ih;
+  return (T(2) / T(3)) * ih * (X[lpos(j + 1)] - X[lpos(j - 1)]) - (X[lpos(j + 2)] - X[lpos(j - 2)]) * (ih / T(12));
+}
 template <typename T>
 __device__ __forceinline__ T fd_derivative(const T* X, int j, int N, T ih) {
   // utils.py:1610-1616

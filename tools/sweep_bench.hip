@@ -21,9 +21,32 @@ __global__ void __launch_bounds__(256) k(int N, double h, const double* g, const
   WaveSolver<double, M> ws;
   ws.setup(src, N, h);
   double acc = 0, sig = ws.hi;
+  if (MODE == 3) {          // bisection loop on the count (minimal control logic)
+    double lo = ws.lo, hi = ws.hi; const double lo0 = lo, hi0 = hi;
+    sig = 0.5 * (lo + hi);
+    for (int r = 0; r < reps; ++r) {
+      const int C = ws.sweep_fwd(sig);
+      if (C == 0) hi = sig; else lo = sig;
+      if (hi - lo < 1e-13) { lo = lo0; hi = hi0; }
+      sig = 0.5 * (lo + hi);
+      acc += ws.zu[3];
+    }
+    if (lane == 0) out[blockIdx.x * 4 + wave] = acc + sig;
+    return;
+  }
+  if (MODE == 4) {          // the full solve, repeated; reports time per solve
+    for (int r = 0; r < reps; r += 16) {
+      SolveInfo inf{0, 0};
+      const double lo0 = ws.lo, hi0 = ws.hi;
+      acc += ws.solve(inf) + inf.iters;
+      ws.lo = lo0; ws.hi = hi0;
+    }
+    if (lane == 0) out[blockIdx.x * 4 + wave] = acc;
+    return;
+  }
   for (int r = 0; r < reps; ++r) {
-    int C = ws.sweep(sig);
-    if (MODE >= 1) { double rho = ws.twisted(sig); acc += rho; }
+    int C = (MODE == 2) ? ws.sweep_fwd(sig) : ws.sweep(sig);
+    if (MODE == 1) { double rho = ws.twisted(sig); acc += rho; }
     acc += C;
     sig = sig * 0.999 + 1e-9 * acc * 1e-9;
   }
@@ -48,9 +71,12 @@ int main() {
   double *dg, *dc, *df, *dout;
   hipMalloc(&dg, N * 8); hipMalloc(&dc, N * 8); hipMalloc(&df, N * 8); hipMalloc(&dout, 1 << 20);
   hipMemcpy(dg, g.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(dc, c.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(df, f.data(), N * 8, hipMemcpyHostToDevice);
-  for (int nblk : {256, 512, 768, 3072}) {
+  for (int nblk : {256, 768}) {
     run<0>("sweep only", nblk, N, h, dg, dc, df, dout);
     run<1>("sweep + twisted", nblk, N, h, dg, dc, df, dout);
+    run<2>("fwd sweep only", nblk, N, h, dg, dc, df, dout);
+    run<3>("bisection loop", nblk, N, h, dg, dc, df, dout);
+    run<4>("full solve / 16", nblk, N, h, dg, dc, df, dout);
   }
   return 0;
 }

@@ -30,17 +30,17 @@ int main(int argc, char** argv) {
     for (int j = 0; j < N; ++j) { double th = -4 * M_PI + j * h; double lam = sh * (th - t0) - al * (sin(th) - sin(t0)); g[j] = 1 + lam * lam; c[j] = al * (cos(th) + sin(th) * lam); f[j] = g[j]; }
   }
   double *dg, *dc, *df, *dt, *dout;
-  hipMalloc(&dg, N * 8); hipMalloc(&dc, N * 8); hipMalloc(&df, N * 8); hipMalloc(&dt, 5 * 64 * 8); hipMalloc(&dout, 64);
-  hipMemset(dt, 0, 5 * 64 * 8);
+  hipMalloc(&dg, N * 8); hipMalloc(&dc, N * 8); hipMalloc(&df, N * 8); hipMalloc(&dt, 6 * 65 * 8); hipMalloc(&dout, 64);
+  hipMemset(dt, 0, 6 * 65 * 8);
   hipMemcpy(dg, g.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(dc, c.data(), N * 8, hipMemcpyHostToDevice); hipMemcpy(df, f.data(), N * 8, hipMemcpyHostToDevice);
   int M = (N - 2 + 63) / 64;
   if (M == 16) hipLaunchKernelGGL(k<16>, dim3(1), dim3(64), 0, 0, N, h, dg, dc, df, dt, dout);
   else if (M == 8) hipLaunchKernelGGL(k<8>, dim3(1), dim3(64), 0, 0, N, h, dg, dc, df, dt, dout);
   else { printf("M=%d not built\n", M); return 1; }
-  std::vector<double> tr(5 * 64); double out[3];
-  hipMemcpy(tr.data(), dt, 5 * 64 * 8, hipMemcpyDeviceToHost); hipMemcpy(out, dout, 24, hipMemcpyDeviceToHost);
+  std::vector<double> tr(6 * 65); double out[3];
+  hipMemcpy(tr.data(), dt, 6 * 65 * 8, hipMemcpyDeviceToHost); hipMemcpy(out, dout, 24, hipMemcpyDeviceToHost);
   printf("lam %.15e iters %g normA %g tol %.3e\n", out[0], out[1], out[2], 64 * 2.22e-16 * out[2]);
-  for (int i = 0; i < (int)out[1] && i < 64; ++i)
-    printf("%2d sig-lam %+.3e C %g rho-lam %+.3e lo-lam %+.3e hi-lam %+.3e\n", i, tr[5*i]-out[0], tr[5*i+1], tr[5*i+2]-out[0], tr[5*i+3]-out[0], tr[5*i+4]-out[0]);
+  for (int i = 0; i <= (int)out[1] && i < 64; ++i)
+    printf("%2d sig-lam %+.3e C %g rho-lam %+.3e lo-lam %+.3e hi-lam %+.3e  dt %.2f us\n", i, tr[6*i]-out[0], tr[6*i+1], tr[6*i+2]-out[0], tr[6*i+3]-out[0], tr[6*i+4]-out[0], i ? (tr[6*i+5]-tr[6*i-1])*0.01 : 0.0);
   return 0;
 }
