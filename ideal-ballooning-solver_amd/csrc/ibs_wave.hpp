@@ -500,8 +500,9 @@ struct WaveSolver {
   // parabola through the two bracket ends and the most recently replaced end (Muller; secant with two points),
   // accepted only if it lies in the 3/4 of the bracket next to the end with the smaller |p| and the step is
   // less than half the previous one (else bisection), so the far regime (hi many eigenvalue gaps above
-  // lam_max, where interpolation crawls) costs no more than bisection.  A proposal within 4096 tol of that end
-  // that follows another interpolation step is trusted to ~tol and the missing count certificate is placed
+  // lam_max, where interpolation crawls) costs no more than bisection; a step that does not even halve |p| is
+  // followed by a bisection.  A proposal within 4096 tol of that end that follows an interpolation step which
+  // cut |p| by >= 16x (the convergent regime) is trusted to ~tol and the missing count certificate is placed
   // tol beyond it (the offset doubles whenever such a certificate fails), so that two counts close the bracket.
   // The solve ends when the certified bracket is narrower than 4 tol; ONE backward sweep + twisted
   // factorisation at the last shift then gives the eigenvector (assemble()) and the Rayleigh-quotient polish.
@@ -578,6 +579,8 @@ struct WaveSolver {
     int aimed = 0;                  // +1 / -1: the last proposal was an upper / lower certificate attempt
     bool lo1 = false;               // count(lo) == 1 is known: lo lies between lam_2 and lam_max
     bool hi_f = false, old_ok = false, was_interp = false;
+    bool conv = false, force_bis = false;   // the last interpolation step cut |p| >= 16x / did not even halve it
+    int lg_prev = 0;                        // log2 of the smaller |p| at the bracket ends when it was proposed
     Pt Plo{lo, T(0), 0}, Phi{hi, T(0), 0}, Pold{hi, T(0), 0};
     T sig_prev = sig;
     int it = 0;
@@ -621,6 +624,13 @@ struct WaveSolver {
         try_below = false;
         continue;
       }
+      // did the interpolation step that produced this shift pay off?  (integer log2 of the shooting values)
+      if (was_interp) {
+        const int e_now = expo_of(shoot_m);
+        const int red = lg_prev - (e_now < -(1 << 27) ? e_now : shoot_e + e_now);
+        conv = red >= 4;
+        force_bis = red < 1;
+      } else if (aimed == 0) conv = false;
       // a failed certificate attempt means the estimate is off by more than the offset: widen it
       const bool cert = (aimed != 0);     // this sweep was a certificate attempt around rho_trust
       if (aimed > 0 && C != 0) off_up *= T(2);
@@ -630,8 +640,10 @@ struct WaveSolver {
       T rho = sig;
       bool ok = false, near = false;
       if (cert) { rho = rho_trust; ok = true; near = true; }
-      else if (hi_f) {
-        const bool b_is_lo = lg2_of(Plo) <= lg2_of(Phi);     // b = the end with the smaller |p|
+      else if (hi_f && !force_bis) {
+        const int lg_lo = lg2_of(Plo), lg_hi = lg2_of(Phi);
+        const bool b_is_lo = lg_lo <= lg_hi;                 // b = the end with the smaller |p|
+        lg_prev = b_is_lo ? lg_lo : lg_hi;
         const Pt b = b_is_lo ? Plo : Phi;
         const Pt a = b_is_lo ? Phi : Plo;
         const bool use_o = old_ok && Pold.x != a.x && Pold.x != b.x;
@@ -640,7 +652,7 @@ struct WaveSolver {
         const T q = T(0.25) * (T(3) * a.x + b.x);
         const bool inside = r >= xmin(q, b.x) && r <= xmax(q, b.x);
         const T stepb = xabs(r - b.x);
-        const bool nr = was_interp && stepb <= T(4096) * tol && prevstep <= T(268435456) * tol;
+        const bool nr = was_interp && conv && stepb <= T(4096) * tol;
         const bool acc = got && inside && (nr || (stepb < T(0.5) * prevstep && stepb >= T(9.5367431640625e-07) * prevstep));
         if (U(acc)) { rho = r; ok = true; near = U(nr); }
       }
@@ -663,6 +675,7 @@ struct WaveSolver {
           sig = rho; moved = true; interp_now = true;     // interpolate() returns points inside (lo, hi) only
         }
       }
+      force_bis = false;
       if (!moved) sig = T(0.5) * (lo + hi);
       was_interp = interp_now;
 #ifdef IBS_PROBE
