@@ -91,18 +91,22 @@ int rows_per_lane(int N) { return (N - 2 + 63) / 64; }
 // IBS_FORCE_P=64|32|16 overrides (tests).
 int pick_lanes(const ibs_ctx* ctx, int N, long n_sys) {
   const int n = N - 2;
-  int P = 64;
-  // Measured (profiles/README.md, r01_e): with two systems per wave the wave runs max(iterations) of the
-  // pair and a full sweep whenever either system wants one, which eats the 1.5x cheaper sweeps; the
-  // sub-wave kernels are therefore opt-in until the iteration is made phase-uniform.
-  (void)ctx; (void)n_sys;
+  const bool can32 = n <= 32 * 16 && n >= 32 * 3 + 1, can16 = n <= 16 * 16 && n >= 16 * 3 + 1;
   if (const char* e = getenv("IBS_FORCE_P")) {
     const int f = atoi(e);
-    if (f == 64) P = 64;
-    if (f == 32 && n <= 32 * 16 && n >= 32 * 8 + 1) P = 32;
-    if (f == 16 && n <= 16 * 16 && n >= 16 * 3 + 1) P = 16;
+    if (f == 32 && can32) return 32;
+    if (f == 16 && can16) return 16;
+    return 64;
   }
-  return P;
+  // Measured (tools/bench_lanes.py, r01_f): every iteration of the shift search is exactly one forward sweep, so
+  // the systems sharing a wave stay in step (15 +- 2 iterations) and the cheaper sweeps pay off as soon as the
+  // sub-wave launch still fills the chip: P = 32 from one wave per SIMD (N = 513: 2,048 systems 42 vs 50 us,
+  // 65,536 systems 0.77 vs 1.00 ms), P = 16 (whose 16-row chunks make a lone wave twice as slow) from two
+  // waves per SIMD (N = 257: 65,536 systems 0.38 vs 0.62 ms).  Smaller batches keep one wave per system.
+  const long simds = 4L * ctx->n_cu;
+  if (can16 && n_sys / 4 >= 2 * simds) return 16;
+  if (can32 && n_sys / 2 >= simds) return 32;
+  return 64;
 }
 
 __global__ void k_count_status(long n, const int* info, int* out) {
@@ -159,7 +163,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     if (P != 64) {
       const int Mg = (N - 2 + P - 1) / P;
       auto fn = ibs::launch_table().gcf_f64_g[P == 32 ? 0 : 1][Mg];
-      if (fn) { launch = fn; M = Mg; per_wave = (size_t)(64 / P) * N * sizeof(T); }
+      if (fn) { launch = fn; M = Mg; per_wave = (size_t)(64 / P) * ibs::lds_pitch(N) * sizeof(T); }
     }
   }
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);

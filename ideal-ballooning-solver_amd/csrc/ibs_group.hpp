@@ -104,6 +104,7 @@ struct GroupSolver {
   T zu_m1, zw_p1;
   int Eu, Ew;
   T lo, hi, normA;          // group-replicated
+  T shoot_m; int shoot_e;   // shooting value of the last forward sweep (group-replicated), see WaveSolver
   T fu, fw;
   int thr;
 
@@ -165,7 +166,9 @@ struct GroupSolver {
     return GP::sum_i(bad ? 1 : 0, lane) != 0;   // per group
   }
 
-  // forward sweep; returns the group's Sturm count (eigenvalues > sig), group-replicated
+  // forward sweep; returns the group's Sturm count (eigenvalues > sig), group-replicated.  STORE: keep the
+  // forward solution zu (needed by twisted() only, i.e. for the last sweep of a solve)
+  template <bool STORE = true>
   __device__ __forceinline__ int sweep_fwd(T sig) {
     T fA = T(1), fAp = T(0), fB = T(0), fBp = T(1);
 #pragma unroll
@@ -180,6 +183,7 @@ struct GroupSolver {
     F.a = fA * kap; F.b = fB * kap; F.c = fAp * ikap; F.d = fBp * ikap; F.e = 0;
     renorm(F);
     const M2<T> Q = GP::scan_fwd(F, lane);
+    shoot_m = GP::bcast_last(Q.a, lane); shoot_e = GP::bcast_last_i(Q.e, lane);
     T u0 = dpp_t<0x138, 0xF>(T(1), Q.a);   // wave_shr:1
     T um = dpp_t<0x138, 0xF>(T(0), Q.c);
     int eu = dpp_i<0x138, 0xF>(0, Q.e);
@@ -192,7 +196,7 @@ struct GroupSolver {
     for (int i = 0; i < M; ++i) {
       const T t = xfma(-sig, Ph[i], D[i]);
       const bool act = (i < M - 1) || has_last;
-      zu[i] = act ? zc : T(0);
+      if constexpr (STORE) zu[i] = act ? zc : T(0);
       const T zn = xfma(-t, zc, -zp);
       count += (act && (signbit_of(zn) != signbit_of(zc))) ? 1 : 0;
       if (act) { zp = zc; zc = zn; }
@@ -316,73 +320,91 @@ struct GroupSolver {
     }
   }
 
-  // per-group safeguarded Newton / bisection with count-certified brackets (WaveSolver::solve, vectorised
-  // over the groups of the wave).  `bad` groups are parked as done.  Returns lam (group-replicated).
+  // The shift iteration of WaveSolver::solve (read its comment first), vectorised over the groups of the wave:
+  // every quantity is group-uniform and lives in VGPRs, the state machine is written with selects, and the wave
+  // loops until every group is done (a finished group keeps re-evaluating its frozen shift).  Each iteration is
+  // exactly ONE forward sweep for all groups, so the only divergence left is the iteration count (15 +- 2 on
+  // NCSX-like systems).  `bad` groups are parked as done.  Returns lam (group-replicated).
   __device__ __forceinline__ T solve(bool bad, int& iters_out, int& status_out) {
+    using WS = WaveSolver<T, M>;
+    using Pt = typename WS::Pt;
     const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
-    T sig = hi, rej = -T(1), lam = hi;
+    T sig = T(0.5) * (lo + hi), sig_prev = sig, lam = hi;
     T off_up = tol, off_dn = tol, rho_trust = hi;
-    int aimed = 0, it = 0;
+    int aimed = 0, it = 0, lg_prev = 0;
+    bool lo1 = false, hi_f = false, old_ok = false, was_interp = false, conv = false;
+    Pt Plo{lo, T(0), 0}, Phi{hi, T(0), 0}, Pold{hi, T(0), 0};
     bool done = bad;
     constexpr int kMaxIt = 200;
     int guard = 0;
+    auto sel = [](bool c, const Pt& a, const Pt& b) { return Pt{c ? a.x : b.x, c ? a.m : b.m, c ? a.e : b.e}; };
     while (__any(!done) && guard < kMaxIt) {
       ++guard;
-      const int C = sweep_fwd(sig);
+      const int C = sweep_fwd<false>(sig);
       const bool act = !done;
-      if (act) {
-        ++it;
-        if (C == 0) hi = xmin(hi, sig); else lo = xmax(lo, sig);
+      it += act ? 1 : 0;
+      const Pt cur{sig, shoot_m, shoot_e};
+      // every shift lies strictly inside (lo, hi): each count moves one end of the bracket
+      const bool uh = act && C == 0, ul = act && C != 0;
+      const bool t1 = uh && hi_f, t2 = ul && lo1;
+      Pold = sel(t1, Phi, sel(t2, Plo, Pold)); old_ok = old_ok || t1 || t2;
+      hi = uh ? sig : hi; Phi = sel(uh, cur, Phi); hi_f = hi_f || uh;
+      lo = ul ? sig : lo; Plo = sel(ul, cur, Plo); lo1 = ul ? (C == 1) : lo1;
+      const T prevstep = xabs(sig - sig_prev);
+      sig_prev = sig;
+      // did the interpolation step that produced this shift pay off?
+      const int e_now = expo_of(shoot_m);
+      const int red = lg_prev - (e_now < -(1 << 27) ? e_now : shoot_e + e_now);
+      conv = was_interp ? (red >= 4) : (aimed != 0 ? conv : false);
+      const bool force_bis = was_interp && red < 1;
+      const bool cert = aimed != 0;
+      off_up = (act && aimed > 0 && C != 0) ? T(2) * off_up : off_up;
+      off_dn = (act && aimed < 0 && C == 0) ? T(2) * off_dn : off_dn;
+      const bool collapsed = (hi - lo) <= T(4) * tol;
+      done = done || (act && collapsed);
+      const bool go = act && !collapsed;
+      T rho = rho_trust;
+      bool ok = go && cert, near = ok;
+      const bool want_i = go && lo1 && !cert && hi_f && !force_bis;
+      if (__any(want_i)) {
+        const int lg_lo = WS::lg2_of(Plo), lg_hi = WS::lg2_of(Phi);
+        const bool b_is_lo = lg_lo <= lg_hi;
+        const Pt b = sel(b_is_lo, Plo, Phi), a = sel(b_is_lo, Phi, Plo);
+        const bool use_o = old_ok && Pold.x != a.x && Pold.x != b.x;
+        T r;
+        const bool got = WS::interpolate(Pold, use_o, a, b, lo, hi, r);
+        const T q = T(0.25) * (T(3) * a.x + b.x);
+        const bool inside = r >= xmin(q, b.x) && r <= xmax(q, b.x);
+        const T stepb = xabs(r - b.x);
+        const bool nr = was_interp && conv && stepb <= T(4096) * tol;
+        const bool acc = want_i && got && inside &&
+                         (nr || (stepb < T(0.5) * prevstep && stepb >= T(9.5367431640625e-07) * prevstep));
+        lg_prev = acc ? (b_is_lo ? lg_lo : lg_hi) : lg_prev;
+        rho = acc ? r : rho; ok = ok || acc; near = near || (acc && nr);
       }
-      const bool cert = act && (aimed != 0);
-      if (act) {
-        if (aimed > 0 && C != 0) off_up *= T(2);
-        if (aimed < 0 && C == 0) off_dn *= T(2);
-        aimed = 0;
-      }
-      const bool collapsed = act && ((hi - lo) <= T(4) * tol);
-      const bool want = act && (collapsed || (!cert && ((C == 1) || (C == 0 && (rej < T(0) || (hi - lo) <= T(0.125) * rej)))));
-      // a parked group re-evaluates its frozen shift so that its last full sweep stays valid
-      const bool anywant = __any(want) != 0;
-      T rho = sig;
-      bool ok = false;
-      if (anywant) {
-        sweep_bwd(sig);
-        const T r = twisted(sig);
-        if (want) { rho = r; ok = finite_of(r); }
-      }
-      if (cert && !want) { rho = rho_trust; ok = true; }
-      bool moved = false;
-      if (act) {
-        if (collapsed) {
-          lam = (ok && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi);
-          done = true;
-        } else if (ok) {
-          const bool near = cert || xabs(rho - sig) <= T(4096) * tol;
-          if (near) rho_trust = rho;
-          T nxt = rho;
-          bool have = false;
-          if (near) {
-            const T up = xmax(rho, lo), dn = xmin(rho, hi);
-            if (hi > up + T(2) * off_up) { nxt = up + off_up; have = true; aimed = 1; }
-            else if (lo < dn - T(2) * off_dn) { nxt = dn - off_dn; have = true; aimed = -1; }
-            have = have && (nxt > lo) && (nxt < hi);
-            if (!have) aimed = 0;
-          } else if (rho > lo && rho < hi) {
-            have = true;
-          }
-          if (have) { sig = nxt; moved = true; }
-          else if (C == 0 && !near) rej = hi - lo;
-        }
-        if (!done && !moved) sig = T(0.5) * (lo + hi);
-      }
+      // next shift
+      const T mid = T(0.5) * (lo + hi);
+      const bool trust = ok && near;
+      const bool fresh = trust && !cert && xabs(rho - rho_trust) > T(4096) * tol;
+      off_up = fresh ? tol : off_up; off_dn = fresh ? tol : off_dn;
+      rho_trust = trust ? rho : rho_trust;
+      const T up = xmax(rho, lo), dn = xmin(rho, hi);
+      const bool c_up = hi > up + T(2) * off_up, c_dn = lo < dn - T(2) * off_dn;
+      const T cand = c_up ? up + off_up : dn - off_dn;
+      const bool aim_ok = trust && (c_up || c_dn) && cand > lo && cand < hi;
+      const bool interp_now = ok && !near;
+      const T nxt = aim_ok ? cand : (interp_now ? rho : mid);
+      sig = go ? nxt : sig;
+      aimed = go ? (aim_ok ? (c_up ? 1 : -1) : 0) : 0;
+      was_interp = go && interp_now;
     }
-    // a group that was parked by another group's full sweep is consistent; one whose last evaluation was
-    // forward-only cannot exist: it finishes only in a collapsed (= full) step.  Bad groups: one full sweep.
-    if (__any(bad)) { sweep_fwd(sig); sweep_bwd(sig); twisted(sig); }
+    // eigenvector and Rayleigh-quotient polish at each group's last shift
+    sweep_fwd<true>(sig);
+    sweep_bwd(sig);
+    const T rho = twisted(sig);
     iters_out = it;
     status_out = bad ? 2 : (done ? 0 : 1);
-    if (!done) lam = sig;
+    lam = done ? ((finite_of(rho) && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi)) : sig;
     return lam;
   }
 };

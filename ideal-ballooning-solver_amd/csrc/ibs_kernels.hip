@@ -85,12 +85,6 @@ struct SrcGeo {
   }
 };
 
-// LDS rows are private to a wave: ordering inside the wave is all that is needed
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 struct NoTangent {};
 

@@ -25,14 +25,15 @@ struct SrcGeoG {     // as SrcGeo (ibs_kernels.hip): 7 derived arrays of the lin
   static constexpr bool kHasGh = false;
   const T* A1; const T* A3; const T* C0; const T* C1; const T* G0; const T* G1; const T* G2;
   T th0, two_th0, th0sq;
-  __device__ __forceinline__ T gd(int j) const { return G0[j] + two_th0 * G1[j] + th0sq * G2[j]; }
-  __device__ __forceinline__ T g(int j) const { return A1[j] * gd(j); }
-  __device__ __forceinline__ T c(int j) const { return C0[j] + th0 * C1[j]; }
-  __device__ __forceinline__ T f(int j) const { return A3[j] * gd(j); }
-  __device__ __forceinline__ T gdp(int j) const { return T(2) * G1[j] + two_th0 * G2[j]; }
-  __device__ __forceinline__ T g_t(int j) const { return A1[j] * gdp(j); }
-  __device__ __forceinline__ T c_t(int j) const { return C1[j]; }
-  __device__ __forceinline__ T f_t(int j) const { return A3[j] * gdp(j); }
+  // rows are padded: element j at lpos(j)
+  __device__ __forceinline__ T gd(int j) const { const int q = lpos(j); return G0[q] + two_th0 * G1[q] + th0sq * G2[q]; }
+  __device__ __forceinline__ T g(int j) const { return A1[lpos(j)] * gd(j); }
+  __device__ __forceinline__ T c(int j) const { const int q = lpos(j); return C0[q] + th0 * C1[q]; }
+  __device__ __forceinline__ T f(int j) const { return A3[lpos(j)] * gd(j); }
+  __device__ __forceinline__ T gdp(int j) const { const int q = lpos(j); return T(2) * G1[q] + two_th0 * G2[q]; }
+  __device__ __forceinline__ T g_t(int j) const { return A1[lpos(j)] * gdp(j); }
+  __device__ __forceinline__ T c_t(int j) const { return C1[lpos(j)]; }
+  __device__ __forceinline__ T f_t(int j) const { return A3[lpos(j)] * gdp(j); }
 };
 
 // eigenvector -> X (LDS, this lane's system) -> growth rate; utils.py:1601-1621 (+1666-1680 when HF)
@@ -52,14 +53,14 @@ __device__ __forceinline__ void finish_g(GroupSolver<T, M, P>& ws, const Src& sr
   const int a = GroupSolver<T, M, P>::rows_start(lg, n);
 #pragma unroll
   for (int i = 0; i < M; ++i)
-    if ((i < M - 1) || ws.has_last) Xs[a + i + 1] = x[i] / m;
-  if (lg == 0) { Xs[0] = T(0); Xs[N - 1] = T(0); }
-  __syncthreads();
+    if ((i < M - 1) || ws.has_last) Xs[lpos(a + i + 1)] = x[i] / m;
+  if (lg == 0) { Xs[lpos(0)] = T(0); Xs[lpos(N - 1)] = T(0); }
+  wave_lds_sync();   // Xs belongs to this group
   const T ih = T(1) / h;
   T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
   for (int j = lg; j < N; j += P) {
-    const T X = Xs[j];
-    const T dX = fd_derivative(Xs, j, N, ih);
+    const T X = Xs[lpos(j)];
+    const T dX = fd_derivative_p(Xs, j, N, ih);
     const T w = T(simpson_w(j, N));
     const T X2 = X * X, dX2 = dX * dX;
     y0 += w * (src.c(j) * X2 - src.g(j) * dX2);
@@ -84,7 +85,7 @@ __device__ __forceinline__ void finish_g(GroupSolver<T, M, P>& ws, const Src& sr
   }
 }
 
-// raw (g, c, f): wave w of block b solves systems (b*wpb + w)*G .. +G-1; dynamic LDS = wpb * G * N * sizeof(T) (X only)
+// raw (g, c, f): wave w of block b solves systems (b*wpb + w)*G .. +G-1; dynamic LDS = wpb * G * lds_pitch(N) * sizeof(T) (X only)
 template <typename T, int M, int P>
 __global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, const T* __restrict__ g,
                                                      const T* __restrict__ c, const T* __restrict__ f, long ld,
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, 
   const long sys = ((long)blockIdx.x * wpb + wave) * G + gid;
   const bool valid = sys < n_sys;
   const long sysc = valid ? sys : (n_sys - 1);
-  T* Xs = smem + ((size_t)wave * G + gid) * N;
+  T* Xs = smem + ((size_t)wave * G + gid) * lds_pitch(N);
   SrcGlobal<T> src{g + sysc * ld, c + sysc * ld, f + sysc * ld};
   GroupSolver<T, M, P> ws;
   const bool bad = ws.setup(src, N, h);
@@ -131,17 +132,19 @@ __global__ void __launch_bounds__(scan_max_threads_g(M), 2) k_gamma_scan_g(
     line = chunk * 8 + r % lines_here;
     part = r / lines_here;
   }
-  T* A1 = smem; T* A3 = A1 + N; T* C0 = A3 + N; T* C1 = C0 + N; T* G0 = C1 + N; T* G1 = G0 + N; T* G2 = G1 + N;
-  T* Xs = G2 + N + ((size_t)wave * G + gid) * N;
+  const int PT = lds_pitch(N);
+  T* A1 = smem; T* A3 = A1 + PT; T* C0 = A3 + PT; T* C1 = C0 + PT; T* G0 = C1 + PT; T* G1 = G0 + PT; T* G2 = G1 + PT;
+  T* Xs = G2 + PT + ((size_t)wave * G + gid) * PT;
   {
     const long off = (long)line * ld;
     const T mdP = -dPdrho[line];
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
       const T B = bmag[off + j], gp = xabs(gradpar[off + j]);
       const T inv = T(1) / (gp * B);
-      A1[j] = gp / B; A3[j] = inv / (B * B);
-      C0[j] = mdP * cvdrift[off + j] * inv; C1[j] = mdP * cvdrift0[off + j] * inv;
-      G0[j] = gds2[off + j]; G1[j] = gds21[off + j]; G2[j] = gds22[off + j];
+      const int q = lpos(j);
+      A1[q] = gp / B; A3[q] = inv / (B * B);
+      C0[q] = mdP * cvdrift[off + j] * inv; C1[q] = mdP * cvdrift0[off + j] * inv;
+      G0[q] = gds2[off + j]; G1[q] = gds21[off + j]; G2[q] = gds22[off + j];
     }
   }
   __syncthreads();
@@ -163,7 +166,7 @@ template <typename T>
 static hipError_t launch_gcf_g(const GcfArgs<T>& a, hipStream_t st) {
   constexpr int G = 64 / IBS_P;
   const int wpb = a.wpb;
-  const size_t lds = (size_t)wpb * G * a.N * sizeof(T);
+  const size_t lds = (size_t)wpb * G * lds_pitch(a.N) * sizeof(T);
   const long nwaves = (a.n_sys + G - 1) / G;
   const long nblk = (nwaves + wpb - 1) / wpb;
   auto kern = k_solve_gcf_g<T, IBS_M, IBS_P>;
@@ -177,7 +180,7 @@ template <typename T>
 static hipError_t launch_scan_g(const ScanArgs<T>& a, hipStream_t st) {
   constexpr int G = 64 / IBS_P;
   const int wpb = a.wpb;
-  const size_t lds = (size_t)(7 + wpb * G) * a.N * sizeof(T);
+  const size_t lds = (size_t)(7 + wpb * G) * lds_pitch(a.N) * sizeof(T);
   auto kern = k_gamma_scan_g<T, IBS_M, IBS_P>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -705,6 +705,13 @@ struct WaveSolver {
 // ---------------------------------------------------------------- growth-rate stage (utils.py:1601-1621)
 // X (normalised eigenfunction incl. the two zero end points) is in LDS.  N odd.
 // Optional Hellmann-Feynman sums for up to NP tangent coefficient sets (utils.py:1676-1680).
+// LDS rows are private to a wave: ordering inside the wave is all that is needed
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // position of element j in a padded LDS row (see lds_pitch in ibs_launch.hpp)
 __device__ __forceinline__ int lpos(int j) { return j + (j >> 3); }
 // the same stencil on a padded row
