@@ -37,6 +37,16 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def pmc_kernel_name(kernel_prefix, default):
+    """full name of the kernel the committed PMC pass saw for this leg (the library picks lanes per system)"""
+    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
+    if os.path.exists(fn):
+        for k in json.load(open(fn)):
+            if k.startswith(kernel_prefix):
+                return k.replace("ibs::", "")
+    return default
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 N_SURF, N_ALPHA, N_THETA0, NPTS = 16, 8, 8, 513
 
@@ -131,9 +141,9 @@ def stress(ctx, device, n_sys, family, reps=3):
     return dict(workload="config 5 raw (g,c,f), %s family, %d systems, N_zeta=512, f64" % (family, n_sys),
                 solves_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms, mean_sweeps=sweeps, nonconverged=nbad,
                 roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                              traffic=(pmc_traffic("ibs::k_solve_gcf<double") if n_sys == 262144 and family == "smooth"
+                              traffic=(pmc_traffic("ibs::k_solve_gcf") if n_sys == 262144 and family == "smooth"
                                        else None),
-                              kernel="k_solve_gcf<double,8>", bytes_per_solve=bytes_per))
+                              kernel=pmc_kernel_name("ibs::k_solve_gcf", "k_solve_gcf"), bytes_per_solve=bytes_per))
 
 
 def sturm_sweep(ctx, device, n_sys, reps=5):

@@ -12,14 +12,15 @@
 //     exactly 1, so the three-term recurrence is ONE fma per row:  z[i+1] = -(D[i]-sig*Ph[i]) z[i] - z[i-1]
 //   * a sweep at shift sig = per-lane 2x2 transfer matrices -> wave-wide Kogge-Stone scan of
 //     2x2 products (DPP row_shr / row_bcast, power-of-two renormalised, exponent carried as int)
-//     -> per-lane replay from the incoming vector.  Forward (from the left end) and backward (from
-//     the right end) sweeps run fused; sign changes of the forward solution are the Sturm count.
-//   * the forward solution u and the backward solution w give the twisted (double-sweep)
-//     eigenvector estimate  x = u/u_k (r<=k), w/w_k (r>=k)  with k = argmax |u_r w_r| (discrete
-//     Wronskian: gamma_r = W/(u_r w_r)), and the Rayleigh-quotient/Newton update
-//     rho = sig + gamma_k / sum(f x^2).  rho is always a lower bound of lam_max, the Sturm count
-//     says on which side of lam_max (and of lam_2) sig is, so the iteration is a safeguarded
-//     Newton/bisection hybrid that needs no start vector and cannot land on a wrong eigenvalue.
+//     -> per-lane replay from the incoming vector.  A forward sweep yields the Sturm count (sign changes of
+//     the forward solution = eigenvalues above sig) and the shooting value u_{n+1}(sig) (the characteristic
+//     polynomial up to a constant, mantissa + exponent).
+//   * the shift iteration (solve()) brackets lam_max with counts only and proposes shifts by Brent-style
+//     Muller/secant interpolation of the shooting value once the bracket has isolated lam_max; it needs no
+//     start vector and cannot land on a wrong eigenvalue.
+//   * ONE backward sweep (from the right end) at the converged shift gives the second solution w; u and w give
+//     the twisted (double-sweep) eigenvector  x = u/u_k (r<=k), w/w_k (r>=k)  with k = argmax |u_r w_r|
+//     (discrete Wronskian: gamma_r = W/(u_r w_r)) and the Rayleigh-quotient polish rho = sig + gamma_k / sum(f x^2).
 //   * no MFMA: there is no dense contraction here; the binding resource is FP64 VALU issue.
 #pragma once
 #include <hip/hip_runtime.h>
