@@ -270,9 +270,9 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
     const T mdP = -dPdrho[line];
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
       const T B = bmag[off + j], gp = xabs(gradpar[off + j]);
-      const T inv = T(1) / (gp * B);                    // 1/(|gradpar| B)
-      const int q = lpos(j);
-      A1[q] = gp / B;                                   // g = |gradpar| gds2 / B        (utils.py:1560)
+      const T inv = T(1) / (gp * B);                    // 1/(|gradpar| B)   (IEEE divisions: the coefficients are
+      const int q = lpos(j);                            //  bit-identical to the oracle's, which near-degenerate
+      A1[q] = gp / B;                                   //  eigenvectors amplify by ~1e9)   g: utils.py:1560
       A3[q] = inv / (B * B);                            // f = gds2/B^2 /(|gradpar| B)   (utils.py:1562)
       C0[q] = mdP * cvdrift[off + j] * inv;             // c = -dPdrho cvdrift/(|gradpar| B) (utils.py:1561)
       C1[q] = mdP * cvdrift0[off + j] * inv;

@@ -441,8 +441,11 @@ struct WaveSolver {
       best = better ? a : best; bi = better ? i : bi;
     }
     // wave argmax in (exponent, mantissa) form; the lane id rides in the low 6 mantissa bits
-    const int ex = fexp(best);
-    T key = (best > T(0) && finite_of(best)) ? T(ex + Eu + Ew) + xldexp(best, -ex) : -T(1e30);
+    // key = (exponent of the product incl. the lanes' scan exponents) + mantissa in [1, 2): integer-built
+    const int ex = expo_of(best);
+    constexpr int L = ExpLim<T>::v;
+    const int exc = ex < -L ? -L : (ex > L ? L : ex);
+    T key = (best > T(0) && finite_of(best) && ex > -(1 << 27)) ? T(ex + Eu + Ew) + T(0.5) * (best * pow2_of<T>(-exc)) : -T(1e30);
     int Lk;
     if constexpr (sizeof(T) == 8) {
       key = __hiloint2double(__double2hiint(key), (__double2loint(key) & ~63) | lane);
