@@ -125,10 +125,11 @@ struct GroupSolver {
     const int a = rows_start(lg, n);
     const T ih2 = T(1) / (h * h);
     T sc = T(1);
+    const T g0 = src.g(a);
     T gcur = src.g(a + 1);
-    T e_lo = T(0.5) * (src.g(a) + gcur) * ih2;
+    T e_lo = T(0.5) * (g0 + gcur) * ih2;
     T vhi = -T(1e300), vlo = -T(1e300), vna = T(0), sum_c = T(0), sum_f = T(0);
-    bool bad = false;
+    bool bad = !(g0 > T(0)) || !(gcur > T(0));   // non-finite data, g <= 0 or f <= 0 anywhere in this lane's rows
     const T e_first = e_lo;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -136,6 +137,7 @@ struct GroupSolver {
       if (act) {
         const int j = a + i + 1;
         const T gnext = src.g(j + 1);
+        bad = bad || !(gnext > T(0));
         const T e_hi = T(0.5) * (gcur + gnext) * ih2;
         const T cj = src.c(j), fj = src.f(j);
         const T d = cj - (e_lo + e_hi);

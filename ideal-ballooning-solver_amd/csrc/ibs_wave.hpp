@@ -301,14 +301,17 @@ struct WaveSolver {
     // grid, or a caller-supplied array when the input grid was regridded (Src::kHasGh)
     T gcur = T(0);
     T e_lo;
+    bool bad = false;                            // non-finite data, g <= 0 or f <= 0 anywhere in this lane's rows
     if constexpr (Src::kHasGh) {
       e_lo = src.gh(a) * ih2;
+      bad = !(src.g(a) > T(0));
     } else {
+      const T g0 = src.g(a);
       gcur = src.g(a + 1);
-      e_lo = T(0.5) * (src.g(a) + gcur) * ih2;  // e_a
+      e_lo = T(0.5) * (g0 + gcur) * ih2;  // e_a
+      bad = !(g0 > T(0)) || !(gcur > T(0));
     }
     T vhi = -T(1e300), vlo = -T(1e300), vna = T(0), sum_c = T(0), sum_f = T(0);
-    bool bad = false;
     const T e_first = e_lo;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -316,8 +319,8 @@ struct WaveSolver {
       if (act) {
         const int j = a + i + 1;  // grid point of row a+i
         T gnext = T(0), e_hi;                           // e_{a+i+1}
-        if constexpr (Src::kHasGh) { e_hi = src.gh(j) * ih2; }
-        else { gnext = src.g(j + 1); e_hi = T(0.5) * (gcur + gnext) * ih2; }
+        if constexpr (Src::kHasGh) { e_hi = src.gh(j) * ih2; bad = bad || !(src.g(j + 1) > T(0)); }
+        else { gnext = src.g(j + 1); e_hi = T(0.5) * (gcur + gnext) * ih2; bad = bad || !(gnext > T(0)); }
         const T cj = src.c(j), fj = src.f(j);
         const T d = cj - (e_lo + e_hi);
         const T s2 = sc * sc;
