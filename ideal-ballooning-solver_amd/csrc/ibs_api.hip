@@ -145,6 +145,27 @@ __global__ void __launch_bounds__(256) k_surface_argmax(int n_per, const double*
   }
 }
 
+// Hellmann-Feynman derivative of the growth rate for given tangent coefficient arrays (utils.py:1676-1680 /
+// 1721-1725): one wave per system, Simpson sums with unit spacing.
+__global__ void __launch_bounds__(256) k_hf_grad(long n_sys, int N, long ld, const double* __restrict__ X,
+                                                 const double* __restrict__ dX, const double* __restrict__ f,
+                                                 const double* __restrict__ g_p, const double* __restrict__ c_p,
+                                                 const double* __restrict__ f_p, const double* __restrict__ gam,
+                                                 double* __restrict__ jac) {
+  const int lane = threadIdx.x & 63;
+  const long sys = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (sys >= n_sys) return;
+  const long o = sys * ld;
+  double y1 = 0.0, sc = 0.0, sg = 0.0, sf = 0.0;
+  for (int j = lane; j < N; j += 64) {
+    const double w = (j == 0 || j == N - 1) ? 1.0 : ((j & 1) ? 4.0 : 2.0);
+    const double x2 = w * X[o + j] * X[o + j], d2 = w * dX[o + j] * dX[o + j];
+    y1 += f[o + j] * x2; sc += c_p[o + j] * x2; sg += g_p[o + j] * d2; sf += f_p[o + j] * x2;
+  }
+  y1 = ibs::wave_sum(y1); sc = ibs::wave_sum(sc); sg = ibs::wave_sum(sg); sf = ibs::wave_sum(sf);
+  if (lane == 0) jac[sys] = sc / y1 - sg / y1 - gam[sys] * sf / y1;
+}
+
 template <typename T>
 int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, const T* c, const T* f, int64_t ld,
                    T* lam, T* gam, T* X, T* dX, int32_t* info, int32_t mem,
@@ -503,6 +524,40 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
   a.line_surf = line_surf; a.line_alpha = line_alpha; a.theta = theta; a.geo = geo; a.dPdrho = dPdrho;
   if (nrows_mn > 0 && nrows_nyq > 0) { a.nrows_mn = nrows_mn; a.nrows_nyq = nrows_nyq; a.rows_mn = rows_mn; a.rows_nyq = rows_nyq; a.dn_mn = dn_mn; a.dn_nyq = dn_nyq; }
   HIPCHK(ibs::launch_geometry(a, ctx->stream));
+  return 0;
+}
+
+int ibs_hf_grad_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, const double* X, const double* dX, const double* f,
+                    const double* g_p, const double* c_p, const double* f_p, int64_t ld, const double* gam,
+                    double* jac, int32_t mem) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_sys < 0 || !X || !dX || !f || !g_p || !c_p || !f_p || !gam || !jac || ld < N)
+    return fail(IBS_ERR_ARG, "bad arguments");
+  if (N < 3 || !(N & 1)) return fail(IBS_ERR_UNSUPPORTED, "N=%d: the Simpson rule of the reference needs N odd", N);
+  if (n_sys == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const dim3 grid((unsigned)((n_sys + 3) / 4));
+  if (mem == IBS_MEM_HOST) {
+    const size_t ne = (size_t)n_sys * ld;
+    if (int r = ensure_ws(ctx, 6 * pad256(ne * 8) + 2 * pad256(n_sys * 8) + 4096)) return r;
+    Arena ar(ctx);
+    const double* src[6] = {X, dX, f, g_p, c_p, f_p};
+    double* dev[6];
+    for (int k = 0; k < 6; ++k) {
+      dev[k] = ar.take<double>(ne);
+      HIPCHK(hipMemcpyAsync(dev[k], src[k], ne * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    double* dgam = ar.take<double>(n_sys); double* djac = ar.take<double>(n_sys);
+    HIPCHK(hipMemcpyAsync(dgam, gam, (size_t)n_sys * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_hf_grad, grid, dim3(256), 0, ctx->stream, (long)n_sys, N, (long)ld, dev[0], dev[1], dev[2], dev[3],
+                       dev[4], dev[5], dgam, djac);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(jac, djac, (size_t)n_sys * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  hipLaunchKernelGGL(k_hf_grad, grid, dim3(256), 0, ctx->stream, (long)n_sys, N, (long)ld, X, dX, f, g_p, c_p, f_p, gam, jac);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

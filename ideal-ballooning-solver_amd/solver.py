@@ -214,6 +214,20 @@ class Context:
         self._keep = (d_ls, d_la, d_th)
         return dict(geo=geo, dPdrho=dP)
 
+    def hf_grad(self, X, dX, f, g_p, c_p, f_p, gam):
+        """Hellmann-Feynman d(gam)/dp for caller-built tangents (utils.py:1676-1680, 1721-1725).
+        X, dX, f, g_p, c_p, f_p: (n_sys, N); gam: (n_sys,) -> jac (n_sys,)"""
+        ar = _Args()
+        n_sys, N = X.shape
+        ptrs = [ar.inp(a) for a in (X, dX, f, g_p, c_p, f_p)]
+        pgam = ar.inp(gam)
+        ref = X if ar.mem == MEM_DEVICE else None
+        if ref is not None:
+            self._stream_from_torch(ref)
+        jac, pjac = ar.out((n_sys,), ref)
+        check(self._lib.ibs_hf_grad_f64(self._h, n_sys, N, *ptrs, N, pgam, pjac, ar.mem), "ibs_hf_grad_f64")
+        return jac
+
     def sturm_count(self, h, g, c, f, shift):
         ar = _Args()
         n_sys, N = g.shape

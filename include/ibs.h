@@ -99,6 +99,15 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
                        const double* theta0, double del_alpha, double* val, double* jac, int32_t* info,
                        int32_t mem);
 
+/* Hellmann-Feynman derivative of gam with respect to any parameter p, given the eigenfunction and the tangent
+ * coefficient arrays (d g/dp, d c/dp, d f/dp) on the grid:
+ *   jac = [ S(c_p X^2) - S(g_p dX^2) - gam S(f_p X^2) ] / S(f X^2),   S = composite Simpson, unit spacing.
+ * Replaces: utils.py:1676-1680 (p = theta0) and utils.py:1721-1725 (p = alpha) for caller-built tangents; the
+ * fused entry point above builds both tangents itself.  All arrays [n_sys][ld], gam and jac [n_sys]; N odd. */
+int ibs_hf_grad_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, const double* X, const double* dX, const double* f,
+                    const double* g_p, const double* c_p, const double* f_p, int64_t ld, const double* gam,
+                    double* jac, int32_t mem);
+
 /* Field-line geometry on the device: the eight arrays of ball_scan.py:251-261 for
  * n_lines field lines (surface index, alpha) on the theta_PEST grid theta[N].
  * Replaces: the per-line arithmetic of vmec_fieldlines, utils.py:359-720 (theta_pest -> theta_vmec secant

@@ -194,6 +194,38 @@ def test_every_rows_per_lane_instantiation(ctx, bo, N):
         assert abs(r["gam"][k] - gam) < 1e-10
 
 
+def test_hf_grad_generic_tangents(ctx, bo):
+    """ibs_hf_grad_f64 (Hellmann-Feynman sums for caller-built tangents) against the oracle formula, host and
+    device pointers; the theta0 tangents of utils.py:1669-1673 must reproduce the fused kernel's d(gam)/d(theta0)"""
+    import torch
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    N = 513
+    geo = g3["geo_%d" % N]
+    th = bo.theta_grid(N)
+    a = [np.ascontiguousarray(geo[:, k, :]) for k in range(7)]
+    dP = g3["dPdrho_%d" % N]
+    t0s = g3["theta0"]
+    r = ctx.gamma_scan(th[1] - th[0], *a, dP, t0s, want_X=True, want_dtheta0=True)
+    nl, nt = r["gam"].shape
+    bmag, gp, cv, cv0, gd2, gd21, gd22 = [x[:, None, :] for x in a]
+    T0 = t0s[None, :, None]
+    gdp = 2 * gd21 + 2 * T0 * gd22
+    g_t = np.abs(gp) * gdp / bmag + 0 * T0
+    c_t = -dP[:, None, None] * cv0 / (np.abs(gp) * bmag) + 0 * T0
+    f_t = gdp / bmag ** 2 / (np.abs(gp) * bmag)
+    f = (gd2 + 2 * T0 * gd21 + T0 ** 2 * gd22) / bmag ** 2 / (np.abs(gp) * bmag)
+    flat = lambda x: np.ascontiguousarray(np.broadcast_to(x, (nl, nt, N)).reshape(nl * nt, N))
+    args = [flat(r["X"]), flat(r["dX"]), flat(f), flat(g_t), flat(c_t), flat(f_t)]
+    jac = ctx.hf_grad(*args, r["gam"].reshape(-1))
+    assert np.abs(jac.reshape(nl, nt) - r["dgam_dtheta0"]).max() < 1e-12
+    k = 5
+    assert abs(jac[k] - bo.hf_derivative(r["gam"].reshape(-1)[k], args[0][k], args[1][k], args[2][k], args[3][k], args[4][k], args[5][k])) < 1e-12
+    dev = torch.device("cuda:0")
+    jd = ctx.hf_grad(*[torch.from_numpy(x).to(dev) for x in args], torch.from_numpy(r["gam"].reshape(-1).copy()).to(dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(jd.cpu().numpy(), jac)
+
+
 def test_surface_argmax_first_tie(ctx):
     tab = np.array([[0.1, 0.5, 0.5, -1.0], [3.0, 3.0, 1.0, 3.0], [-2.0, -3.0, -2.5, -2.0]])
     idx, val = ctx.surface_argmax(tab)
