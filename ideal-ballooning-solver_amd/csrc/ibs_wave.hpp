@@ -603,7 +603,6 @@ struct WaveSolver {
       const int C = sweep_fwd(sig);
 #ifdef IBS_PROBE
       const long long tp1 = wall_clock64(); t_sweep += tp1 - tp0;
-      struct Acc { long long& t; int& n; long long t1; __device__ ~Acc() {} };
 #endif
       ++it;
       // every shift lies strictly inside (lo, hi), so each count moves one end of the bracket
@@ -721,7 +720,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // position of element j in a padded LDS row (see lds_pitch in ibs_launch.hpp)
 __device__ __forceinline__ int lpos(int j) { return j + (j >> 3); }
-// the same stencil on a padded row
+// dX of utils.py:1610-1616 on a padded row (the branch-free form used by the wave kernels is in finish())
 template <typename T>
 __device__ __forceinline__ T fd_derivative_p(const T* X, int j, int N, T ih) {
   if (j == 0) return (T(-1.5) * X[lpos(0)] + T(2) * X[lpos(1)] - T(0.5) * X[lpos(2)]) * ih;
@@ -729,15 +728,6 @@ __device__ __forceinline__ T fd_derivative_p(const T* X, int j, int N, T ih) {
   if (j == N - 2) return (X[lpos(N - 1)] - X[lpos(N - 3)]) * (T(0.5) * ih);
   if (j == N - 1) return (T(0.5) * X[lpos(N - 3)] - T(2) * X[lpos(N - 2)]) * ih;
   return (T(2) / T(3)) * ih * (X[lpos(j + 1)] - X[lpos(j - 1)]) - (X[lpos(j + 2)] - X[lpos(j - 2)]) * (ih / T(12));
-}
-template <typename T>
-__device__ __forceinline__ T fd_derivative(const T* X, int j, int N, T ih) {
-  // utils.py:1610-1616
-  if (j == 0) return (T(-1.5) * X[0] + T(2) * X[1] - T(0.5) * X[2]) * ih;
-  if (j == 1) return (X[2] - X[0]) * (T(0.5) * ih);
-  if (j == N - 2) return (X[N - 1] - X[N - 3]) * (T(0.5) * ih);
-  if (j == N - 1) return (T(0.5) * X[N - 3] - T(2) * X[N - 2]) * ih;
-  return (T(2) / T(3)) * ih * (X[j + 1] - X[j - 1]) - (X[j + 2] - X[j - 2]) * (ih / T(12));
 }
 __device__ __forceinline__ int simpson_w(int j, int N) { return (j == 0 || j == N - 1) ? 1 : ((j & 1) ? 4 : 2); }
 
