@@ -143,19 +143,19 @@ struct GroupSolver {
         const T d = cj - (e_lo + e_hi);
         const T s2 = sc * sc;
         D[i] = d * s2; Ph[i] = fj * s2;
-        const T rf = T(1) / fj;
+        const T rf = fast_rcp(fj);          // bounds only (margins added below)
         vhi = xmax(vhi, cj * rf);
         vlo = xmax(vlo, d * rf);
         vna = xmax(vna, (xabs(d) + e_lo + e_hi) * rf);
         sum_c += cj; sum_f += fj;
         bad = bad || !(fj > T(0)) || !(e_hi > T(0)) || !finite_of(cj);
-        sc = T(1) / (e_hi * sc);
+        sc = fast_rcp(e_hi * sc);           // e s_i s_{i+1} = 1 to rounding
         gcur = gnext; e_lo = e_hi;
       } else {
         D[i] = T(0); Ph[i] = T(0);
       }
     }
-    kap = sc; ikap = T(1) / sc;
+    kap = sc; ikap = fast_rcp(sc);
     bad = bad || !(e_first > T(0));
     // e_0 lives in the group's first lane, e_n in its last lane
     const T ends = GP::sum((lg == 0 ? e_first : T(0)) + (lg == P - 1 ? e_lo : T(0)), lane);   // e_0 + e_n
@@ -287,8 +287,8 @@ struct GroupSolver {
     int du = Eu - Euk, dw = Ew - Ewk;
     du = du > 1000 ? 1000 : (du < -2000 ? -2000 : du);
     dw = dw > 1000 ? 1000 : (dw < -2000 ? -2000 : dw);
-    fu = xldexp(T(1) / zu_k, du);
-    fw = xldexp(T(1) / zw_k, dw);
+    fu = xldexp(fast_rcp(zu_k), du);
+    fw = xldexp(fast_rcp(zw_k), dw);
     thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
     T acc = T(0);
 #pragma unroll
@@ -298,7 +298,7 @@ struct GroupSolver {
       if ((i < M - 1) || has_last) acc = xfma(Ph[i] * x, x, acc);
     }
     const T tot = GP::sum(acc, lane);
-    return sig + num / (uw * tot);
+    return sig + num * fast_rcp(uw * tot);
   }
 
   // eigenvector entries of this lane's rows up to a common factor per group (normalised by the caller);
@@ -316,7 +316,7 @@ struct GroupSolver {
       x[i] = act ? ((i <= thr) ? xu : xw) : T(0);
       if (act) {
         const T gnext = src.g(a + i + 2);
-        sc = T(1) / (T(0.5) * (gcur + gnext) * ih2 * sc);
+        sc = fast_rcp(T(0.5) * (gcur + gnext) * ih2 * sc);
         gcur = gnext;
       }
     }
