@@ -214,7 +214,7 @@ def test_hf_grad_generic_tangents(ctx, bo):
     c_t = -dP[:, None, None] * cv0 / (np.abs(gp) * bmag) + 0 * T0
     f_t = gdp / bmag ** 2 / (np.abs(gp) * bmag)
     f = (gd2 + 2 * T0 * gd21 + T0 ** 2 * gd22) / bmag ** 2 / (np.abs(gp) * bmag)
-    flat = lambda x: np.ascontiguousarray(np.broadcast_to(x, (nl, nt, N)).reshape(nl * nt, N))
+    flat = lambda x: np.array(np.broadcast_to(x, (nl, nt, N)).reshape(nl * nt, N), copy=True)
     args = [flat(r["X"]), flat(r["dX"]), flat(f), flat(g_t), flat(c_t), flat(f_t)]
     jac = ctx.hf_grad(*args, r["gam"].reshape(-1))
     assert np.abs(jac.reshape(nl, nt) - r["dgam_dtheta0"]).max() < 1e-12
