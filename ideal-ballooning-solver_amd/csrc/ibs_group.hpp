@@ -100,7 +100,9 @@ struct GroupSolver {
   T kap, ikap;
   bool has_last;
   int lane, lg, gid;
-  T zu[M], zw[M];
+  T sig_vec;                // shift of the last twisted() call (assemble() replays the forward solution there)
+  T zw[M];                  // backward solution of the last sweep_bwd; the forward one is replayed from (u0_in, zu_m1)
+  T u0_in;
   T zu_m1, zw_p1;
   int Eu, Ew;
   T lo, hi, normA;          // group-replicated
@@ -169,7 +171,8 @@ struct GroupSolver {
   }
 
   // forward sweep; returns the group's Sturm count (eigenvalues > sig), group-replicated.  STORE: keep the
-  // forward solution zu (needed by twisted() only, i.e. for the last sweep of a solve)
+  // incoming vector so that twisted() / assemble() can replay the forward solution (M fma per replay: cheaper
+  // in registers than an M-entry array, which is what bounds the occupancy of these kernels)
   template <bool STORE = true>
   __device__ __forceinline__ int sweep_fwd(T sig) {
     T fA = T(1), fAp = T(0), fB = T(0), fBp = T(1);
@@ -192,13 +195,13 @@ struct GroupSolver {
     if constexpr (P < 64) { const bool first = (lg == 0); u0 = first ? T(1) : u0; um = first ? T(0) : um; eu = first ? 0 : eu; }
     Eu = eu;
     zu_m1 = um;
+    if constexpr (STORE) u0_in = u0;
     T zc = u0, zp = um;
     int count = 0;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const T t = xfma(-sig, Ph[i], D[i]);
       const bool act = (i < M - 1) || has_last;
-      if constexpr (STORE) zu[i] = act ? zc : T(0);
       const T zn = xfma(-t, zc, -zp);
       count += (act && (signbit_of(zn) != signbit_of(zc))) ? 1 : 0;
       if (act) { zp = zc; zc = zn; }
@@ -239,13 +242,25 @@ struct GroupSolver {
 
   // twisted estimate per group (see WaveSolver::twisted); returns rho, group-replicated
   __device__ __forceinline__ T twisted(T sig) {
+    // pass A: replay the forward solution; per-lane candidate for the twist row k = argmax f |u w| together with
+    // the entries around it (so that no dynamically indexed array access is needed afterwards)
     T best = T(0);
     int bi = 0;
+    T zu_b = T(1), zum_b = T(0), zw_b = T(1), zwp_b = T(0), t_b = T(0);
+    {
+      T zc = u0_in, zp = zu_m1;
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      const T a = xabs(Ph[i] * (zu[i] * zw[i]));      // f-weighted |u w|: any row with a large product will do
-      const bool better = a > best;
-      best = better ? a : best; bi = better ? i : bi;
+      for (int i = 0; i < M; ++i) {
+        const T t = xfma(-sig, Ph[i], D[i]);
+        const bool act = (i < M - 1) || has_last;
+        const T a = act ? xabs(Ph[i] * (zc * zw[i])) : T(0);   // f-weighted |u w|: any row with a large product will do
+        const bool better = a > best;
+        best = better ? a : best; bi = better ? i : bi;
+        zu_b = better ? zc : zu_b; zum_b = better ? zp : zum_b; t_b = better ? t : t_b;
+        zw_b = better ? zw[i] : zw_b; zwp_b = better ? (i == M - 1 ? zw_p1 : zw[i < M - 1 ? i + 1 : M - 1]) : zwp_b;
+        const T zn = xfma(-t, zc, -zp);
+        if (act) { zp = zc; zc = zn; }
+      }
     }
     const int ex = fexp(best);
     T key = (best > T(0) && finite_of(best)) ? T(ex + Eu + Ew) + xldexp(best, -ex) : -T(1e30);
@@ -257,28 +272,19 @@ struct GroupSolver {
       key = __int_as_float((__float_as_int(key) & ~63) | lane);
       Lk = __float_as_int(GP::max(key, lane)) & 63;
     }
-    // per group: fetch the entries around (Lk, ik) through scalar reads, keep them in this group's lanes
+    // per group: fetch the owner's candidate entries through scalar reads, keep them in this group's lanes
     T zu_k = T(1), zw_k = T(1), t_k = T(0), um1 = T(0), wp1 = T(0);
     int ik = 0, Euk = 0, Ewk = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int sLk = readlane_i(Lk, g * P);
-      const int sik = readlane_i(bi, sLk);
-      T a_zu = T(1), a_zw = T(1), a_t = T(0), a_um1 = T(0), a_wp1 = T(0);
-#pragma unroll
-      for (int i = 0; i < M; ++i) {
-        if (i == sik) {
-          a_zu = readlane_t(zu[i], sLk); a_zw = readlane_t(zw[i], sLk);
-          a_t = readlane_t(xfma(-sig, Ph[i], D[i]), sLk);
-          a_um1 = readlane_t(i == 0 ? zu_m1 : zu[i > 0 ? i - 1 : 0], sLk);
-          a_wp1 = readlane_t(i == M - 1 ? zw_p1 : zw[i < M - 1 ? i + 1 : M - 1], sLk);
-        }
-      }
-      const int a_Eu = readlane_i(Eu, sLk), a_Ew = readlane_i(Ew, sLk);
       const bool mine = (gid == g);
+      const T a_zu = readlane_t(zu_b, sLk), a_zw = readlane_t(zw_b, sLk), a_t = readlane_t(t_b, sLk);
+      const T a_um1 = readlane_t(zum_b, sLk), a_wp1 = readlane_t(zwp_b, sLk);
+      const int a_ik = readlane_i(bi, sLk), a_Eu = readlane_i(Eu, sLk), a_Ew = readlane_i(Ew, sLk);
       zu_k = mine ? a_zu : zu_k; zw_k = mine ? a_zw : zw_k; t_k = mine ? a_t : t_k;
       um1 = mine ? a_um1 : um1; wp1 = mine ? a_wp1 : wp1;
-      ik = mine ? sik : ik; Euk = mine ? a_Eu : Euk; Ewk = mine ? a_Ew : Ewk;
+      ik = mine ? a_ik : ik; Euk = mine ? a_Eu : Euk; Ewk = mine ? a_Ew : Ewk;
     }
     const T uw = zu_k * zw_k;
     const T num = xfma(um1, zw_k, xfma(t_k, uw, wp1 * zu_k));
@@ -290,34 +296,47 @@ struct GroupSolver {
     fu = xldexp(fast_rcp(zu_k), du);
     fw = xldexp(fast_rcp(zw_k), dw);
     thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
+    // pass B: sum f x^2 over the twisted vector (forward solution replayed again)
     T acc = T(0);
+    {
+      T zc = u0_in, zp = zu_m1;
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      const T xu = zu[i] * fu, xw = zw[i] * fw;
-      const T x = (i <= thr) ? xu : xw;
-      if ((i < M - 1) || has_last) acc = xfma(Ph[i] * x, x, acc);
+      for (int i = 0; i < M; ++i) {
+        const T t = xfma(-sig, Ph[i], D[i]);
+        const bool act = (i < M - 1) || has_last;
+        const T xu = zc * fu, xw = zw[i] * fw;
+        const T x = (i <= thr) ? xu : xw;
+        if (act) acc = xfma(Ph[i] * x, x, acc);
+        const T zn = xfma(-t, zc, -zp);
+        if (act) { zp = zc; zc = zn; }
+      }
     }
+    sig_vec = sig;
     const T tot = GP::sum(acc, lane);
     return sig + num * fast_rcp(uw * tot);
   }
 
   // eigenvector entries of this lane's rows up to a common factor per group (normalised by the caller);
-  // the diagonal scaling s is rebuilt here from g (s_0 = 1, s_{i+1} = 1/(e_{i+1} s_i))
+  // the diagonal scaling s is rebuilt here from g (s_0 = 1, s_{i+1} = 1/(e_{i+1} s_i)), the forward solution is
+  // replayed at the shift of the last twisted() call
   template <class Src>
   __device__ __forceinline__ void assemble(const Src& src, int N, T h, T (&x)[M]) {
     const int a = rows_start(lg, N - 2);
     const T ih2 = T(1) / (h * h);
     T sc = T(1);
     T gcur = src.g(a + 1);
+    T zc = u0_in, zp = zu_m1;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const bool act = (i < M - 1) || has_last;
-      const T xu = sc * zu[i] * fu, xw = sc * zw[i] * fw;
+      const T xu = sc * zc * fu, xw = sc * zw[i] * fw;
       x[i] = act ? ((i <= thr) ? xu : xw) : T(0);
       if (act) {
         const T gnext = src.g(a + i + 2);
         sc = fast_rcp(T(0.5) * (gcur + gnext) * ih2 * sc);
         gcur = gnext;
+        const T zn = xfma(-xfma(-sig_vec, Ph[i], D[i]), zc, -zp);
+        zp = zc; zc = zn;
       }
     }
   }

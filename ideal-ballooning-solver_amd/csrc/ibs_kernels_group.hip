@@ -101,10 +101,11 @@ __device__ __forceinline__ void finish_g(GroupSolver<T, M, P>& ws, const Src& sr
 }
 
 // raw (g, c, f): wave w of block b solves systems (b*wpb + w)*G .. +G-1; dynamic LDS = wpb * G * lds_pitch(N) * sizeof(T) (X only)
-// (3 waves per SIMD = 168 VGPRs: 44 registers of the one-off eigenvector stage spill, the iteration loop does not;
-//  measured 9.6e7 vs 9.0e7 solves/s at 2 waves per SIMD and 4.8e7 at 4; the scan form below is better off at 2)
+// (2 waves per SIMD: the shift iteration keeps ~210 VGPRs live.  Forcing 3 waves (168 VGPRs) spills 45 of them:
+//  6 % faster (9.6e7 vs 9.0e7 solves/s) but the scratch traffic doubles the HBM bytes per launch (8.1 vs 4.3 GB
+//  PMC), so it is not used; 4 waves per SIMD halve the rate.)
 template <typename T, int M, int P>
-__global__ void __launch_bounds__(256, 3) k_solve_gcf_g(long n_sys, int N, T h, const T* __restrict__ g,
+__global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, const T* __restrict__ g,
                                                      const T* __restrict__ c, const T* __restrict__ f, long ld,
                                                      T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
