@@ -116,6 +116,8 @@ __global__ void k_count_status(long n, const int* info, int* out) {
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
 }
 
+static inline int argmax_threads(int n_per) { const int t = ((n_per + 63) / 64) * 64; return t > 256 ? 256 : t; }
+
 // first-argmax per surface (ball_scan.py:283-295 tie rule: lowest row-major index wins)
 __global__ void __launch_bounds__(256) k_surface_argmax(int n_per, const double* gam, int* idx, double* val, double* pack) {
   __shared__ double sv[4];
@@ -133,11 +135,13 @@ __global__ void __launch_bounds__(256) k_surface_argmax(int n_per, const double*
     const int i2 = __shfl_xor(bi, d);
     if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
   }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
-  __syncthreads();
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (nw > 1) {                      // (one wave per surface when n_per <= 64: no LDS round trip, no barrier)
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k)
+    for (int k = 1; k < nw; ++k)
       if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
     if (idx) idx[blockIdx.x] = bi;
     if (val) val[blockIdx.x] = best;
@@ -613,14 +617,14 @@ int ibs_surface_argmax_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per, const do
     Arena ar(ctx);
     double* dg = ar.take<double>(ne); double* dv = ar.take<double>(n_surf); int* di = ar.take<int>(n_surf);
     HIPCHK(hipMemcpyAsync(dg, gam, ne * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, dg, di, dv, (double*)nullptr);
+    hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(argmax_threads(n_per)), 0, ctx->stream, n_per, dg, di, dv, (double*)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(idx, di, (size_t)n_surf * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(val, dv, (size_t)n_surf * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
   }
-  hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, gam, idx, val, (double*)nullptr);
+  hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(argmax_threads(n_per)), 0, ctx->stream, n_per, gam, idx, val, (double*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -630,7 +634,7 @@ int ibs_surface_argmax_pack_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per, con
   if (n_surf < 0 || n_per <= 0 || !gam || !pack) return fail(IBS_ERR_ARG, "bad arguments");
   if (n_surf == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(256), 0, ctx->stream, n_per, gam, (int*)nullptr, (double*)nullptr, pack);
+  hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(argmax_threads(n_per)), 0, ctx->stream, n_per, gam, (int*)nullptr, (double*)nullptr, pack);
   HIPCHK(hipGetLastError());
   return 0;
 }
