@@ -151,9 +151,8 @@ struct RowStart {
   __device__ __forceinline__ void init(double tv_, double phi_) { init_phi(phi_); init(tv_); }
   __device__ __forceinline__ void start(double m, double n0, double& ca, double& sa) {
     if (m != m_cur) {
-      const double dm = m - m_cur;
-      if (dm > 0.0 && dm <= 4.0 && dm == floor(dm)) {
-        for (double q = 0.0; q < dm; q += 1.0) { const double c2 = cm * ctv - sm * stv, s2 = sm * ctv + cm * stv; cm = c2; sm = s2; }
+      if (m - m_cur == 1.0) {          // VMEC order: the next row is the next m -> one plane rotation
+        const double c2 = cm * ctv - sm * stv, s2 = sm * ctv + cm * stv; cm = c2; sm = s2;
       } else {
         sincos(m * tv, &sm, &cm);
       }
@@ -297,11 +296,16 @@ __device__ __forceinline__ void geo_rows_body(const GeoArgs& a) {
   auto resid = [&](double tv) {
     double acc0 = 0.0, acc1 = 0.0;
     rs.init(tv);
+    int o_nx = off1[sub < nr1 ? sub : 0], e_nx = off1[sub < nr1 ? sub + 1 : 0];
+    double m_nx = rm1[sub < nr1 ? sub : 0], n_nx = rn1[sub < nr1 ? sub : 0];
     for (int r = sub; r < nr1; r += LPP) {
-      const int o = row_int<LPP>(off1[r]);
-      const int ng = (row_int<LPP>(off1[r + 1]) - o) >> 2;
+      // this row's table entries were fetched one row ahead (the LDS latency hides behind the previous row)
+      const int o = row_int<LPP>(o_nx);
+      const int ng = (row_int<LPP>(e_nx) - o) >> 2;
+      const double m_r = m_nx, n_r = n_nx;
+      { const int rn = r + LPP < nr1 ? r + LPP : r; o_nx = off1[rn]; e_nx = off1[rn + 1]; m_nx = rm1[rn]; n_nx = rn1[rn]; }
       double s0, c0;
-      rs.start(rm1[r], rn1[r], c0, s0);
+      rs.start(m_r, n_r, c0, s0);
       double sm1 = s0 * cD + c0 * sD;              // sin of the (virtual) previous mode: angle + D
       const double2* Lp = reinterpret_cast<const double2*>(lm_s + o);
       for (int g = 0; g < ng; ++g) {
@@ -338,11 +342,15 @@ __device__ __forceinline__ void geo_rows_body(const GeoArgs& a) {
   const double tv = p1;
   double R = 0, R_s = 0, R_t = 0, R_p = 0, Z_s = 0, Z_t = 0, Z_p = 0, l_s = 0, l_t = 0, l_p = 0;
   rs.init(tv);
+  int o_nx = off1[sub < nr1 ? sub : 0], e_nx = off1[sub < nr1 ? sub + 1 : 0];
+  double m_nx = rm1[sub < nr1 ? sub : 0], n_nx = rn1[sub < nr1 ? sub : 0];
   for (int r = sub; r < nr1; r += LPP) {
-    const int o = row_int<LPP>(off1[r]);
-    const int ng = (row_int<LPP>(off1[r + 1]) - o) >> 1;
+    const int o = row_int<LPP>(o_nx);
+    const int ng = (row_int<LPP>(e_nx) - o) >> 1;
+    const double m_r = m_nx, n_r = n_nx;
+    { const int rn = r + LPP < nr1 ? r + LPP : r; o_nx = off1[rn]; e_nx = off1[rn + 1]; m_nx = rm1[rn]; n_nx = rn1[rn]; }
     double sa, ca;
-    rs.start(rm1[r], rn1[r], ca, sa);
+    rs.start(m_r, n_r, ca, sa);
     double sm1 = sa * cD + ca * sD, cm1 = ca * cD - sa * sD;
     const double2* q = reinterpret_cast<const double2*>(amn + 10 * o);
     for (int g = 0; g < ng; ++g, q += 10) {
@@ -370,11 +378,15 @@ __device__ __forceinline__ void geo_rows_body(const GeoArgs& a) {
   }
   double sqg = 0, modB = 0, B_s = 0, B_t = 0, B_p = 0, Bsup_phi = 0, Bsub_s = 0, Bsub_t = 0, Bsub_p = 0;
   rs.init(tv);
+  o_nx = off2[sub < nr2 ? sub : 0]; e_nx = off2[sub < nr2 ? sub + 1 : 0];
+  m_nx = rm2[sub < nr2 ? sub : 0]; n_nx = rn2[sub < nr2 ? sub : 0];
   for (int r = sub; r < nr2; r += LPP) {
-    const int o = row_int<LPP>(off2[r]);
-    const int ng = (row_int<LPP>(off2[r + 1]) - o) >> 1;
+    const int o = row_int<LPP>(o_nx);
+    const int ng = (row_int<LPP>(e_nx) - o) >> 1;
+    const double m_r = m_nx, n_r = n_nx;
+    { const int rn = r + LPP < nr2 ? r + LPP : r; o_nx = off2[rn]; e_nx = off2[rn + 1]; m_nx = rm2[rn]; n_nx = rn2[rn]; }
     double sa, ca;
-    rs.start(rm2[r], rn2[r], ca, sa);
+    rs.start(m_r, n_r, ca, sa);
     double sm1 = sa * cD + ca * sD, cm1 = ca * cD - sa * sD;
     const double2* q = reinterpret_cast<const double2*>(anq + 10 * o);
     for (int g = 0; g < ng; ++g, q += 10) {

@@ -193,11 +193,12 @@ class Context:
                                                        float(tables.dn_mn), float(tables.dn_nyq), MEM_HOST), "ibs_fieldline_geometry_f64")
             return dict(geo=geo, dPdrho=dP)
         import torch
-        key = id(tables)
-        cache = getattr(self, "_tab_cache", {})
-        if key not in cache:      # tables are uploaded once and stay resident
-            cache[key] = [torch.from_numpy(a).to(device) for a in host + [tables.rows_mn, tables.rows_nyq]]
-            self._tab_cache = cache
+        # tables are uploaded once and stay resident; the device copies live ON the tables object (a cache keyed by
+        # id(tables) would hand a later object that re-uses the id the previous object's tables)
+        cache = tables.__dict__.setdefault("_device_copies", {})
+        key = str(device)
+        if key not in cache:
+            cache[key] = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in host + [tables.rows_mn, tables.rows_nyq]]
         dev = cache[key][:7]
         d_rows = cache[key][7:]
         d_ls, d_la, d_th = (torch.from_numpy(a).to(device) for a in (ls, la, th))

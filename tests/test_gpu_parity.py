@@ -448,6 +448,13 @@ def test_F1_fieldline_geometry_kernel(ctx, bo):
     surf = [int(np.argmin(np.abs(ref["s"] - s))) for s, a in lines]
     dev = torch.device("cuda:0")
     rd = ctx.fieldline_geometry(tabs, surf, lines[:, 1], th, device=dev)
+    # the resident device copies belong to the tables object (an id()-keyed cache once served stale tables to a new
+    # object that re-used the id); a second, different table set on the same context must give its own geometry
+    assert "_device_copies" in tabs.__dict__ and not hasattr(ctx, "_tab_cache")
+    one = ibs_amd.SurfaceTables.from_wout(wout, [float(ref["s"][3])])
+    r1 = ctx.fieldline_geometry(one, [0], [0.7], th, device=dev)
+    r1h = ctx.fieldline_geometry(one, [0], [0.7], th)
+    assert np.abs(r1["geo"].cpu().numpy() - r1h["geo"]).max() < 1e-10
     t0 = torch.from_numpy(g3["theta0"]).to(dev)
     sc = ctx.gamma_scan(th[1] - th[0], *[rd["geo"][k] for k in range(7)], rd["dPdrho"], t0)
     assert np.abs(sc["gam"].cpu().numpy() - g3["gam_tight_513"]).max() < 1e-9
