@@ -37,6 +37,16 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def pmc_value(kernel_prefix, key):
+    """any other figure of the committed PMC summary for a kernel (None if absent)"""
+    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
+    if os.path.exists(fn):
+        for k, v in json.load(open(fn)).items():
+            if k.startswith(kernel_prefix) and key in v:
+                return v[key]
+    return None
+
+
 def pmc_kernel_name(kernel_prefix, default):
     """full name of the kernel the committed PMC pass saw for this leg (the library picks lanes per system)"""
     fn = os.path.join(ROOT, "profiles", "pmc_current.json")
@@ -295,6 +305,10 @@ def main():
                          "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("ibs::k_gamma_scan<double"),
                          "kernel": "k_gamma_scan<double,8>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         # what actually binds (committed PMC pass, profiles/pmc_current.json): VALU instructions per
+                         # wave and the fraction of the wave's lifetime its SIMD's VALU is busy (1 wave per SIMD here)
+                         "valu_insts_per_wave": pmc_value("ibs::k_gamma_scan<double", "valu_insts_per_wave"),
+                         "valu_busy_frac": pmc_value("ibs::k_gamma_scan<double", "valu_busy_frac_of_wave_lifetime"),
                          "note": "FP64-VALU-issue bound, not HBM bound: see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu:
