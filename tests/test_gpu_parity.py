@@ -226,6 +226,25 @@ def test_hf_grad_generic_tangents(ctx, bo):
     assert np.array_equal(jd.cpu().numpy(), jac)
 
 
+@pytest.mark.parametrize("N", [513, 1025])
+def test_nearly_degenerate_top_eigenvalues(ctx, bo, N):
+    """two identical, well separated wells: lam_1 - lam_2 from 2e-2 down to 2e-9.  The count-certified bracket
+    must still close on lam_max (no C == 1 window may ever be seen: pure bisection then), status 0."""
+    from scipy.linalg import eigh_tridiagonal
+    th = bo.theta_grid(N)
+    cases = ((6.0, 3.0, 0.8), (8.0, 5.0, 0.5), (3.0, 2.0, 1.0), (9.0, 1.0, 1.5))
+    g = np.ones((len(cases), N)); f = np.ones_like(g)
+    c = np.stack([d * (np.exp(-((th - s) / w) ** 2) + np.exp(-((th + s) / w) ** 2)) - 0.5 for s, d, w in cases])
+    r = ctx.solve_gcf(th[1] - th[0], g, c, f, want_info=True)
+    assert r["nbad"] == 0 and ((r["info"] >> 16) == 0).all() and ((r["info"] & 0xffff) < 60).all()
+    for k in range(len(cases)):
+        d, e, fd = bo.assemble(th, g[k], c[k], f[k])[:3]
+        n = len(d)
+        w = eigh_tridiagonal(d / fd, e[1:n] / np.sqrt(fd[:-1] * fd[1:]), eigvals_only=True, select="i", select_range=(n - 1, n - 1))
+        norm_a = np.max(np.abs(d / fd)) + 2 * np.max(e / fd.min())
+        assert abs(r["lam"][k] - w[0]) <= 4 * 64 * np.finfo(float).eps * norm_a
+
+
 def test_surface_argmax_first_tie(ctx):
     tab = np.array([[0.1, 0.5, 0.5, -1.0], [3.0, 3.0, 1.0, 3.0], [-2.0, -3.0, -2.5, -2.0]])
     idx, val = ctx.surface_argmax(tab)
