@@ -91,7 +91,7 @@ int rows_per_lane(int N) { return (N - 2 + 63) / 64; }
 // IBS_FORCE_P=64|32|16 overrides (tests).
 int pick_lanes(const ibs_ctx* ctx, int N, long n_sys) {
   const int n = N - 2;
-  const bool can32 = n <= 32 * 16 && n >= 32 * 3 + 1, can16 = n <= 16 * 16 && n >= 16 * 3 + 1;
+  const bool can32 = n <= 32 * 20 && n >= 32 * 3 + 1, can16 = n <= 16 * 16 && n >= 16 * 3 + 1;
   if (const char* e = getenv("IBS_FORCE_P")) {
     const int f = atoi(e);
     if (f == 32 && can32) return 32;
@@ -105,7 +105,10 @@ int pick_lanes(const ibs_ctx* ctx, int N, long n_sys) {
   // waves per SIMD (N = 257: 65,536 systems 0.38 vs 0.62 ms).  Smaller batches keep one wave per system.
   const long simds = 4L * ctx->n_cu;
   if (can16 && n_sys / 4 >= 2 * simds) return 16;
-  if (can32 && n_sys / 2 >= simds) return 32;
+  // (17..20 rows per lane, i.e. N up to the 641-point D3D grid: a lone wave is slower, pays off from 4 waves per SIMD:
+  //  N = 641: 65,536 systems 0.82 vs 1.05 ms, 8,192 systems 147 vs 150 us, 2,048 systems 72 vs 52 us)
+  const int m32 = (n + 31) / 32;
+  if (can32 && n_sys / 2 >= (m32 > 16 ? 4 : 1) * simds) return 32;
   return 64;
 }
 
