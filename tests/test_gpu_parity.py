@@ -392,10 +392,11 @@ def test_config3_shape_ncsx_1025_tiled(ctx, bo):
     assert r["nbad"] == 0 and np.abs(r["gam"] - gam_c).max() < TOL and np.abs(r["lam"] - lam_c).max() < TOL
 
 
-@pytest.mark.parametrize("N,P", [(513, 32), (385, 32), (257, 16), (129, 16), (641, 32)])
+@pytest.mark.parametrize("N,P", [(513, 32), (385, 32), (257, 16), (129, 16), (641, 32), (705, 32), (513, 16)])
 def test_subwave_variants_match_full_wave(ctx, bo, N, P):
     """32 / 16 lanes per system (ibs_group.hpp) against the one-wave-per-system kernels and the oracle;
-    (641, 32) is outside the 32-lane range and must silently use the full-wave kernel."""
+    (641, 32) is the D3D grid at 20 rows per lane; (705, 32) and (513, 16) are outside the sub-wave ranges and must
+    silently use the full-wave kernel."""
     rng = np.random.default_rng(N + P)
     n_sys = 37                                                  # not a multiple of the systems per wave
     params = np.stack([rng.uniform(0.2, 2, n_sys), rng.uniform(0.1, 1.2, n_sys), rng.uniform(0, 1.5, n_sys)], 1)
