@@ -203,7 +203,7 @@ struct GroupSolver {
       const T t = xfma(-sig, Ph[i], D[i]);
       const bool act = (i < M - 1) || has_last;
       const T zn = xfma(-t, zc, -zp);
-      count += (act && (signbit_of(zn) != signbit_of(zc))) ? 1 : 0;
+      count += (act && sign_differs(zn, zc)) ? 1 : 0;
       if (act) { zp = zc; zc = zn; }
     }
     return GP::sum_i(count, lane);

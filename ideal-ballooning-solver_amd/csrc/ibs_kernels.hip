@@ -194,6 +194,121 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
   }
 }
 
+// one grid point of the Simpson sums of utils.py:1618-1619 (and, with WT, of the theta0-tangent sums of
+// utils.py:1676-1680); w = Simpson weight
+template <typename T, class Src, bool WT>
+__device__ __forceinline__ void simpson_point(const Src& src, int j, T w, T X, T dX, T& y0, T& y1, T& hc, T& hg, T& hf) {
+  const T X2 = w * (X * X), dX2 = w * (dX * dX);
+  T g_, c_, f_;
+  if constexpr (WT) {
+    T gt, ct, ft;
+    src.gcf_with_tangent(j, g_, c_, f_, gt, ct, ft);
+    hc = xfma(ct, X2, hc); hg = xfma(gt, dX2, hg); hf = xfma(ft, X2, hf);
+  } else {
+    src.gcf(j, g_, c_, f_);
+  }
+  y0 += c_ * X2 - g_ * dX2;                                          // utils.py:1618
+  y1 = xfma(f_, X2, y1);                                             // utils.py:1619
+}
+
+// Growth rate without an LDS round trip: the eigenfunction stays in the lanes' row chunks, the four stencil neighbours beyond a chunk come from the adjacent lanes (wave_shr / wave_shl),
+// and every lane sums its own rows of the Simpson integrals; the two end points j = 0, N-1 (X = 0, one-sided dX)
+// are added by the first and last lane.  Same per-point arithmetic as finish() (utils.py:1601-1621).  X and dX, when
+// requested, go through the wave's LDS row Xs (which may alias an LDS array of `src`: it is written after the
+// sums) to be stored coalesced.
+template <typename T, int M, class Src, bool HF>
+__device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& src, int N, T h, T* Xs, T lam,
+                                             const SolveInfo& inf, long sys, T* lam_out, T* gam_out,
+                                             T* X_out, T* dX_out, T* dth0_out, int* info_out) {
+  static_assert(M >= 3, "the halo exchange takes two rows from each neighbour lane");
+  const int lane = ws.lane;
+  const int n = N - 2;
+  const bool hl = ws.has_last;
+  T x[M];
+  ws.assemble(x);
+  T m = T(0);
+#pragma unroll
+  for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
+  m = uniform(wave_max(m));
+  const T rm = T(1) / m;
+#pragma unroll
+  for (int i = 0; i < M; ++i) x[i] *= rm;                                   // utils.py:1605 (v / max|v|)
+  const int a = WaveSolver<T, M>::rows_start(lane, n);
+  // xe[k] = X at grid point a + k - 1 (k = 0, 1: the previous lane's last two rows; beyond this lane's rows: the
+  // next lane's first two).  The zero end points X[0], X[N-1] (and the clamped X[-1], X[N]) are the DPP fill value.
+  const T lastv = hl ? x[M - 1] : x[M - 2], last2 = hl ? x[M - 2] : x[M - 3];
+  const T xp1 = dpp_t<0x130, 0xF>(T(0), x[0]), xp2 = dpp_t<0x130, 0xF>(T(0), x[1]);    // wave_shl:1
+  T xe[M + 4];
+  xe[0] = dpp_t<0x138, 0xF>(T(0), last2); xe[1] = dpp_t<0x138, 0xF>(T(0), lastv);       // wave_shr:1
+#pragma unroll
+  for (int i = 0; i < M - 1; ++i) xe[i + 2] = x[i];
+  xe[M + 1] = hl ? x[M - 1] : xp1; xe[M + 2] = hl ? xp1 : xp2; xe[M + 3] = xp2;
+  IBS_PROBE_AT(13);
+  const T ih = T(1) / h;
+  const T A_in = (T(2) / T(3)) * ih, B_in = -ih / T(12), A_e1 = T(0.5) * ih, A_e0 = T(2) * ih, B_e0 = T(-0.5) * ih;
+  bool do_hf = false;
+  if constexpr (HF) do_hf = dth0_out != nullptr;
+  T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
+  const T w_even = ((a + 1) & 1) ? T(4) : T(2), w_odd = ((a + 1) & 1) ? T(2) : T(4);   // Simpson weight of slot i
+  const int i_end = (lane == kWave - 1) ? (hl ? M - 1 : M - 2) : -1;                   // slot of grid point N-2
+  auto all_points = [&](auto with_tangent) {
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const bool act = (i < M - 1) || hl;
+      const bool e1 = (i == 0 && lane == 0) || (i == i_end);                           // j = 1, N-2: utils.py:1611, 1613
+      const T A = e1 ? A_e1 : A_in, B = e1 ? T(0) : B_in;
+      const T dX = xfma(A, xe[i + 3] - xe[i + 1], B * (xe[i + 4] - xe[i]));           // utils.py:1616
+      const T w = act ? ((i & 1) ? w_odd : w_even) : T(0);
+      simpson_point<T, Src, HF && decltype(with_tangent)::value>(src, a + i + 1, w, xe[i + 2], dX, y0, y1, hc, hg, hf);
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most 4 rows of LDS reads in flight (registers)
+    }
+    if (lane == 0 || lane == kWave - 1) {                                              // j = 0, N-1: utils.py:1610, 1614
+      const bool first = lane == 0;
+      const T d1 = first ? x[0] : -lastv, d2 = first ? x[1] : -last2;
+      simpson_point<T, Src, HF && decltype(with_tangent)::value>(src, first ? 0 : N - 1, T(1), T(0), xfma(A_e0, d1, B_e0 * d2), y0, y1, hc, hg, hf);
+    }
+  };
+  if constexpr (HF) {
+    if (do_hf) all_points(std::true_type{});
+    else all_points(std::false_type{});
+  } else {
+    all_points(std::false_type{});
+  }
+  IBS_PROBE_AT(14);
+  y0 = wave_sum(y0); y1 = wave_sum(y1);
+  const T gam = y0 / y1;                                             // utils.py:1621 (the 1/3 of Simpson cancels)
+  if constexpr (HF) {
+    if (do_hf) {
+      hc = wave_sum(hc); hg = wave_sum(hg); hf = wave_sum(hf);
+      const T jac = hc / y1 - hg / y1 - gam * hf / y1;               // utils.py:1676-1680
+      if (lane == 0) dth0_out[sys] = jac;
+    }
+  }
+  if (lane == 0) {
+    if (lam_out) lam_out[sys] = lam;
+    if (gam_out) gam_out[sys] = gam;
+    if (info_out) info_out[sys] = inf.iters | (inf.status << 16);
+  }
+  if (X_out || dX_out) {                   // wave-uniform
+    for (int pass = 0; pass < 2; ++pass) {
+      T* out = pass ? dX_out : X_out;
+      if (!out) continue;
+      wave_lds_sync();                     // the row's previous content (f of k_solve_gcf, or X) has been consumed
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const bool e1 = (i == 0 && lane == 0) || (i == i_end);
+        const T A = e1 ? A_e1 : A_in, B = e1 ? T(0) : B_in;
+        const T v = pass ? xfma(A, xe[i + 3] - xe[i + 1], B * (xe[i + 4] - xe[i])) : xe[i + 2];
+        if ((i < M - 1) || hl) Xs[lpos(a + i + 1)] = v;
+      }
+      if (lane == 0) Xs[lpos(0)] = pass ? xfma(A_e0, x[0], B_e0 * x[1]) : T(0);                 // utils.py:1607, 1610
+      if (lane == kWave - 1) Xs[lpos(N - 1)] = pass ? xfma(A_e0, -lastv, B_e0 * (-last2)) : T(0);   // utils.py:1608, 1614
+      wave_lds_sync();
+      for (int j = lane; j < N; j += kWave) out[sys * N + j] = Xs[lpos(j)];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- raw (g, c, f) systems
 // block = WPB waves, one system per wave; dynamic LDS = WPB * 3N * sizeof(T): (g, c, f) staged once
 // through LDS for the chunked register load; afterwards the eigenfunction X reuses f's slot and the
@@ -226,10 +341,16 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   T lam = T(0);
   if (!bad) lam = ws.solve(inf);
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
-  const SrcGCFG<T> srcf{gs, cs, fg};       // growth-rate stage: f from global memory
-  finish<T, M, SrcGCFG<T>, false>(ws, srcf, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
-                                 valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
-                                 nullptr, valid ? info_out : nullptr);
+  if constexpr (M >= 3) {                  // f is read from its LDS slot, which X / dX reuse afterwards
+    finish_chunk<T, M, SrcGCF<T>, false>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                         valid ? gam_out : nullptr, valid ? X_out : nullptr,
+                                         valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
+  } else {
+    const SrcGCFG<T> srcf{gs, cs, fg};     // growth-rate stage: f from global memory
+    finish<T, M, SrcGCFG<T>, false>(ws, srcf, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                   valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                   nullptr, valid ? info_out : nullptr);
+  }
 }
 
 // ---------------------------------------------------------------- geometry-fed theta0 scan
@@ -295,9 +416,15 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   if (!bad) lam = lam_guess ? ws.solve(inf, true, lam_guess[sys], guess_width) : ws.solve(inf);
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   IBS_PROBE_AT(3);
-  finish<T, M, SrcGeo<T>, true>(ws, src, N, h, Xs, lam, inf, sys, valid ? lam_out : nullptr,
-                                valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
-                                valid ? dth0_out : nullptr, valid ? info_out : nullptr);
+  if constexpr (M >= 3) {
+    finish_chunk<T, M, SrcGeo<T>, true>(ws, src, N, h, Xs, lam, inf, sys, valid ? lam_out : nullptr,
+                                        valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                        valid ? dth0_out : nullptr, valid ? info_out : nullptr);
+  } else {
+    finish<T, M, SrcGeo<T>, true>(ws, src, N, h, Xs, lam, inf, sys, valid ? lam_out : nullptr,
+                                  valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                  valid ? dth0_out : nullptr, valid ? info_out : nullptr);
+  }
   IBS_PROBE_AT(4);
 }
 
@@ -497,7 +624,7 @@ __global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, con
   for (int i = 0; i < M; ++i) {
     const bool act = (i < M - 1) || has_last;
     const T zn = xfma(-t[i], zc, -(e2[i] * zp));
-    const bool flip = act && (signbit_of(zn) != signbit_of(zc));
+    const bool flip = act && sign_differs(zn, zc);
     cnt += __popcll(__ballot(flip));
     if (act) { zp = zc; zc = zn; }
   }

@@ -54,6 +54,14 @@ __device__ __forceinline__ double xmin(double a, double b) { return __builtin_fm
 __device__ __forceinline__ float xmin(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ bool signbit_of(double a) { return __double2hiint(a) < 0; }
 __device__ __forceinline__ bool signbit_of(float a) { return __float_as_int(a) < 0; }
+// sign bits differ: one xor of the high words + one 32-bit compare (the empty asm keeps the compiler from widening
+// the test to a 64-bit xor + 64-bit compare)
+__device__ __forceinline__ bool sign_differs(double a, double b) {
+  int x = __double2hiint(a) ^ __double2hiint(b);
+  asm("" : "+v"(x));
+  return x < 0;
+}
+__device__ __forceinline__ bool sign_differs(float a, float b) { return (__float_as_int(a) ^ __float_as_int(b)) < 0; }
 __device__ __forceinline__ bool finite_of(double a) { return xabs(a) <= 1.7976931348623157e308; }
 __device__ __forceinline__ bool finite_of(float a) { return xabs(a) <= 3.4028234e38f; }
 
@@ -385,7 +393,7 @@ struct WaveSolver {
       const bool act = (i < M - 1) || has_last;
       zu[i] = act ? zc : T(0);
       const T zn = xfma(-t, zc, -zp);
-      const bool flip = act && (signbit_of(zn) != signbit_of(zc));
+      const bool flip = act && sign_differs(zn, zc);
       count += __popcll(__ballot(flip));
       if (act) { zp = zc; zc = zn; }
     }
