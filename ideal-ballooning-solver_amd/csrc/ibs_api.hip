@@ -1,6 +1,7 @@
 // C-ABI layer of libibs_hip.so (declarations and reference citations: include/ibs.h).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -240,6 +241,125 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   return 0;
 }
 
+
+// ---------------------------------------------------------------- (alpha, theta0) maximiser state machine (row F2)
+// One thread per evaluation point.  Mirrors the bounded quasi-Newton of BallooningScan.refine_batched
+// (projected BFGS + Armijo backtracking; same bounds, tolerances and iteration cap as the scipy L-BFGS-B call of
+// ball_scan.py:307-314), but every point advances on its own: no host round trip between evaluations.
+struct RefineState {
+  double x[2], f, g[2], H[4], pg[2], d[2], t, xt[2];
+  int phase;    // 0 = waiting for the first evaluation, 1 = line search
+  int ls, it, active, nev;
+};
+struct RefineParams { double lo[2], hi[2], del_alpha, ftol, gtol; int maxiter, n_surf; };
+
+__device__ inline double clipd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// evaluation request of one point into slot j of the batch: the three field lines of utils.py:1641-1646 and theta0
+__device__ inline void refine_emit(const RefineState& s, const RefineParams& p, int j, int surf, int* line_surf,
+                                   double* line_alpha, double* th0) {
+  const double a = s.active ? s.xt[0] : s.x[0];
+  for (int l = 0; l < 3; ++l) { line_surf[3 * j + l] = surf; line_alpha[3 * j + l] = a + (l - 1) * 0.5 * p.del_alpha; }
+  th0[j] = s.active ? s.xt[1] : s.x[1];
+}
+
+// start of a quasi-Newton iteration at (x, f, g): projected gradient test, direction, first trial step
+__device__ inline void refine_begin_iter(RefineState& s, const RefineParams& p) {
+  for (int i = 0; i < 2; ++i) {
+    double v = s.g[i];
+    if ((s.x[i] <= p.lo[i] && v > 0) || (s.x[i] >= p.hi[i] && v < 0)) v = 0.0;
+    s.pg[i] = v;
+  }
+  if (!(fmax(fabs(s.pg[0]), fabs(s.pg[1])) > p.gtol)) { s.active = 0; return; }
+  s.d[0] = -(s.H[0] * s.pg[0] + s.H[1] * s.pg[1]);
+  s.d[1] = -(s.H[2] * s.pg[0] + s.H[3] * s.pg[1]);
+  if (s.d[0] * s.pg[0] + s.d[1] * s.pg[1] >= 0) { s.d[0] = -s.pg[0]; s.d[1] = -s.pg[1]; }   // not a descent direction
+  const double nrm = fmax(fmax(fabs(s.d[0]), fabs(s.d[1])), 1e-300);
+  s.t = fmin(1.0, 0.3 / nrm);                                          // first trial step: at most 0.3 rad
+  s.ls = 0;
+  for (int i = 0; i < 2; ++i) s.xt[i] = clipd(s.x[i] + s.t * s.d[i], p.lo[i], p.hi[i]);
+  s.phase = 1;
+}
+
+__global__ void k_refine_init(int n, const int* pt_surf, const double* start, RefineState* st, RefineParams p,
+                              int* idx, int* line_surf, double* line_alpha, double* th0) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  RefineState s{};
+  for (int i = 0; i < 2; ++i) { s.x[i] = clipd(start[2 * k + i], p.lo[i], p.hi[i]); s.xt[i] = s.x[i]; }
+  s.H[0] = 1.0; s.H[3] = 1.0;
+  s.active = 1;
+  st[k] = s;
+  idx[k] = k;
+  const int surf = min(max(pt_surf[k], 0), p.n_surf - 1);
+  refine_emit(s, p, k, surf, line_surf, line_alpha, th0);
+}
+
+// consumes the evaluations (val, jac) of the n_c batch slots (slot j holds point idx[j]) and emits the next
+// evaluation request of each into the same slot
+__global__ void k_refine_step(int n_c, const int* idx, const int* pt_surf, RefineState* st, RefineParams p,
+                              const double* val, const double* jac, int* line_surf, double* line_alpha, double* th0,
+                              int* n_active) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_c) return;
+  const int k = idx[j];
+  RefineState s = st[k];
+  if (s.active) {
+    const double ft = val[j], gt[2] = {jac[2 * j], jac[2 * j + 1]};
+    s.nev++;
+    if (s.phase == 0) {
+      s.f = ft; s.g[0] = gt[0]; s.g[1] = gt[1]; s.it = 0;
+      refine_begin_iter(s, p);
+    } else {
+      const double dec = s.pg[0] * (s.xt[0] - s.x[0]) + s.pg[1] * (s.xt[1] - s.x[1]);
+      if (ft <= s.f + 1e-4 * dec) {                                  // Armijo: accept
+        const double sk[2] = {s.xt[0] - s.x[0], s.xt[1] - s.x[1]}, yk[2] = {gt[0] - s.g[0], gt[1] - s.g[1]};
+        const double sy = sk[0] * yk[0] + sk[1] * yk[1];
+        if (sy > 1e-14) {                                            // BFGS update of the inverse Hessian
+          const double rho = 1.0 / sy;
+          double V[4] = {1.0 - rho * sk[0] * yk[0], -rho * sk[0] * yk[1], -rho * sk[1] * yk[0], 1.0 - rho * sk[1] * yk[1]};
+          double VH[4] = {V[0] * s.H[0] + V[1] * s.H[2], V[0] * s.H[1] + V[1] * s.H[3],
+                          V[2] * s.H[0] + V[3] * s.H[2], V[2] * s.H[1] + V[3] * s.H[3]};
+          s.H[0] = VH[0] * V[0] + VH[1] * V[1] + rho * sk[0] * sk[0];
+          s.H[1] = VH[0] * V[2] + VH[1] * V[3] + rho * sk[0] * sk[1];
+          s.H[2] = VH[2] * V[0] + VH[3] * V[1] + rho * sk[1] * sk[0];
+          s.H[3] = VH[2] * V[2] + VH[3] * V[3] + rho * sk[1] * sk[1];
+        }
+        const bool small = fabs(s.f - ft) <= p.ftol * fmax(fmax(fabs(s.f), fabs(ft)), 1.0);
+        s.x[0] = s.xt[0]; s.x[1] = s.xt[1]; s.f = ft; s.g[0] = gt[0]; s.g[1] = gt[1];
+        s.it++;
+        if (small || s.it >= p.maxiter) s.active = 0;
+        else refine_begin_iter(s, p);
+      } else {
+        s.t *= 0.35; s.ls++;
+        if (s.ls >= 12) s.active = 0;                                // line search failed: stop this point
+        else for (int i = 0; i < 2; ++i) s.xt[i] = clipd(s.x[i] + s.t * s.d[i], p.lo[i], p.hi[i]);
+      }
+    }
+    st[k] = s;
+  }
+  const int surf = min(max(pt_surf[k], 0), p.n_surf - 1);
+  refine_emit(s, p, j, surf, line_surf, line_alpha, th0);
+  if (s.active) atomicAdd(n_active, 1);
+}
+
+// drop the finished points from the batch: the still active ones get new slots (any order) and re-emit there
+__global__ void k_refine_compact(int n_c, const int* idx_in, int* idx_out, const int* pt_surf, const RefineState* st,
+                                 RefineParams p, int* line_surf, double* line_alpha, double* th0, int* counter) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_c) return;
+  const int k = idx_in[j];
+  if (!st[k].active) return;
+  const int pos = atomicAdd(counter, 1);
+  idx_out[pos] = k;
+  refine_emit(st[k], p, pos, min(max(pt_surf[k], 0), p.n_surf - 1), line_surf, line_alpha, th0);
+}
+
+__global__ void k_refine_out(int n, const RefineState* st, double* x_opt, double* f_opt, int* n_evals) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  x_opt[2 * k] = st[k].x[0]; x_opt[2 * k + 1] = st[k].x[1]; f_opt[k] = st[k].f; n_evals[k] = st[k].nev;
+}
 }  // namespace
 
 extern "C" {
@@ -640,6 +760,139 @@ int ibs_surface_argmax_pack_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per, con
   hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(argmax_threads(n_per)), 0, ctx->stream, n_per, gam, (int*)nullptr, (double*)nullptr, pack);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm, const double* xn,
+                   const double* xm_nyq, const double* xn_nyq, const double* tab_mn, const double* tab_nyq,
+                   const double* scal, int32_t nrows_mn, const int32_t* rows_mn, int32_t nrows_nyq,
+                   const int32_t* rows_nyq, double dn_mn, double dn_nyq, int32_t n_pts, const int32_t* pt_surf,
+                   const double* start, int32_t N, const double* theta, double del_alpha, int32_t maxiter,
+                   double ftol, double gtol, double* x_opt, double* f_opt, int32_t* n_evals, int32_t mem) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (nrows_mn < 0 || nrows_nyq < 0 || (nrows_mn > 0 && !rows_mn) || (nrows_nyq > 0 && !rows_nyq))
+    return fail(IBS_ERR_ARG, "bad row tables");
+  if (n_surf <= 0 || mnmax <= 0 || mnmax_nyq <= 0 || n_pts < 0 || !xm || !xn || !xm_nyq || !xn_nyq || !tab_mn ||
+      !tab_nyq || !scal || !pt_surf || !start || !theta || !x_opt || !f_opt || !(del_alpha > 0) || maxiter < 0)
+    return fail(IBS_ERR_ARG, "bad arguments");
+  if (n_pts == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const bool host = (mem == IBS_MEM_HOST);
+  // theta must be uniform; h from its ends (checked on the host copy)
+  std::vector<double> th_h(N > 0 ? N : 0);
+  if (N < 2) return fail(IBS_ERR_ARG, "N=%d", N);
+  HIPCHK(hipMemcpyAsync(th_h.data(), theta, (size_t)N * 8, hipMemcpyDefault, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const double h = (th_h[N - 1] - th_h[0]) / (N - 1);
+  if (int r = check_grid(N, h)) return r;
+  for (int j = 1; j < N; ++j)
+    if (fabs((th_h[j] - th_h[j - 1]) - h) > 1e-9 * fabs(h)) return fail(IBS_ERR_UNSUPPORTED, "theta grid is not uniform");
+  if (host)
+    for (int i = 0; i < n_pts; ++i)
+      if (pt_surf[i] < 0 || pt_surf[i] >= n_surf) return fail(IBS_ERR_ARG, "pt_surf[%d]=%d out of range", i, pt_surf[i]);
+  const int M = rows_per_lane(N);
+  auto grad = ibs::launch_table().grad_f64[M];
+  if (!grad) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
+  const size_t per_wave = (size_t)8 * ibs::lds_pitch(N) * sizeof(double);
+  int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
+  {
+    long per_blk = (long)n_pts / ctx->n_cu;
+    if (per_blk < 1) per_blk = 1;
+    if (per_blk < wpb) wpb = (int)per_blk;
+  }
+  const long ld = N;
+  const int n_lines = 3 * n_pts;
+  const size_t n_mn = (size_t)n_surf * 6 * mnmax, n_nyq = (size_t)n_surf * 7 * mnmax_nyq, n_geo = (size_t)8 * n_lines * ld;
+  size_t need = pad256(n_geo * 8) + 2 * pad256((size_t)n_lines * 4) + 2 * pad256((size_t)n_lines * 8) + 12 * pad256((size_t)n_pts * 16) +
+                pad256((size_t)n_pts * sizeof(RefineState)) + pad256((size_t)N * 8) + 8192;
+  if (host) need += pad256(n_mn * 8) + pad256(n_nyq * 8) + 2 * pad256((size_t)mnmax * 8) + 2 * pad256((size_t)mnmax_nyq * 8) +
+                    pad256((size_t)n_surf * 48) + pad256((size_t)nrows_mn * 8) + pad256((size_t)nrows_nyq * 8) + 4096;
+  if (int r = ensure_ws(ctx, need)) return r;
+  Arena ar(ctx);
+  hipStream_t st = ctx->stream;
+  auto up = [&](const void* src, size_t bytes, void* dst) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st); };
+  ibs::GeoArgs ga{};
+  ga.n_surf = n_surf; ga.mnmax = mnmax; ga.mnmax_nyq = mnmax_nyq; ga.n_lines = n_lines; ga.N = N; ga.ld = ld;
+  if (host) {
+    double* d_xm = ar.take<double>(mnmax); double* d_xn = ar.take<double>(mnmax);
+    double* d_xmq = ar.take<double>(mnmax_nyq); double* d_xnq = ar.take<double>(mnmax_nyq);
+    double* d_mn = ar.take<double>(n_mn); double* d_nyq = ar.take<double>(n_nyq); double* d_sc = ar.take<double>((size_t)n_surf * 6);
+    HIPCHK(up(xm, (size_t)mnmax * 8, d_xm)); HIPCHK(up(xn, (size_t)mnmax * 8, d_xn));
+    HIPCHK(up(xm_nyq, (size_t)mnmax_nyq * 8, d_xmq)); HIPCHK(up(xn_nyq, (size_t)mnmax_nyq * 8, d_xnq));
+    HIPCHK(up(tab_mn, n_mn * 8, d_mn)); HIPCHK(up(tab_nyq, n_nyq * 8, d_nyq)); HIPCHK(up(scal, (size_t)n_surf * 48, d_sc));
+    ga.xm = d_xm; ga.xn = d_xn; ga.xm_nyq = d_xmq; ga.xn_nyq = d_xnq; ga.tab_mn = d_mn; ga.tab_nyq = d_nyq; ga.scal = d_sc;
+    if (nrows_mn > 0 && nrows_nyq > 0) {
+      int* d_r1 = ar.take<int>((size_t)2 * nrows_mn); int* d_r2 = ar.take<int>((size_t)2 * nrows_nyq);
+      HIPCHK(up(rows_mn, (size_t)nrows_mn * 8, d_r1)); HIPCHK(up(rows_nyq, (size_t)nrows_nyq * 8, d_r2));
+      ga.nrows_mn = nrows_mn; ga.nrows_nyq = nrows_nyq; ga.rows_mn = d_r1; ga.rows_nyq = d_r2; ga.dn_mn = dn_mn; ga.dn_nyq = dn_nyq;
+    }
+  } else {
+    ga.xm = xm; ga.xn = xn; ga.xm_nyq = xm_nyq; ga.xn_nyq = xn_nyq; ga.tab_mn = tab_mn; ga.tab_nyq = tab_nyq; ga.scal = scal;
+    if (nrows_mn > 0 && nrows_nyq > 0) { ga.nrows_mn = nrows_mn; ga.nrows_nyq = nrows_nyq; ga.rows_mn = rows_mn; ga.rows_nyq = rows_nyq; ga.dn_mn = dn_mn; ga.dn_nyq = dn_nyq; }
+  }
+  double* d_th = ar.take<double>(N);
+  HIPCHK(up(theta, (size_t)N * 8, d_th));
+  int* d_ps = ar.take<int>(n_pts); double* d_start = ar.take<double>((size_t)2 * n_pts);
+  HIPCHK(up(pt_surf, (size_t)n_pts * 4, d_ps)); HIPCHK(up(start, (size_t)n_pts * 16, d_start));
+  double* d_geo = ar.take<double>(n_geo);
+  int* d_ls[2]; double* d_la[2]; double* d_t0[2]; int* d_idx[2];
+  for (int q = 0; q < 2; ++q) { d_ls[q] = ar.take<int>(n_lines); d_la[q] = ar.take<double>(n_lines); d_t0[q] = ar.take<double>(n_pts); d_idx[q] = ar.take<int>(n_pts); }
+  RefineState* d_st = ar.take<RefineState>(n_pts);
+  double* d_val = ar.take<double>(n_pts); double* d_jac = ar.take<double>((size_t)2 * n_pts);
+  double* d_gam = ar.take<double>(n_pts); double* d_da = ar.take<double>(n_pts); double* d_dt = ar.take<double>(n_pts);
+  int* d_info = ar.take<int>(n_pts); int* d_nact = ar.take<int>(2);
+  double* d_xo = ar.take<double>((size_t)2 * n_pts); double* d_fo = ar.take<double>(n_pts); int* d_ne = ar.take<int>(n_pts);
+  ga.theta = d_th; ga.geo = d_geo; ga.dPdrho = nullptr;
+
+  RefineParams prm{};
+  prm.lo[0] = 0.0; prm.lo[1] = 0.0; prm.hi[0] = 3.141592653589793; prm.hi[1] = 1.5707963267948966;   // ball_scan.py:311
+  prm.del_alpha = del_alpha; prm.ftol = ftol; prm.gtol = gtol; prm.maxiter = maxiter; prm.n_surf = n_surf;
+  ibs::GradArgs<double> a{};
+  a.n_pts = n_pts; a.N = N; a.h = h; a.ld = ld; a.del_alpha = del_alpha; a.wpb = wpb;
+  a.line_stride = ld;                                                   // geometry kernel output: [8][lines][ld] planes
+  a.geo = d_geo; a.val = d_val; a.jac = d_jac; a.gam = d_gam; a.dalpha = d_da; a.dth0 = d_dt; a.info = d_info;
+
+  const dim3 grd((unsigned)((n_pts + 127) / 128)), blk(128);
+  hipLaunchKernelGGL(k_refine_init, grd, blk, 0, st, n_pts, d_ps, d_start, d_st, prm, d_idx[0], d_ls[0], d_la[0], d_t0[0]);
+  HIPCHK(hipGetLastError());
+  // every round = one objective/gradient evaluation of every point still in the batch; at most 1 + 12 per iteration
+  const int max_rounds = 1 + 12 * (maxiter > 0 ? maxiter : 1);
+  int rounds = 0, n_c = n_pts, cur = 0;
+  while (rounds < max_rounds && n_c > 0) {
+    const dim3 grc((unsigned)((n_c + 127) / 128));
+    ga.n_lines = 3 * n_c; ga.line_surf = d_ls[cur]; ga.line_alpha = d_la[cur];
+    a.n_pts = n_c; a.theta0 = d_t0[cur]; a.arr_stride = (long)ga.n_lines * ld;   // planes of this round's batch
+    {
+      long per_blk = (long)n_c / ctx->n_cu;
+      a.wpb = (int)(per_blk < 1 ? 1 : (per_blk < wpb ? per_blk : wpb));
+    }
+    const int burst = rounds < 8 ? 4 : 2;                               // rounds between two looks at the active count
+    for (int b = 0; b < burst && rounds < max_rounds; ++b, ++rounds) {
+      HIPCHK(ibs::launch_geometry(ga, st));
+      HIPCHK(grad(a, st));
+      HIPCHK(hipMemsetAsync(d_nact, 0, 2 * sizeof(int), st));
+      hipLaunchKernelGGL(k_refine_step, grc, blk, 0, st, n_c, d_idx[cur], d_ps, d_st, prm, d_val, d_jac, d_ls[cur], d_la[cur],
+                         d_t0[cur], d_nact);
+      HIPCHK(hipGetLastError());
+    }
+    int n_active = 0;
+    HIPCHK(hipMemcpyAsync(&n_active, d_nact, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_active < n_c && n_active > 0) {                               // finished points leave the batch
+      hipLaunchKernelGGL(k_refine_compact, grc, blk, 0, st, n_c, d_idx[cur], d_idx[cur ^ 1], d_ps, d_st, prm, d_ls[cur ^ 1],
+                         d_la[cur ^ 1], d_t0[cur ^ 1], d_nact + 1);
+      HIPCHK(hipGetLastError());
+      cur ^= 1;
+    }
+    n_c = n_active;
+  }
+  hipLaunchKernelGGL(k_refine_out, grd, blk, 0, st, n_pts, d_st, d_xo, d_fo, d_ne);
+  HIPCHK(hipGetLastError());
+  HIPCHK(up(d_xo, (size_t)n_pts * 16, x_opt)); HIPCHK(up(d_fo, (size_t)n_pts * 8, f_opt));
+  if (n_evals) HIPCHK(up(d_ne, (size_t)n_pts * 4, n_evals));
+  HIPCHK(hipStreamSynchronize(st));
+  return rounds;
 }
 
 }  // extern "C"

@@ -441,6 +441,7 @@ __device__ __forceinline__ T line_dPdrho(const T* p, long ld, int N, int lane) {
 }
 template <typename T, int M>
 __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const T* __restrict__ geo, long ld,
+                                                    long line_stride,
                                                     const T* __restrict__ theta0, T del_alpha, T* val_out,
                                                     T* jac_out, T* gam_out, T* dalpha_out, T* dth0_out, int* info_out) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -453,9 +454,12 @@ __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const
   const int P = lds_pitch(N);
   T* A1 = smem + (size_t)wave * 8 * P;
   T* A3 = A1 + P; T* C0 = A3 + P; T* C1 = C0 + P; T* G0 = C1 + P; T* G1 = G0 + P; T* G2 = G1 + P; T* Xs = G2 + P;
-  const T* pl = geo + ((long)ptc * 3 + 0) * 8 * ld;
-  const T* pc = geo + ((long)ptc * 3 + 1) * 8 * ld;
-  const T* pr = geo + ((long)ptc * 3 + 2) * 8 * ld;
+  // `ld` = distance between the 8 arrays of one line, `line_stride` = distance between consecutive lines:
+  // (ld, 8 ld) for the [n_pts][3][8][ld] layout of the C ABI, (n_lines ld, ld) for the [8][n_lines][ld] planes the
+  // geometry kernel writes
+  const T* pl = geo + ((long)ptc * 3 + 0) * line_stride;
+  const T* pc = geo + ((long)ptc * 3 + 1) * line_stride;
+  const T* pr = geo + ((long)ptc * 3 + 2) * line_stride;
   const T dP_l = line_dPdrho(pl, ld, N, lane), dP_c = line_dPdrho(pc, ld, N, lane), dP_r = line_dPdrho(pr, ld, N, lane);
   for (int j = lane; j < N; j += kWave) {
     const T B = pc[j], gp = xabs(pc[ld + j]);
@@ -677,8 +681,8 @@ static hipError_t launch_grad(const GradArgs<T>& a, hipStream_t st) {
   auto kern = k_obj_w_grad<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((a.n_pts + wpb - 1) / wpb), dim3(wpb * 64), lds, st, a.n_pts, a.N, a.h, a.geo, a.ld,
-                     a.theta0, a.del_alpha, a.val, a.jac, a.gam, a.dalpha, a.dth0, a.info);
+  hipLaunchKernelGGL(kern, dim3((a.n_pts + wpb - 1) / wpb), dim3(wpb * 64), lds, st, a.n_pts, a.N, a.h, a.geo,
+                     a.arr_stride ? a.arr_stride : a.ld, a.line_stride ? a.line_stride : 8 * a.ld, a.theta0, a.del_alpha, a.val, a.jac, a.gam, a.dalpha, a.dth0, a.info);
   return hipGetLastError();
 }
 

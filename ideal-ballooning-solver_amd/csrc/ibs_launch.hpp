@@ -30,6 +30,7 @@ template <typename T>
 struct GradArgs {
   int n_pts, N; T h; const T* geo; long ld; const T* theta0; T del_alpha;
   T *val, *jac, *gam, *dalpha, *dth0; int* info; int wpb;
+  long arr_stride, line_stride;   // 0 = the [n_pts][3][8][ld] layout (ld, 8 ld); see k_obj_w_grad
 };
 
 struct LaunchTable {

@@ -198,13 +198,21 @@ class BallooningScan:
             active &= ~small
         return x, f, nev
 
+    def refine_device(self, starts, maxiter=30, ftol=5.0e-11, gtol=2.0e-8):
+        """the same maximisation with the quasi-Newton state machine on the device as well (ibs_refine_f64): no host
+        round trip per evaluation.  Returns (x_opt (n, 2), f_opt (n,) = -gam, evaluations per surface (n,))."""
+        surf = np.array([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own])
+        xo, fo, ne, _ = self.ctx.refine(self.tables, surf, np.asarray(starts, dtype=np.float64).reshape(len(surf), 2),
+                                        self.theta, self.del_alpha, maxiter, ftol, gtol, device=self.device)
+        return xo, fo, ne
+
     def run(self, refine=True):
         """returns (theta0_arr, alpha_arr, gam_arr), each (nsurfs,), identical on every rank"""
         tabs = self.coarse()
         rows = []
         if refine and self.tables is not None and self.device is not None and self.own:
             starts = np.array([pick_start(tab, self.alpha_scan, self.theta0_scan)[:2] for tab in tabs])
-            xo, fo, _ = self.refine_batched(starts)
+            xo, fo, _ = self.refine_device(starts)
             local = np.stack([xo[:, 1], xo[:, 0], -fo], axis=1)
             full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device)
             return full[:, 0], full[:, 1], full[:, 2]

@@ -195,12 +195,9 @@ class Context:
         import torch
         # tables are uploaded once and stay resident; the device copies live ON the tables object (a cache keyed by
         # id(tables) would hand a later object that re-uses the id the previous object's tables)
-        cache = tables.__dict__.setdefault("_device_copies", {})
-        key = str(device)
-        if key not in cache:
-            cache[key] = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in host + [tables.rows_mn, tables.rows_nyq]]
-        dev = cache[key][:7]
-        d_rows = cache[key][7:]
+        allc = self._device_tables(tables, device)
+        dev = allc[:7]
+        d_rows = allc[7:]
         d_ls, d_la, d_th = (torch.from_numpy(a).to(device) for a in (ls, la, th))
         geo = torch.empty((8, n_lines, N), dtype=torch.float64, device=device)
         dP = torch.empty((n_lines,), dtype=torch.float64, device=device)
@@ -214,6 +211,53 @@ class Context:
               "ibs_fieldline_geometry_f64")
         self._keep = (d_ls, d_la, d_th)
         return dict(geo=geo, dPdrho=dP)
+
+    def _device_tables(self, tables, device):
+        """the surface/mode/row tables of `tables` resident on `device` (uploaded once, cached on the object)"""
+        import torch
+        cache = tables.__dict__.setdefault("_device_copies", {})
+        key = str(device)
+        if key not in cache:
+            host = [tables.xm, tables.xn, tables.xm_nyq, tables.xn_nyq, tables.tab_mn, tables.tab_nyq, tables.scal]
+            cache[key] = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in host + [tables.rows_mn, tables.rows_nyq]]
+        return cache[key]
+
+    def refine(self, tables, pt_surf, starts, theta, del_alpha=0.004, maxiter=30, ftol=5.0e-11, gtol=2.0e-8, device=None):
+        """maximise gam over (alpha, theta0) from starts (n, 2) on surfaces tables.s[pt_surf] -- the whole
+        quasi-Newton loop runs on the device (ibs_refine_f64; replaces ball_scan.py:305-314).
+        Returns (x_opt (n, 2), f_opt (n,) = -gam, n_evals (n,), rounds) as numpy."""
+        ps = np.ascontiguousarray(pt_surf, dtype=np.int32)
+        st = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 2)
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        n = len(ps)
+        if st.shape[0] != n:
+            raise IbsError("starts must be (len(pt_surf), 2)")
+        if ps.size and (ps.min() < 0 or ps.max() >= len(tables.s)):
+            raise IbsError("pt_surf out of range")
+        nr = (len(tables.rows_mn), len(tables.rows_nyq))
+        head = (self._h, len(tables.s), len(tables.xm), len(tables.xm_nyq))
+        tail = (float(del_alpha), int(maxiter), float(ftol), float(gtol))
+        if device is None:
+            xo = np.empty((n, 2)); fo = np.empty(n); ne = np.zeros(n, dtype=np.int32)
+            p = lambda a: C.c_void_p(a.ctypes.data)
+            host = [tables.xm, tables.xn, tables.xm_nyq, tables.xn_nyq, tables.tab_mn, tables.tab_nyq, tables.scal]
+            rounds = check(self._lib.ibs_refine_f64(*head, *[p(a) for a in host], nr[0], p(tables.rows_mn), nr[1],
+                                                    p(tables.rows_nyq), float(tables.dn_mn), float(tables.dn_nyq), n, p(ps),
+                                                    p(st), len(th), p(th), *tail, p(xo), p(fo), p(ne), MEM_HOST),
+                           "ibs_refine_f64")
+            return xo, fo, ne, rounds
+        import torch
+        dev = self._device_tables(tables, device)
+        d_ps, d_st, d_th = (torch.from_numpy(a).to(device) for a in (ps, st, th))
+        xo = torch.empty((n, 2), dtype=torch.float64, device=device)
+        fo = torch.empty((n,), dtype=torch.float64, device=device)
+        ne = torch.zeros((n,), dtype=torch.int32, device=device)
+        self._stream_from_torch(xo)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rounds = check(self._lib.ibs_refine_f64(*head, *[p(t) for t in dev[:7]], nr[0], p(dev[7]), nr[1], p(dev[8]),
+                                                float(tables.dn_mn), float(tables.dn_nyq), n, p(d_ps), p(d_st), len(th),
+                                                p(d_th), *tail, p(xo), p(fo), p(ne), MEM_DEVICE), "ibs_refine_f64")
+        return xo.cpu().numpy(), fo.cpu().numpy(), ne.cpu().numpy(), rounds
 
     def hf_grad(self, X, dX, f, g_p, c_p, f_p, gam):
         """Hellmann-Feynman d(gam)/dp for caller-built tangents (utils.py:1676-1680, 1721-1725).
