@@ -214,6 +214,61 @@ def warm_rescan(ctx, device, h, geo7, dP_d, th0_d, reps=20):
                 max_abs_dgam_warm_vs_cold=float((warm["gam"] - cold["gam"]).abs().max().item()), guess_width=width)
 
 
+def ncsx_pipeline(ctx, device):
+    """configs[2] shape on one GPU (64 surfaces x 32 alpha x 16 theta0, N_zeta=1024) from the shipped NCSX equilibrium's
+    wout tables: field-line geometry kernel (row F1) -> geometry-fed scan -> per-surface argmax, and the reference's
+    own batch (5 surfaces x 24 x 15, N=969) with its refinement (ball_scan.py:305-339) on the device (row F2)."""
+    import torch
+    import ibs_amd
+    from oracle import ballooning_oracle as bo          # theta grid helper only (A0)
+    wout = dict(np.load(os.path.join(ROOT, "tests", "golden", "G8_wout_ncsx_op.npz")))
+    out = {}
+    for tag, ns, na, nt0, N, svals in (("ncsx_c3", 64, 32, 16, 1025, np.linspace(0.1, 0.95, 64)),
+                                       ("reference_batch", 5, 24, 15, 969, np.linspace(0.5, 0.95, 5))):
+        tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
+        th = bo.theta_grid(N)
+        alphas = np.linspace(0, np.pi, na)
+        t0 = torch.from_numpy(np.linspace(0, np.pi / 2, nt0)).to(device)
+        surf = np.repeat(np.arange(ns), na); al = np.tile(alphas, ns)
+        best = None
+        for rep in range(3):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+            r = ctx.fieldline_geometry(tabs, surf, al, th, device=device)
+            e[1].record()
+            sc = ctx.gamma_scan(th[1] - th[0], *[r["geo"][k] for k in range(7)], r["dPdrho"], t0, want_info=True)
+            e[2].record()
+            idx, val = ctx.surface_argmax(sc["gam"].reshape(ns, -1))
+            e[3].record()
+            torch.cuda.synchronize()
+            t = [e[k].elapsed_time(e[k + 1]) for k in range(3)]
+            if best is None or sum(t) < sum(best):
+                best = t
+        n = ns * na * nt0
+        bytes_per = (7 * N * 8 + 8) / nt0 + 8
+        gbs = n * bytes_per / (best[1] * 1e-3) / 1e9
+        leg = dict(workload="%d surfaces x %d alpha x %d theta0, N=%d, NCSX_op wout tables" % (ns, na, nt0, N),
+                   geometry_ms_incl_host_glue=best[0], geometry_points_per_s=ns * na * N / (best[0] * 1e-3),
+                   scan_ms=best[1], scan_solves_per_s=n / (best[1] * 1e-3), argmax_ms=best[2],
+                   mean_sweeps=float((sc["info"] & 0xffff).double().mean().item()),
+                   nonconverged=int(((sc["info"] >> 16) != 0).sum().item()),
+                   roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                                 traffic=None, kernel="k_gamma_scan", bytes_per_solve=bytes_per))
+        if tag == "reference_batch":
+            scan = ibs_amd.BallooningScan(ctx, None, th, svals, nalpha=na, ntheta0=nt0, tables=tabs, device=device)
+            tab = sc["gam"].reshape(ns, na, nt0).cpu().numpy()
+            starts = np.array([ibs_amd.pick_start(t_, scan.alpha_scan, scan.theta0_scan)[:2] for t_ in tab])
+            scan.refine_device(starts)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            xo, fo, ne = scan.refine_device(starts)
+            leg["refine_ms"] = (time.perf_counter() - t1) * 1e3
+            leg["refine_evaluations_per_surface"] = [int(v) for v in ne]
+            leg["gam_coarse_max"] = [float(v) for v in tab.reshape(ns, -1).max(axis=1)]
+            leg["gam_refined"] = [float(-v) for v in fo]
+        out[tag] = leg
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,6 +376,7 @@ def main():
             out["stress_rough"] = stress(ctx, device, max(args.stress_systems // 4, 1024), "rough")
             out["sturm_sweep"] = sturm_sweep(ctx, device, args.stress_systems)
             out["warm_rescan"] = warm_rescan(ctx, device, h, geo7, dP_d, th0_d)
+            out.update(ncsx_pipeline(ctx, device))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
