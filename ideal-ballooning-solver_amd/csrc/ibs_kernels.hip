@@ -233,7 +233,11 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& sr
   const T rm = T(1) / m;
 #pragma unroll
   for (int i = 0; i < M; ++i) x[i] *= rm;                                   // utils.py:1605 (v / max|v|)
-  const int a = WaveSolver<T, M>::rows_start(lane, n);
+  int a = WaveSolver<T, M>::rows_start(lane, n);
+  // The coefficient rows read below were read once already by setup(), at the same LDS addresses: unless the row
+  // index is made opaque here the compiler keeps all those addresses alive (spilled to scratch: 200 VGPRs at
+  // M = 16) across the whole shift iteration instead of recomputing them.
+  asm volatile("" : "+v"(a));
   // xe[k] = X at grid point a + k - 1 (k = 0, 1: the previous lane's last two rows; beyond this lane's rows: the
   // next lane's first two).  The zero end points X[0], X[N-1] (and the clamped X[-1], X[N]) are the DPP fill value.
   const T lastv = hl ? x[M - 1] : x[M - 2], last2 = hl ? x[M - 2] : x[M - 3];
@@ -413,6 +417,7 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   IBS_PROBE_AT(2);
   const long sys = (long)line * n_theta0 + it0c;
   T lam = T(0);
+  // (two inlined copies of the solver: in the cold one the warm-start bookkeeping is compiled out of the loop)
   if (!bad) lam = lam_guess ? ws.solve(inf, true, lam_guess[sys], guess_width) : ws.solve(inf);
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   IBS_PROBE_AT(3);

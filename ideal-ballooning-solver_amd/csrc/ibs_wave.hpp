@@ -344,6 +344,9 @@ struct WaveSolver {
       } else {
         S[i] = T(0); D[i] = T(0); Ph[i] = T(0);
       }
+      // keep the coefficient reads of at most 4 rows in flight (a geometry-fed source reads 7 LDS values per
+      // row: hoisting all of them costs more registers than the kernel has)
+      if ((i & 3) == 3 && i != M - 1) __builtin_amdgcn_sched_barrier(0);
     }
     IBS_PROBE_AT(8);
     kap = sc; ikap = fast_rcp(sc);
@@ -400,8 +403,10 @@ struct WaveSolver {
     return count;
   }
 
-  // backward sweep at shift sig (solution from the right end); fills zw
-  __device__ __forceinline__ void sweep_bwd(T sig) {
+  // backward sweep at shift sig (solution from the right end); fills zw.  Returns the number of sign
+  // changes of the backward solution w_{n-1}, ..., w_0, w_{-1} = the Sturm count (eigenvalues > sig) taken from the
+  // other end of the matrix (the same theorem applied to the reversed index order).
+  __device__ __forceinline__ int sweep_bwd(T sig) {
     T bA = T(1), bAn = T(0), bB = T(0), bBn = T(1);
 #pragma unroll
     for (int i = M - 1; i >= 0; --i) {
@@ -421,14 +426,17 @@ struct WaveSolver {
     Ew = dpp_i<0x130, 0xF>(0, Q.e);
     T wc = wp * kap, wn = wq * ikap;   // (z_{cnt-1}, z_cnt)
     zw_p1 = wn;
+    int count = 0;
 #pragma unroll
     for (int i = M - 1; i >= 0; --i) {
       const T t = xfma(-sig, Ph[i], D[i]);
       const bool act = (i < M - 1) || has_last;
       zw[i] = act ? wc : wn;           // the unused last slot holds z_cnt (needed as "i+1" neighbour)
       const T z2 = xfma(-t, wc, -wn);
+      count += __popcll(__ballot(act && sign_differs(z2, wc)));
       if (act) { wn = wc; wc = z2; }
     }
+    return count;
   }
 
   __device__ __forceinline__ int sweep(T sig) {
@@ -441,7 +449,11 @@ struct WaveSolver {
   // per-lane normalisation (fu, fw, thr) that assemble() uses.
   T fu, fw;
   int thr;
-  __device__ __forceinline__ T twisted(T sig) {
+  __device__ __forceinline__ T twisted(T sig) { return twisted(sig, sig); }
+  // sig = shift of the forward solution (rows <= k), sig_w = shift of the backward solution (rows > k).  With
+  // (T x)_r = sig f_r x_r below k and sig_w f_r x_r above, the Rayleigh quotient of the twisted vector is
+  //   rho = sig + [gamma_k + (sig_w - sig) sum_{r>k} f_r x_r^2] / sum_r f_r x_r^2 ,   gamma_k = [(T - sig F) x]_k.
+  __device__ __forceinline__ T twisted(T sig, T sig_w) {
     // k = argmax |u_k w_k| (= argmin |gamma_k|, discrete Wronskian): per-lane candidate first
     T best = T(0);
     int bi = 0;
@@ -487,15 +499,22 @@ struct WaveSolver {
     fu = xldexp(fast_rcp(S_k * zu_k), du);
     fw = xldexp(fast_rcp(S_k * zw_k), dw);
     thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
-    T acc = T(0);
+    T acc = T(0), acc_w = T(0);
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const T xu = zu[i] * fu, xw = zw[i] * fw;
-      const T x = (i <= thr) ? xu : xw;
-      if ((i < M - 1) || has_last) acc = xfma(Ph[i] * x, x, acc);
+      const bool below = i <= thr;
+      const T x = below ? xu : xw;
+      if ((i < M - 1) || has_last) {
+        acc = xfma(Ph[i] * x, x, acc);
+        acc_w = below ? acc_w : xfma(Ph[i] * x, x, acc_w);
+      }
     }
     const T tot = wave_sum(acc);
-    return sig + gam_k * fast_rcp(tot);
+    const T dsig = sig_w - sig;
+    T corr = T(0);
+    if (U(dsig != T(0))) corr = dsig * wave_sum(acc_w);      // wave-uniform: only the mixed-shift finish pays for it
+    return sig + (gam_k + corr) * fast_rcp(tot);
   }
 
   // eigenvector entries of this lane's rows (twisted, x_k = 1) from the last sweep/twisted() call
