@@ -100,6 +100,113 @@ __device__ __forceinline__ void finish_g(GroupSolver<T, M, P>& ws, const Src& sr
   }
 }
 
+// one grid point of the Simpson sums (utils.py:1618-1619; with WT also the theta0-tangent sums, utils.py:1676-1680)
+template <typename T, class Src, bool WT>
+__device__ __forceinline__ void simpson_point_g(const Src& src, int j, T w, T X, T dX, T& y0, T& y1, T& hc, T& hg, T& hf) {
+  const T X2 = w * (X * X), dX2 = w * (dX * dX);
+  y0 += src.c(j) * X2 - src.g(j) * dX2;
+  y1 = xfma(src.f(j), X2, y1);
+  if constexpr (WT) { hc = xfma(src.c_t(j), X2, hc); hg = xfma(src.g_t(j), dX2, hg); hf = xfma(src.f_t(j), X2, hf); }
+}
+
+// The same stage with the eigenfunction kept in the lanes' row chunks (see finish_chunk in ibs_kernels.hip): the four
+// stencil neighbours beyond a chunk come from the adjacent lanes of the group, every lane sums its own rows, the
+// first and last lane of the group add the end points j = 0, N-1.  X / dX, when requested, go through the group's
+// LDS row afterwards.
+template <typename T, int M, int P, class Src, bool HF>
+__device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const Src& src, int N, T h, T* Xs, T lam,
+                                               int iters, int status, long sys, bool valid, T* lam_out, T* gam_out,
+                                               T* X_out, T* dX_out, T* dth0_out, int* info_out) {
+  static_assert(M >= 3, "the halo exchange takes two rows from each neighbour lane");
+  using GP = Grp<P>;
+  const int lane = ws.lane, lg = ws.lg;
+  const int n = N - 2;
+  const bool hl = ws.has_last, first = lg == 0, last = lg == P - 1;
+  T x[M];
+  ws.assemble(src, N, h, x);
+  T m = T(0);
+#pragma unroll
+  for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
+  m = GP::max(m, lane);
+  const T rm = T(1) / m;
+#pragma unroll
+  for (int i = 0; i < M; ++i) x[i] *= rm;                                   // utils.py:1605
+  int a = GroupSolver<T, M, P>::rows_start(lg, n);
+  asm volatile("" : "+v"(a));   // keep setup()'s addresses from being carried across the iteration (see finish_chunk)
+  const T lastv = hl ? x[M - 1] : x[M - 2], last2 = hl ? x[M - 2] : x[M - 3];
+  // neighbours across the wave; at the ends of a group the zero end points X[0], X[N-1] take their place
+  const T sp1 = dpp_t<0x130, 0xF>(T(0), x[0]), sp2 = dpp_t<0x130, 0xF>(T(0), x[1]);      // wave_shl:1
+  const T sm2 = dpp_t<0x138, 0xF>(T(0), last2), sm1 = dpp_t<0x138, 0xF>(T(0), lastv);    // wave_shr:1
+  const T xp1 = last ? T(0) : sp1, xp2 = last ? T(0) : sp2;
+  T xe[M + 4];
+  xe[0] = first ? T(0) : sm2; xe[1] = first ? T(0) : sm1;
+#pragma unroll
+  for (int i = 0; i < M - 1; ++i) xe[i + 2] = x[i];
+  xe[M + 1] = hl ? x[M - 1] : xp1; xe[M + 2] = hl ? xp1 : xp2; xe[M + 3] = xp2;
+  const T ih = T(1) / h;
+  const T A_in = (T(2) / T(3)) * ih, B_in = -ih / T(12), A_e1 = T(0.5) * ih, A_e0 = T(2) * ih, B_e0 = T(-0.5) * ih;
+  bool do_hf = false;
+  if constexpr (HF) do_hf = dth0_out != nullptr;
+  T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
+  const T w_even = ((a + 1) & 1) ? T(4) : T(2), w_odd = ((a + 1) & 1) ? T(2) : T(4);
+  const int i_end = last ? (hl ? M - 1 : M - 2) : -1;
+  auto all_points = [&](auto with_tangent) {
+    constexpr bool WT = HF && decltype(with_tangent)::value;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const bool act = (i < M - 1) || hl;
+      const bool e1 = (i == 0 && first) || (i == i_end);               // j = 1, N-2: utils.py:1611, 1613
+      const T A = e1 ? A_e1 : A_in, B = e1 ? T(0) : B_in;
+      const T dX = xfma(A, xe[i + 3] - xe[i + 1], B * (xe[i + 4] - xe[i]));   // utils.py:1616
+      const T w = act ? ((i & 1) ? w_odd : w_even) : T(0);
+      simpson_point_g<T, Src, WT>(src, a + i + 1, w, xe[i + 2], dX, y0, y1, hc, hg, hf);
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (first || last) {                                               // j = 0, N-1: utils.py:1610, 1614
+      const T d1 = first ? x[0] : -lastv, d2 = first ? x[1] : -last2;
+      simpson_point_g<T, Src, WT>(src, first ? 0 : N - 1, T(1), T(0), xfma(A_e0, d1, B_e0 * d2), y0, y1, hc, hg, hf);
+    }
+  };
+  if constexpr (HF) {
+    if (do_hf) all_points(std::true_type{});
+    else all_points(std::false_type{});
+  } else {
+    all_points(std::false_type{});
+  }
+  y0 = GP::sum(y0, lane); y1 = GP::sum(y1, lane);
+  const T gam = y0 / y1;                                               // utils.py:1621
+  if constexpr (HF) {
+    if (do_hf) {
+      hc = GP::sum(hc, lane); hg = GP::sum(hg, lane); hf = GP::sum(hf, lane);
+      const T jac = hc / y1 - hg / y1 - gam * hf / y1;                 // utils.py:1676-1680
+      if (first && valid) dth0_out[sys] = jac;
+    }
+  }
+  if (first && valid) {
+    if (lam_out) lam_out[sys] = lam;
+    if (gam_out) gam_out[sys] = gam;
+    if (info_out) info_out[sys] = iters | (status << 16);
+  }
+  if (X_out || dX_out) {                   // kernel-uniform
+    for (int pass = 0; pass < 2; ++pass) {
+      T* out = pass ? dX_out : X_out;
+      if (!out) continue;
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const bool e1 = (i == 0 && first) || (i == i_end);
+        const T A = e1 ? A_e1 : A_in, B = e1 ? T(0) : B_in;
+        const T v = pass ? xfma(A, xe[i + 3] - xe[i + 1], B * (xe[i + 4] - xe[i])) : xe[i + 2];
+        if ((i < M - 1) || hl) Xs[lpos(a + i + 1)] = v;
+      }
+      if (first) Xs[lpos(0)] = pass ? xfma(A_e0, x[0], B_e0 * x[1]) : T(0);
+      if (last) Xs[lpos(N - 1)] = pass ? xfma(A_e0, -lastv, B_e0 * (-last2)) : T(0);
+      wave_lds_sync();
+      if (valid) for (int j = lg; j < N; j += P) out[sys * N + j] = Xs[lpos(j)];
+    }
+  }
+}
+
 // raw (g, c, f): wave w of block b solves systems (b*wpb + w)*G .. +G-1; dynamic LDS = wpb * G * lds_pitch(N) * sizeof(T) (X only)
 // (2 waves per SIMD: the shift iteration keeps ~210 VGPRs live.  Forcing 3 waves (168 VGPRs) spills 45 of them:
 //  6 % faster (9.6e7 vs 9.0e7 solves/s) but the scratch traffic doubles the HBM bytes per launch (8.1 vs 4.3 GB
@@ -123,7 +230,7 @@ __global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, 
   const bool bad = ws.setup(src, N, h);
   int iters = 0, status = 0;
   const T lam = ws.solve(bad, iters, status);
-  finish_g<T, M, P, SrcGlobal<T>, false>(ws, src, N, h, Xs, lam, iters, status, sysc, valid, lam_out, gam_out, X_out,
+  finish_chunk_g<T, M, P, SrcGlobal<T>, false>(ws, src, N, h, Xs, lam, iters, status, sysc, valid, lam_out, gam_out, X_out,
                                          dX_out, nullptr, info_out);
 }
 
@@ -176,7 +283,7 @@ __global__ void __launch_bounds__(scan_max_threads_g(M), 2) k_gamma_scan_g(
   int iters = 0, status = 0;
   const T lam = ws.solve(bad, iters, status);
   const long sys = (long)line * n_theta0 + it0c;
-  finish_g<T, M, P, SrcGeoG<T>, true>(ws, src, N, h, Xs, lam, iters, status, sys, valid, lam_out, gam_out, X_out,
+  finish_chunk_g<T, M, P, SrcGeoG<T>, true>(ws, src, N, h, Xs, lam, iters, status, sys, valid, lam_out, gam_out, X_out,
                                       dX_out, dth0_out, info_out);
 }
 
