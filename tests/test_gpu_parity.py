@@ -343,12 +343,12 @@ def test_large_grid_2049(ctx, bo):
 
 
 def test_full_size_stress_properties(ctx):
-    """BASELINE config 5 at scale (2^17 systems, N_zeta = 512), checked through size-independent properties:
+    """BASELINE config 5 at its full size (10^6 systems, N_zeta = 512), checked through size-independent properties:
     the Sturm count is 0 just above the returned eigenvalue and exactly 1 just below it; lam is invariant
     under a common scaling of (g, c) and shifts by s under c -> c + s f."""
     import torch
     dev = torch.device("cuda:0")
-    n, N = 1 << 17, 513
+    n, N = 1000000, 513
     gen = torch.Generator(device=dev); gen.manual_seed(5)
     u = lambda lo, hi, shape: lo + (hi - lo) * torch.rand(shape, dtype=torch.float64, device=dev, generator=gen)
     g = torch.exp(u(np.log(0.01), np.log(50.0), (n, N)))
@@ -375,6 +375,39 @@ def test_full_size_stress_properties(ctx):
     assert float((below == 1).double().mean()) > 0.999          # near-degenerate pairs are allowed but rare
     r2 = ctx.solve_gcf(h, 2 * g[:4096], 2 * c[:4096] + 0.25 * 2 * f[:4096], 2 * f[:4096])
     assert float(((r2["lam"] - (lam[:4096] + 0.25)).abs() / normA[:4096]).max()) < 3e-13   # inside the certified brackets
+
+
+def test_config3_full_size_from_wout_tables(ctx, bo):
+    """BASELINE config 3 at its full single-GPU size (64 surfaces x 32 alpha x 16 theta0 = 32,768 solves, N_zeta = 1024)
+    from the shipped equilibrium's wout tables, geometry on the device: a random sample of lines against the C
+    oracle, no system flagged, and the result of a line does not depend on where it sits in the batch (the same
+    lines in reversed order give bitwise the same growth rates)."""
+    import ibs_amd
+    import torch
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    ns, na, nt0, N = 64, 32, 16, 1025
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, np.linspace(0.1, 0.95, ns))
+    th = bo.theta_grid(N)
+    surf = np.repeat(np.arange(ns), na); al = np.tile(np.linspace(0, np.pi, na), ns)
+    r = ctx.fieldline_geometry(tabs, surf, al, th, device=dev)
+    t0 = np.linspace(0, np.pi / 2, nt0)
+    t0d = torch.from_numpy(t0).to(dev)
+    h = th[1] - th[0]
+    sc = ctx.gamma_scan(h, *[r["geo"][k] for k in range(7)], r["dPdrho"], t0d, want_info=True)
+    assert int(((sc["info"] >> 16) != 0).sum()) == 0
+    rev = torch.arange(ns * na - 1, -1, -1, device=dev)
+    sc_r = ctx.gamma_scan(h, *[r["geo"][k][rev].contiguous() for k in range(7)], r["dPdrho"][rev].contiguous(), t0d)
+    assert bool((sc_r["gam"][rev] == sc["gam"]).all()) and bool((sc_r["lam"][rev] == sc["lam"]).all())
+    pick = np.random.default_rng(3).choice(ns * na, size=48, replace=False)
+    geo_h = r["geo"][:, torch.from_numpy(pick).to(dev)].cpu().numpy()
+    gam_c, lam_c, _ = co.gamma_scan(h, *[np.ascontiguousarray(geo_h[k]) for k in range(7)],
+                                    r["dPdrho"].cpu().numpy()[pick], t0)
+    assert np.abs(sc["gam"].cpu().numpy()[pick] - gam_c).max() < TOL
+    assert np.abs(sc["lam"].cpu().numpy()[pick] - lam_c).max() < TOL
+    idx, val = ctx.surface_argmax(sc["gam"].reshape(ns, -1))
+    assert np.array_equal(idx.cpu().numpy(), sc["gam"].reshape(ns, -1).argmax(dim=1).cpu().numpy())
 
 
 def test_config3_shape_ncsx_1025_tiled(ctx, bo):

@@ -9,7 +9,9 @@
 using namespace ibs;
 namespace ibs { LaunchTable& launch_table() { static LaunchTable t{}; return t; } }
 int main(int argc, char** argv) {
-  const int nl = 128, nt = 8, N = 513; const double h = 8 * M_PI / (N - 1);
+  // usage: pp geo.bin [wpb [N nl nt]]   (defaults: the bench step, N = 513, 128 lines x 8 theta0)
+  const int N = argc > 3 ? atoi(argv[3]) : 513, nl = argc > 4 ? atoi(argv[4]) : 128, nt = argc > 5 ? atoi(argv[5]) : 8;
+  const double h = 8 * M_PI / (N - 1);
   std::vector<double> buf(7 * nl * N + nl + nt);
   FILE* fp = fopen(argv[1], "rb"); if (!fp || fread(buf.data(), 8, buf.size(), fp) != buf.size()) { printf("bad input\n"); return 1; }
   double* d; hipMalloc(&d, buf.size() * 8); hipMemcpy(d, buf.data(), buf.size() * 8, hipMemcpyHostToDevice);
