@@ -445,7 +445,17 @@ hipError_t launch_geometry(const GeoArgs& a, hipStream_t st) {
     // slower at every shape tried (128 x 513: 120 / 144 / 135 us; 2048 x 1025: 1.74 / 2.17 / 2.71 ms): each
     // block stages its own 68 KB of tables and only two blocks fit a CU, so more, smaller blocks do not shorten
     // the critical path.  Kept as an experiment switch only.
-    int lpp = 1;
+    // ... except for batches that leave most of the chip idle (the refinement rounds of ibs_refine_f64: 3 lines per
+    // point): there the launch is the latency of one thread's ~630 modes, and splitting a point over 4 (2) lanes
+    // shortens it (5 surfaces, N = 969: 3.3 -> 2.2 ms for the whole refinement).  IBS_GEO_LPP=1|2|4 overrides.
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+      else n_cu = 256;
+    }
+    const long blocks1 = (long)((a.N + kGeoBlock - 1) / kGeoBlock) * a.n_lines;
+    int lpp = blocks1 * 4 <= n_cu ? 4 : (blocks1 * 2 <= n_cu ? 2 : 1);
     if (const char* e = getenv("IBS_GEO_LPP")) lpp = atoi(e);
     auto go = [&](auto kern, int l) {
       hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

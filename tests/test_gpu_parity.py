@@ -514,6 +514,30 @@ def test_F1_fieldline_geometry_kernel(ctx, bo):
     assert np.abs(sc["gam"].cpu().numpy() - g3["gam_513"]).max() < TOL
 
 
+def test_F1_geometry_lanes_per_point_variants_agree(ctx, bo, monkeypatch):
+    """small batches split a grid point over 2 / 4 lanes (latency of the refinement rounds): same arrays as the
+    one-lane-per-point kernel up to the summation order"""
+    import ibs_amd
+    import torch
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, [0.5, 0.8])
+    th = bo.theta_grid(969)
+    surf = [0, 0, 1, 1, 1]; al = [0.0, 1.3, 0.4, 2.0, np.pi]
+    out = {}
+    for lpp in ("1", "2", "4"):
+        monkeypatch.setenv("IBS_GEO_LPP", lpp)
+        r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))
+        out[lpp] = (r["geo"].cpu().numpy(), r["dPdrho"].cpu().numpy())
+    monkeypatch.delenv("IBS_GEO_LPP")
+    r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))     # automatic choice (4 here)
+    auto = r["geo"].cpu().numpy()
+    scale = np.abs(out["1"][0]).max(axis=2, keepdims=True)
+    for lpp in ("2", "4"):
+        assert (np.abs(out[lpp][0] - out["1"][0]) / scale).max() < 1e-12
+        assert np.abs(out[lpp][1] - out["1"][1]).max() < 1e-12 * np.abs(out["1"][1]).max()
+    assert (np.abs(auto - out["1"][0]) / scale).max() < 1e-12
+
+
 def test_driver_with_device_geometry_reproduces_reference_scan(ctx, bo):
     """ball_scan.py:248-295 on one NCSX_op surface with the geometry produced on the GPU: the coarse
     24 x 15 table and its argmax against the reference trace (G5), then a refinement step."""
