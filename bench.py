@@ -220,13 +220,12 @@ def ncsx_pipeline(ctx, device):
     own batch (5 surfaces x 24 x 15, N=969) with its refinement (ball_scan.py:305-339) on the device (row F2)."""
     import torch
     import ibs_amd
-    from oracle import ballooning_oracle as bo          # theta grid helper only (A0)
     wout = dict(np.load(os.path.join(ROOT, "tests", "golden", "G8_wout_ncsx_op.npz")))
     out = {}
     for tag, ns, na, nt0, N, svals in (("ncsx_c3", 64, 32, 16, 1025, np.linspace(0.1, 0.95, 64)),
                                        ("reference_batch", 5, 24, 15, 969, np.linspace(0.5, 0.95, 5))):
         tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
-        th = bo.theta_grid(N)
+        th = ibs_amd.theta_grid(N)
         alphas = np.linspace(0, np.pi, na)
         t0 = torch.from_numpy(np.linspace(0, np.pi / 2, nt0)).to(device)
         surf = np.repeat(np.arange(ns), na); al = np.tile(alphas, ns)

@@ -83,3 +83,8 @@ def make_obj_w_grad(fieldlines, ctx=None, del_alpha=0.004):
         val, jac = c.obj_w_grad(uniform_spacing(theta), geo[None], np.array([theta0_val]), del_alpha)
         return float(val[0]), np.asarray(jac[0], dtype=np.float64)
     return obj_w_grad
+
+
+def theta_grid(N, theta_fac=4):
+    """the theta_PEST grid of ball_scan.py:201-209: N points on [-theta_fac pi, theta_fac pi]"""
+    return np.linspace(-theta_fac * np.pi, theta_fac * np.pi, int(N))

@@ -1,6 +1,6 @@
 """max relative deviation of the device geometry (rows kernel) from the reference's arrays (G3) per quantity"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, ibs_amd
 from oracle import ballooning_oracle as bo
 G = os.path.join(ROOT, "tests", "golden")

@@ -1,6 +1,6 @@
 """one-off parity campaign: many perturbed NCSX-like lines x theta0 values, GPU scan vs the C oracle"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch, ibs_amd
 from oracle import c_oracle as co
 dev = torch.device("cuda", 0); ctx = ibs_amd.Context(0)

@@ -3,11 +3,10 @@ equilibria vs scan warm-started from the base equilibrium's eigenvalues (ibs_gam
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, ibs_amd
-from oracle import ballooning_oracle as bo
 ctx = ibs_amd.Context(0); dev = torch.device("cuda", 0)
 wout = dict(np.load(os.path.join(ROOT, "tests/golden/G8_wout_ncsx_op.npz")))
 n_eq, ns, na, nt0, N = 73, 5, 24, 15, 969
-svals = np.linspace(0.5, 0.95, ns); th = bo.theta_grid(N); alphas = np.linspace(0, np.pi, na)
+svals = np.linspace(0.5, 0.95, ns); th = ibs_amd.theta_grid(N); alphas = np.linspace(0, np.pi, na)
 t0 = torch.from_numpy(np.linspace(0, np.pi / 2, nt0)).to(dev)
 tabs_all = []
 for q in range(n_eq):

@@ -2,7 +2,6 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, ibs_amd
-from oracle import ballooning_oracle as bo
 ctx = ibs_amd.Context(0); dev = torch.device('cuda', 0)
 wout = dict(np.load(os.path.join(ROOT, 'tests/golden/G8_wout_ncsx_op.npz')))
 for name, ns, na, nt0, N in (("reference batch (5 surfaces x 24 alpha x 15 theta0, N=969)", 5, 24, 15, 969),
@@ -10,7 +9,7 @@ for name, ns, na, nt0, N in (("reference batch (5 surfaces x 24 alpha x 15 theta
                              ("config 3 (64 x 32 x 16, N=1025)", 64, 32, 16, 1025)):
     svals = np.linspace(0.5, 0.95, ns) if ns <= 16 else np.linspace(0.1, 0.95, ns)
     t = time.time(); tabs = ibs_amd.SurfaceTables.from_wout(wout, svals); t_spl = time.time() - t
-    th = bo.theta_grid(N); alphas = np.linspace(0, np.pi, na); t0 = torch.from_numpy(np.linspace(0, np.pi / 2, nt0)).to(dev)
+    th = ibs_amd.theta_grid(N); alphas = np.linspace(0, np.pi, na); t0 = torch.from_numpy(np.linspace(0, np.pi / 2, nt0)).to(dev)
     surf = np.repeat(np.arange(ns), na); al = np.tile(alphas, ns)
     for rep in range(2):
         torch.cuda.synchronize(); e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -26,7 +25,7 @@ for name, ns, na, nt0, N in (("reference batch (5 surfaces x 24 alpha x 15 theta
 
 # config 4 shape: one FD-gradient step of the optimizer = 73 equilibria x 5 surfaces x 24 alpha x 15 theta0, N = 969
 n_eq, ns, na, nt0, N = 73, 5, 24, 15, 969
-svals = np.linspace(0.5, 0.95, ns); th = bo.theta_grid(N); alphas = np.linspace(0, np.pi, na)
+svals = np.linspace(0.5, 0.95, ns); th = ibs_amd.theta_grid(N); alphas = np.linspace(0, np.pi, na)
 t0 = torch.from_numpy(np.linspace(0, np.pi / 2, nt0)).to(dev)
 t = time.time()
 tabs_all = []

@@ -2,13 +2,12 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, ibs_amd
-from oracle import ballooning_oracle as bo
 ctx = ibs_amd.Context(0); dev = torch.device("cuda", 0)
 wout = dict(np.load(os.path.join(ROOT, "tests/golden/G8_wout_ncsx_op.npz")))
 for ns, N in ((5, 969), (16, 513), (64, 1025)):
     svals = np.linspace(0.5, 0.95, ns) if ns <= 16 else np.linspace(0.1, 0.95, ns)
     tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
-    th = bo.theta_grid(N)
+    th = ibs_amd.theta_grid(N)
     scan = ibs_amd.BallooningScan(ctx, None, th, svals, tables=tabs, device=dev)
     tabs_c = scan.coarse()
     starts = np.array([ibs_amd.pick_start(t, scan.alpha_scan, scan.theta0_scan)[:2] for t in tabs_c])

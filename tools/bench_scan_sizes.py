@@ -2,10 +2,9 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, ibs_amd
-from oracle import ballooning_oracle as bo
 dev = torch.device("cuda", 0); ctx = ibs_amd.Context(0)
 g3 = np.load(os.path.join(ROOT, "tests", "golden", "G3_ncsx_lines.npz")); geo = g3["geo_513"]
-th = bo.theta_grid(513)
+th = ibs_amd.theta_grid(513)
 for n_surf, n_alpha, n_t0 in ((16, 8, 8), (32, 8, 8), (64, 8, 8), (64, 16, 8), (64, 32, 16), (256, 32, 16)):
     nl = n_surf * n_alpha
     rng = np.random.default_rng(3)

@@ -25,11 +25,10 @@ print("sturm", w["sweeps_per_s"], flush=True)
 
 # F1 geometry kernel: 2,048 lines x 1,025 points (3 launches)
 import numpy as np  # noqa: E402
-from oracle import ballooning_oracle as bo  # noqa: E402
 wout = dict(np.load(os.path.join(ROOT, "tests", "golden", "G8_wout_ncsx_op.npz")))
 tabs = ibs_amd.SurfaceTables.from_wout(wout, np.linspace(0.3, 0.95, 64))
 surf = np.repeat(np.arange(64), 32); al = np.tile(np.linspace(0, np.pi, 32), 64)
 for _ in range(3):
-    ctx.fieldline_geometry(tabs, surf, al, bo.theta_grid(1025), device=dev)
+    ctx.fieldline_geometry(tabs, surf, al, ibs_amd.theta_grid(1025), device=dev)
 torch.cuda.synchronize()
 print("geometry done", flush=True)
