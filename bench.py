@@ -285,7 +285,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    force_dist = os.environ.get("IBS_BENCH_FORCE_DIST") == "1"   # rehearsal of the N > 1 path with a 1-rank RCCL group
+    if args.gpus > 1 or world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         torch.cuda.set_device(local)
@@ -298,16 +299,20 @@ def main():
     plan = ibs_amd.ScanPlan(ctx, h, geo7, dP_d, th0_d, N_SURF)
     n_solves = N_SURF * N_ALPHA * N_THETA0
     use_dist = dist.is_available() and dist.is_initialized()
+    # N > 1: the per-surface maxima of every step are all-gathered in-stream (replaces comm_lead.Gather x3,
+    # ball_scan.py:345-347; 256 B per rank, latency-bound).  Overlapping the collective with the next scan on a side
+    # stream was measured (1-rank RCCL group, IBS_BENCH_FORCE_DIST=1): the two event dependencies per step cost more
+    # stream time on this platform (60 us per step) than the collective they hide (39 us in-stream vs 30 us without).
     gathered = torch.empty((world, N_SURF, 2), dtype=torch.float64, device=device) if use_dist else None
 
-    def step(ev=None):
+    def step(k=0, ev=None):
         if ev is not None:
             ev[0].record()
         plan.scan()
         if ev is not None:
             ev[1].record()
         plan.argmax()
-        if use_dist:        # replaces comm_lead.Gather x3 (ball_scan.py:345-347): (lam_max, flat index) per surface
+        if use_dist:
             dist.all_gather_into_tensor(gathered, plan.pack)
 
     def fence():
@@ -315,8 +320,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
     # the dominant kernel is timed live with HIP events inside the timed region, on every 8th step (an event
     # pair costs ~6 us of stream time, more than the per-surface argmax kernel: bracketing every step would
@@ -326,7 +331,7 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(evs[k // EV] if k % EV == 0 else None)
+        step(k, evs[k // EV] if k % EV == 0 else None)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -334,6 +339,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    if use_dist:      # every rank holds every rank's maxima of the last step; its own row must be what it sent
+        assert torch.equal(gathered[rank], plan.pack), "all-gather result does not match the local maxima"
     info = plan.info.cpu().numpy()
     nbad = int(((info >> 16) != 0).sum())
     sweeps = float((info & 0xffff).mean())
@@ -352,7 +359,7 @@ def main():
             "dtype": "f64", "data": "synthetic (NCSX_op-derived field-line geometry, perturbed per line)",
             "config": {"workload": "configs[1] D3D-shape: 16 surfaces x 8 alpha x 8 theta0 = 1024 solves/step/GPU, "
                                    "N_zeta=512 (513 points), geometry-fed scan + per-surface argmax"
-                                   + (" + RCCL all-gather" if use_dist else ""),
+                                   + (" + RCCL all-gather of the per-surface maxima" if use_dist else ""),
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
                        "nonconverged": nbad},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

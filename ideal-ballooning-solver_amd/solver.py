@@ -336,7 +336,10 @@ class ScanPlan:
         self.lam = torch.empty((n_lines, n_t0), dtype=t64, device=dev)
         self.dth0 = torch.empty((n_lines, n_t0), dtype=t64, device=dev) if want_dtheta0 else None
         self.info = torch.empty((n_lines, n_t0), dtype=torch.int32, device=dev)
-        self.pack = torch.empty((n_surf, 2), dtype=t64, device=dev)      # (lam_max, flat index) per surface
+        # (lam_max, flat index) per surface; two buffers so that the all-gather of one step can still be reading its
+        # buffer while the next step's argmax writes the other one (argmax(slot))
+        self.packs = [torch.empty((n_surf, 2), dtype=t64, device=dev) for _ in range(2)]
+        self.pack = self.packs[0]
         self.best_val = self.pack[:, 0]
         self.best_idx = self.pack[:, 1]
         ctx._stream_from_torch(self.geo[0])
@@ -344,15 +347,15 @@ class ScanPlan:
         self._scan_args = (ctx._h, n_lines, n_t0, N, float(h), *[p(g) for g in self.geo], N, p(self.dP), p(self.t0),
                            p(self.gam), p(self.lam), C.c_void_p(None), C.c_void_p(None), p(self.dth0), p(self.info),
                            MEM_DEVICE)
-        self._amax_args = (ctx._h, n_surf, (n_lines // n_surf) * n_t0, p(self.gam), p(self.pack))
+        self._amax_args = [(ctx._h, n_surf, (n_lines // n_surf) * n_t0, p(self.gam), p(pk)) for pk in self.packs]
 
     def scan(self):
         rc = self.lib.ibs_gamma_scan_f64(*self._scan_args)
         if rc < 0:
             check(rc, "ibs_gamma_scan_f64")
 
-    def argmax(self):
-        rc = self.lib.ibs_surface_argmax_pack_f64(*self._amax_args)
+    def argmax(self, slot=0):
+        rc = self.lib.ibs_surface_argmax_pack_f64(*self._amax_args[slot])
         if rc < 0:
             check(rc, "ibs_surface_argmax_pack_f64")
 
