@@ -390,6 +390,14 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   const int P = lds_pitch(N);
   T* A1 = smem; T* A3 = A1 + P; T* C0 = A3 + P; T* C1 = C0 + P; T* G0 = C1 + P; T* G1 = G0 + P; T* G2 = G1 + P;
   T* Xs = G2 + P + (size_t)wave * P;
+  // this wave's theta0 (and warm-start guess): requested before the staging loads so that their latency is
+  // covered by the geometry's instead of following the block barrier
+  const int it0 = part * wpb + wave;
+  const bool valid = it0 < n_theta0;
+  const int it0c = valid ? it0 : (n_theta0 - 1);
+  const T th0 = theta0[it0c];
+  const long sys = (long)line * n_theta0 + it0c;
+  const T guess = lam_guess ? lam_guess[sys] : T(0);
   {
     const long off = (long)line * ld;
     const T mdP = -dPdrho[line];
@@ -406,19 +414,14 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   }
   __syncthreads();
   IBS_PROBE_AT(1);
-  const int it0 = part * wpb + wave;
-  const bool valid = it0 < n_theta0;
-  const int it0c = valid ? it0 : (n_theta0 - 1);
-  const T th0 = theta0[it0c];
   SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
   const bool bad = ws.setup(src, N, h);
   IBS_PROBE_AT(2);
-  const long sys = (long)line * n_theta0 + it0c;
   T lam = T(0);
   // (two inlined copies of the solver: in the cold one the warm-start bookkeeping is compiled out of the loop)
-  if (!bad) lam = lam_guess ? ws.solve(inf, true, lam_guess[sys], guess_width) : ws.solve(inf);
+  if (!bad) lam = lam_guess ? ws.solve(inf, true, guess, guess_width) : ws.solve(inf);
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   IBS_PROBE_AT(3);
   if constexpr (M >= 3) {
