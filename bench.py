@@ -302,7 +302,8 @@ def main():
     # N > 1: the per-surface maxima of every step are all-gathered in-stream (replaces comm_lead.Gather x3,
     # ball_scan.py:345-347; 256 B per rank, latency-bound).  Overlapping the collective with the next scan on a side
     # stream was measured (1-rank RCCL group, IBS_BENCH_FORCE_DIST=1): the two event dependencies per step cost more
-    # stream time on this platform (60 us per step) than the collective they hide (39 us in-stream vs 30 us without).
+    # stream time on this platform (60 us per step) than the collective they hide (39 us in-stream vs 30 us without);
+    # async_op=True from a ring of buffers is host-bound in torch's Work bookkeeping (56 us per step).
     gathered = torch.empty((world, N_SURF, 2), dtype=torch.float64, device=device) if use_dist else None
 
     def step(k=0, ev=None):

@@ -318,7 +318,7 @@ class ScanPlan:
     .best_idx (n_surf,) -- index into the flattened (alpha, theta0) table of the surface; both are views of
     .pack (n_surf, 2) float64, the buffer the per-surface all-gather sends."""
 
-    def __init__(self, ctx, h, geo7, dPdrho, theta0, n_surf, want_dtheta0=False):
+    def __init__(self, ctx, h, geo7, dPdrho, theta0, n_surf, want_dtheta0=False, n_pack=2):
         import torch
         self.ctx = ctx
         self.lib = ctx._lib
@@ -336,9 +336,9 @@ class ScanPlan:
         self.lam = torch.empty((n_lines, n_t0), dtype=t64, device=dev)
         self.dth0 = torch.empty((n_lines, n_t0), dtype=t64, device=dev) if want_dtheta0 else None
         self.info = torch.empty((n_lines, n_t0), dtype=torch.int32, device=dev)
-        # (lam_max, flat index) per surface; two buffers so that the all-gather of one step can still be reading its
-        # buffer while the next step's argmax writes the other one (argmax(slot))
-        self.packs = [torch.empty((n_surf, 2), dtype=t64, device=dev) for _ in range(2)]
+        # (lam_max, flat index) per surface; n_pack buffers so that the all-gather of one step can still be reading its
+        # buffer while later steps' argmax write the others (argmax(slot))
+        self.packs = [torch.empty((n_surf, 2), dtype=t64, device=dev) for _ in range(max(1, int(n_pack)))]
         self.pack = self.packs[0]
         self.best_val = self.pack[:, 0]
         self.best_idx = self.pack[:, 1]
