@@ -57,6 +57,19 @@ def pmc_kernel_name(kernel_prefix, default):
     return default
 
 
+def valu_issue_frac(kernel_prefix, n_sys, ms):
+    """wave64 VALU instructions per second of a launch (instruction count per system from the committed PMC pass of
+    the same workload) against the chip's issue peak: 256 CUs x 4 SIMDs x one instruction per 4 clocks at 2.4 GHz"""
+    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
+    if not os.path.exists(fn):
+        return None
+    for k, v in json.load(open(fn)).items():
+        if k.startswith(kernel_prefix) and "SQ_INSTS_VALU" in v:
+            per_launch = v["SQ_INSTS_VALU"]["mean"]          # the PMC pass ran the same 262,144-system launch
+            return per_launch / (ms * 1e-3) / (256 * 4 * 2.4e9 / 4)
+    return None
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 N_SURF, N_ALPHA, N_THETA0, NPTS = 16, 8, 8, 513
 
@@ -153,7 +166,8 @@ def stress(ctx, device, n_sys, family, reps=3):
                 roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
                               traffic=(pmc_traffic("ibs::k_solve_gcf") if n_sys == 262144 and family == "smooth"
                                        else None),
-                              kernel=pmc_kernel_name("ibs::k_solve_gcf", "k_solve_gcf"), bytes_per_solve=bytes_per))
+                              kernel=pmc_kernel_name("ibs::k_solve_gcf", "k_solve_gcf"), bytes_per_solve=bytes_per,
+                              valu_issue_frac=valu_issue_frac("ibs::k_solve_gcf", n_sys, ms) if family == "smooth" and n_sys == 262144 else None))
 
 
 def sturm_sweep(ctx, device, n_sys, reps=5):
@@ -373,6 +387,14 @@ def main():
                          "valu_busy_frac": pmc_value("ibs::k_gamma_scan<double", "valu_busy_frac_of_wave_lifetime"),
                          "note": "FP64-VALU-issue bound, not HBM bound: see DESIGN.md"},
         }
+        # the bound that does bind: wave64 VALU instructions issued per second against one instruction per SIMD per
+        # 4 clocks (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz), instruction count from the committed PMC pass
+        vi = pmc_value("ibs::k_gamma_scan<double", "valu_insts_per_wave")
+        if vi:
+            peak_issue = 256 * 4 * 2.4e9 / 4
+            ach = vi * n_solves / (kern_ms * 1e-3)
+            out["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak_issue, "unit": "wave-instructions/s",
+                                             "frac": ach / peak_issue}
         if world == 1 and not args.no_cpu:
             cb, gam_cpu = cpu_baseline(h, base, dP, theta0)
             out["cpu_baseline"] = cb
