@@ -344,9 +344,6 @@ struct WaveSolver {
       } else {
         S[i] = T(0); D[i] = T(0); Ph[i] = T(0);
       }
-      // keep the coefficient reads of at most 4 rows in flight (a geometry-fed source reads 7 LDS values per
-      // row: hoisting all of them costs more registers than the kernel has)
-      if ((i & 3) == 3 && i != M - 1) __builtin_amdgcn_sched_barrier(0);
     }
     IBS_PROBE_AT(8);
     kap = sc; ikap = fast_rcp(sc);
