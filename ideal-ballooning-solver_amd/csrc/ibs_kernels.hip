@@ -255,7 +255,12 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& sr
   T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
   const T w_even = ((a + 1) & 1) ? T(4) : T(2), w_odd = ((a + 1) & 1) ? T(2) : T(4);   // Simpson weight of slot i
   const int i_end = (lane == kWave - 1) ? (hl ? M - 1 : M - 2) : -1;                   // slot of grid point N-2
+  // one-sided dX of the two end points (utils.py:1610, 1614), formed now so that the rows it needs are not kept
+  // alive across the row loop
+  const T dX_end = xfma(A_e0, lane == 0 ? x[0] : -lastv, B_e0 * (lane == 0 ? x[1] : -last2));
   auto all_points = [&](auto with_tangent) {
+    if (lane == 0 || lane == kWave - 1)                                                // j = 0, N-1
+      simpson_point<T, Src, HF && decltype(with_tangent)::value>(src, lane == 0 ? 0 : N - 1, T(1), T(0), dX_end, y0, y1, hc, hg, hf);
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const bool act = (i < M - 1) || hl;
@@ -265,11 +270,6 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& sr
       const T w = act ? ((i & 1) ? w_odd : w_even) : T(0);
       simpson_point<T, Src, HF && decltype(with_tangent)::value>(src, a + i + 1, w, xe[i + 2], dX, y0, y1, hc, hg, hf);
       if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most 4 rows of LDS reads in flight (registers)
-    }
-    if (lane == 0 || lane == kWave - 1) {                                              // j = 0, N-1: utils.py:1610, 1614
-      const bool first = lane == 0;
-      const T d1 = first ? x[0] : -lastv, d2 = first ? x[1] : -last2;
-      simpson_point<T, Src, HF && decltype(with_tangent)::value>(src, first ? 0 : N - 1, T(1), T(0), xfma(A_e0, d1, B_e0 * d2), y0, y1, hc, hg, hf);
     }
   };
   if constexpr (HF) {
@@ -305,8 +305,8 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& sr
         const T v = pass ? xfma(A, xe[i + 3] - xe[i + 1], B * (xe[i + 4] - xe[i])) : xe[i + 2];
         if ((i < M - 1) || hl) Xs[lpos(a + i + 1)] = v;
       }
-      if (lane == 0) Xs[lpos(0)] = pass ? xfma(A_e0, x[0], B_e0 * x[1]) : T(0);                 // utils.py:1607, 1610
-      if (lane == kWave - 1) Xs[lpos(N - 1)] = pass ? xfma(A_e0, -lastv, B_e0 * (-last2)) : T(0);   // utils.py:1608, 1614
+      if (lane == 0) Xs[lpos(0)] = pass ? dX_end : T(0);                                        // utils.py:1607, 1610
+      if (lane == kWave - 1) Xs[lpos(N - 1)] = pass ? dX_end : T(0);                            // utils.py:1608, 1614
       wave_lds_sync();
       for (int j = lane; j < N; j += kWave) out[sys * N + j] = Xs[lpos(j)];
     }

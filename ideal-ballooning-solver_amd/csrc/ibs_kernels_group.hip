@@ -150,8 +150,12 @@ __device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const S
   T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
   const T w_even = ((a + 1) & 1) ? T(4) : T(2), w_odd = ((a + 1) & 1) ? T(2) : T(4);
   const int i_end = last ? (hl ? M - 1 : M - 2) : -1;
+  // one-sided dX of the two end points, formed now so that the rows it needs are not kept alive across the row loop
+  const T dX_end = xfma(A_e0, first ? x[0] : -lastv, B_e0 * (first ? x[1] : -last2));
   auto all_points = [&](auto with_tangent) {
     constexpr bool WT = HF && decltype(with_tangent)::value;
+    if (first || last)                                                 // j = 0, N-1: utils.py:1610, 1614
+      simpson_point_g<T, Src, WT>(src, first ? 0 : N - 1, T(1), T(0), dX_end, y0, y1, hc, hg, hf);
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const bool act = (i < M - 1) || hl;
@@ -161,10 +165,6 @@ __device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const S
       const T w = act ? ((i & 1) ? w_odd : w_even) : T(0);
       simpson_point_g<T, Src, WT>(src, a + i + 1, w, xe[i + 2], dX, y0, y1, hc, hg, hf);
       if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (first || last) {                                               // j = 0, N-1: utils.py:1610, 1614
-      const T d1 = first ? x[0] : -lastv, d2 = first ? x[1] : -last2;
-      simpson_point_g<T, Src, WT>(src, first ? 0 : N - 1, T(1), T(0), xfma(A_e0, d1, B_e0 * d2), y0, y1, hc, hg, hf);
     }
   };
   if constexpr (HF) {
@@ -199,8 +199,8 @@ __device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const S
         const T v = pass ? xfma(A, xe[i + 3] - xe[i + 1], B * (xe[i + 4] - xe[i])) : xe[i + 2];
         if ((i < M - 1) || hl) Xs[lpos(a + i + 1)] = v;
       }
-      if (first) Xs[lpos(0)] = pass ? xfma(A_e0, x[0], B_e0 * x[1]) : T(0);
-      if (last) Xs[lpos(N - 1)] = pass ? xfma(A_e0, -lastv, B_e0 * (-last2)) : T(0);
+      if (first) Xs[lpos(0)] = pass ? dX_end : T(0);
+      if (last) Xs[lpos(N - 1)] = pass ? dX_end : T(0);
       wave_lds_sync();
       if (valid) for (int j = lg; j < N; j += P) out[sys * N + j] = Xs[lpos(j)];
     }
