@@ -188,10 +188,12 @@ def test_every_rows_per_lane_instantiation(ctx, bo, N):
     """one system per kernel instantiation (rows per lane M = 2 ... 31) against the LAPACK oracle"""
     th, g, c = salpha_batch(bo, N, np.array([[0.9, 0.7, 0.3], [1.7, 0.4, 1.1]]))
     r = ctx.solve_gcf(th[1] - th[0], g, c, g, want_info=True)
+    rx = ctx.solve_gcf(th[1] - th[0], g, c, g, want_X=True)          # X / dX leave through the wave's LDS row
     assert r["nbad"] == 0
     for k in range(2):
-        gam = bo.solve_gcf(th, g[k], c[k], g[k])[0]
-        assert abs(r["gam"][k] - gam) < 1e-10
+        gam, lam, X, dX = bo.solve_gcf(th, g[k], c[k], g[k])
+        assert abs(r["gam"][k] - gam) < 1e-10 and abs(rx["gam"][k] - r["gam"][k]) < 1e-13
+        assert np.abs(rx["X"][k] - X).max() < 1e-7 and np.abs(rx["dX"][k] - dX).max() < 1e-7 * np.abs(dX).max() + 1e-7
 
 
 def test_hf_grad_generic_tangents(ctx, bo):
