@@ -36,70 +36,6 @@ struct SrcGeoG {     // as SrcGeo (ibs_kernels.hip): 7 derived arrays of the lin
   __device__ __forceinline__ T f_t(int j) const { return A3[lpos(j)] * gdp(j); }
 };
 
-// eigenvector -> X (LDS, this lane's system) -> growth rate; utils.py:1601-1621 (+1666-1680 when HF)
-template <typename T, int M, int P, class Src, bool HF>
-__device__ __forceinline__ void finish_g(GroupSolver<T, M, P>& ws, const Src& src, int N, T h, T* Xs, T lam,
-                                         int iters, int status, long sys, bool valid, T* lam_out, T* gam_out,
-                                         T* X_out, T* dX_out, T* dth0_out, int* info_out) {
-  using GP = Grp<P>;
-  const int lane = ws.lane, lg = ws.lg;
-  const int n = N - 2;
-  T x[M];
-  ws.assemble(src, N, h, x);
-  T m = T(0);
-#pragma unroll
-  for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
-  m = GP::max(m, lane);
-  const int a = GroupSolver<T, M, P>::rows_start(lg, n);
-  const T rm = T(1) / m;
-#pragma unroll
-  for (int i = 0; i < M; ++i)
-    if ((i < M - 1) || ws.has_last) Xs[lpos(a + i + 1)] = x[i] * rm;
-  if (lg == 0) { Xs[lpos(0)] = T(0); Xs[lpos(N - 1)] = T(0); }
-  wave_lds_sync();   // Xs belongs to this group
-  // dX (utils.py:1610-1616) in the branch-free clamped-index form of finish() (ibs_kernels.hip)
-  const T ih = T(1) / h;
-  const T A_in = (T(2) / T(3)) * ih, B_in = -ih / T(12), A_e1 = T(0.5) * ih, A_e0 = T(2) * ih, B_e0 = T(-0.5) * ih;
-  bool do_hf = false;
-  if constexpr (HF) do_hf = dth0_out != nullptr;
-  T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0);
-  for (int j0 = 0; j0 < N; j0 += P) {
-    const int j = j0 + lg;
-    const bool in = j < N;
-    const int jc = in ? j : N - 1;
-    const int jm1 = jc > 0 ? jc - 1 : 0, jm2 = jc > 1 ? jc - 2 : 0;
-    const int jp1 = jc < N - 1 ? jc + 1 : N - 1, jp2 = jc < N - 2 ? jc + 2 : N - 1;
-    const T X = Xs[lpos(jc)];
-    const T d1 = Xs[lpos(jp1)] - Xs[lpos(jm1)], d2 = Xs[lpos(jp2)] - Xs[lpos(jm2)];
-    const bool end0 = (jc == 0) || (jc == N - 1), end1 = (jc == 1) || (jc == N - 2);
-    const T A = end0 ? A_e0 : (end1 ? A_e1 : A_in), B = end0 ? B_e0 : (end1 ? T(0) : B_in);
-    const T dX = xfma(A, d1, B * d2);
-    const T w = in ? (end0 ? T(1) : ((jc & 1) ? T(4) : T(2))) : T(0);
-    const T X2 = w * (X * X), dX2 = w * (dX * dX);
-    y0 += src.c(jc) * X2 - src.g(jc) * dX2;
-    y1 = xfma(src.f(jc), X2, y1);
-    if constexpr (HF) {
-      if (do_hf) { hc = xfma(src.c_t(jc), X2, hc); hg = xfma(src.g_t(jc), dX2, hg); hf = xfma(src.f_t(jc), X2, hf); }
-    }
-    if (valid && in && X_out) X_out[sys * N + j] = X;
-    if (valid && in && dX_out) dX_out[sys * N + j] = dX;
-  }
-  y0 = GP::sum(y0, lane); y1 = GP::sum(y1, lane);
-  const T gam = y0 / y1;
-  if constexpr (HF) {
-    if (do_hf) {
-      hc = GP::sum(hc, lane); hg = GP::sum(hg, lane); hf = GP::sum(hf, lane);
-      const T jac = hc / y1 - hg / y1 - gam * hf / y1;
-      if (lg == 0 && valid) dth0_out[sys] = jac;
-    }
-  }
-  if (lg == 0 && valid) {
-    if (lam_out) lam_out[sys] = lam;
-    if (gam_out) gam_out[sys] = gam;
-    if (info_out) info_out[sys] = iters | (status << 16);
-  }
-}
-
 // one grid point of the Simpson sums (utils.py:1618-1619; with WT also the theta0-tangent sums, utils.py:1676-1680)
 template <typename T, class Src, bool WT>
 __device__ __forceinline__ void simpson_point_g(const Src& src, int j, T w, T X, T dX, T& y0, T& y1, T& hc, T& hg, T& hf) {
@@ -109,7 +45,8 @@ __device__ __forceinline__ void simpson_point_g(const Src& src, int j, T w, T X,
   if constexpr (WT) { hc = xfma(src.c_t(j), X2, hc); hg = xfma(src.g_t(j), dX2, hg); hf = xfma(src.f_t(j), X2, hf); }
 }
 
-// The same stage with the eigenfunction kept in the lanes' row chunks (see finish_chunk in ibs_kernels.hip): the four
+// eigenvector -> growth rate (utils.py:1601-1621, +1666-1680 when HF) with the eigenfunction kept in the lanes' row
+// chunks (see finish_chunk in ibs_kernels.hip): the four
 // stencil neighbours beyond a chunk come from the adjacent lanes of the group, every lane sums its own rows, the
 // first and last lane of the group add the end points j = 0, N-1.  X / dX, when requested, go through the group's
 // LDS row afterwards.
