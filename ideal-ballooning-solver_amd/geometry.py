@@ -12,6 +12,24 @@ NAMES_MN = ("rmnc", "zmns", "lmns", "d_rmnc_d_s", "d_zmns_d_s", "d_lmns_d_s")
 NAMES_NYQ = ("gmnc", "bmnc", "d_bmnc_d_s", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc")
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=16)
+def _radial_weights(ns, svals_bytes):
+    """(W_full, W_full', W_half, W_half'): matrices that evaluate, at svals, the not-a-knot cubic spline (and its
+    derivative) through data given on VMEC's full mesh linspace(0, 1, ns) / half mesh (columns 1..ns-1)."""
+    from scipy.interpolate import make_interp_spline
+    svals = np.frombuffer(svals_bytes, dtype=np.float64)
+    s_full = np.linspace(0, 1, ns)                           # vmec.s_full_grid
+    s_half = s_full[1:] - 0.5 * (s_full[1] - s_full[0])      # vmec.s_half_grid
+    out = []
+    for grid in (s_full, s_half):
+        sp = make_interp_spline(grid, np.eye(len(grid)), k=3)
+        out += [np.ascontiguousarray(sp(svals)), np.ascontiguousarray(sp.derivative()(svals))]
+    return tuple(out)
+
+
 def mode_rows(xm, xn, dn=None, max_len=64):
     """runs of modes with equal m and n advancing by the common step dn (VMEC's ordering: dn = nfp) as int32
     (nrows, 2) = {first, count}, plus dn.  Any ordering is valid: runs simply get shorter (down to 1)."""
@@ -30,6 +48,12 @@ def mode_rows(xm, xn, dn=None, max_len=64):
     return np.ascontiguousarray(rows, dtype=np.int32), dn
 
 
+@functools.lru_cache(maxsize=16)
+def _mode_rows_cached(xm_bytes, xn_bytes):
+    """mode_rows for the (unchanging) mode tables of an equilibrium family"""
+    return mode_rows(np.frombuffer(xm_bytes, dtype=np.float64), np.frombuffer(xn_bytes, dtype=np.float64))
+
+
 class SurfaceTables:
     """per-surface inputs of the geometry kernel, packed as the C ABI wants them (include/ibs.h)"""
 
@@ -43,8 +67,8 @@ class SurfaceTables:
         self.scal = np.ascontiguousarray(np.stack([self.s, iota, d_iota_d_s, d_pressure_d_s,
                                                    np.full(n, float(phiedge)), np.full(n, float(Aminor_p))], axis=1))
         assert self.tab_mn.shape == (n, 6, len(self.xm)) and self.tab_nyq.shape == (n, 7, len(self.xm_nyq))
-        self.rows_mn, self.dn_mn = mode_rows(self.xm, self.xn)
-        self.rows_nyq, self.dn_nyq = mode_rows(self.xm_nyq, self.xn_nyq)
+        self.rows_mn, self.dn_mn = _mode_rows_cached(self.xm.tobytes(), self.xn.tobytes())
+        self.rows_nyq, self.dn_nyq = _mode_rows_cached(self.xm_nyq.tobytes(), self.xn_nyq.tobytes())
 
     @classmethod
     def from_arrays(cls, d):
@@ -57,26 +81,26 @@ class SurfaceTables:
     def from_wout(cls, wout, svals):
         """wout: mapping with rmnc, zmns, lmns, gmnc, bmnc, bsupvmnc, bsubsmns, bsubumnc, bsubvmnc stored
         (mn, ns) as in simsopt's Vmec.wout, pres, iotas, phi (ns,), xm, xn, xm_nyq, xn_nyq, Aminor_p, ns."""
-        from scipy.interpolate import make_interp_spline
         ns = int(wout["ns"])
-        s_full = np.linspace(0, 1, ns)                     # vmec.s_full_grid
-        s_half = s_full[1:] - 0.5 * (s_full[1] - s_full[0])  # vmec.s_half_grid
         svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))
+        # cubic interpolating splines with not-a-knot ends = what InterpolatedUnivariateSpline builds (utils.py:58-107).
+        # Interpolation is linear in the data and the radial grids are the same for every mode, array and
+        # equilibrium, so the splines are applied as four weight matrices (value / derivative on the full / half
+        # mesh at svals), built once per (ns, svals) by splining the identity: one small matrix product per array.
+        Wf, Wfd, Wh, Whd = _radial_weights(ns, svals.tobytes())
 
         def ev(tab, half, deriv=False):
-            # cubic interpolating spline with not-a-knot ends = what InterpolatedUnivariateSpline builds
-            # (utils.py:58-107), fitted for all modes at once
             tab = np.asarray(tab, dtype=np.float64)
-            sp = make_interp_spline(s_half, tab[:, 1:].T, k=3) if half else make_interp_spline(s_full, tab.T, k=3)
-            return (sp.derivative() if deriv else sp)(svals)
+            if half:
+                return (Whd if deriv else Wh) @ tab[:, 1:].T          # (n_s, modes)
+            return (Wfd if deriv else Wf) @ tab.T
 
         mn = np.stack([ev(wout["rmnc"], False), ev(wout["zmns"], False), ev(wout["lmns"], True),
                        ev(wout["rmnc"], False, True), ev(wout["zmns"], False, True), ev(wout["lmns"], True, True)], axis=1)
         nyq = np.stack([ev(wout["gmnc"], True), ev(wout["bmnc"], True), ev(wout["bmnc"], True, True),
                         ev(wout["bsupvmnc"], True), ev(wout["bsubsmns"], False), ev(wout["bsubumnc"], True),
                         ev(wout["bsubvmnc"], True)], axis=1)
-        pres = make_interp_spline(s_half, np.asarray(wout["pres"], dtype=np.float64)[1:], k=3)    # utils.py:112
-        iota = make_interp_spline(s_half, np.asarray(wout["iotas"], dtype=np.float64)[1:], k=3)   # utils.py:118
-        return cls(svals, wout["xm"], wout["xn"], wout["xm_nyq"], wout["xn_nyq"], mn, nyq, iota(svals),
-                   iota.derivative()(svals), pres.derivative()(svals), float(np.asarray(wout["phi"])[-1]),
-                   float(wout["Aminor_p"]))
+        pres_h = np.asarray(wout["pres"], dtype=np.float64)[1:]        # utils.py:112
+        iota_h = np.asarray(wout["iotas"], dtype=np.float64)[1:]       # utils.py:118
+        return cls(svals, wout["xm"], wout["xn"], wout["xm_nyq"], wout["xn_nyq"], mn, nyq, Wh @ iota_h,
+                   Whd @ iota_h, Whd @ pres_h, float(np.asarray(wout["phi"])[-1]), float(wout["Aminor_p"]))
