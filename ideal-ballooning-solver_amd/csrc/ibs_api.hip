@@ -480,6 +480,33 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   wpb = (waves_per_line + nblk - 1) / nblk;
   ibs::ScanArgs<double> a{};
   a.n_lines = n_lines; a.n_theta0 = n_theta0; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
+  // Batches much larger than the chip (one wave per system, no caller-supplied guesses): chain consecutive theta0
+  // values of a line through one wave, each solve warm-started from the previous eigenvalue (k_gamma_scan_chain).
+  // 4 per wave once that still leaves two waves per SIMD, 2 from one wave per SIMD.  IBS_SCAN_CHAIN=n overrides.
+  if (G == 1 && !lam_guess) {
+    const long waves = (long)n_lines * n_theta0, simds = 4L * ctx->n_cu;
+    int chain = 1;
+    if (n_theta0 >= 8 && waves >= 8 * simds) chain = 4;
+    else if (n_theta0 >= 4 && waves >= 2 * simds) chain = 2;
+    if (const char* e = getenv("IBS_SCAN_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= n_theta0) chain = v; }
+    auto fc = ibs::launch_table().scan_chain_f64[M];
+    if (chain > 1 && fc) {
+      const bool need_x = (M < 3) || X || dX;
+      const int wpl = (n_theta0 + chain - 1) / chain;
+      long w = need_x ? (long)(((size_t)ctx->lds_per_block - 7 * per_arr) / per_arr) : cap;
+      if (w > cap) w = cap;
+      if (w > wpl) w = wpl;
+      if (w >= 1) {
+        const int nb = (wpl + (int)w - 1) / (int)w;
+        a.wpb = (wpl + nb - 1) / nb;
+        a.chain = chain;
+        a.chain_w1 = 0.25; a.chain_w2 = 1.0;     // measured on the NCSX shapes (tools/bench_chain.py): 9.2 sweeps per solve instead of 15.7
+        if (const char* e = getenv("IBS_CHAIN_W1")) a.chain_w1 = atof(e);
+        if (const char* e = getenv("IBS_CHAIN_W2")) a.chain_w2 = atof(e);
+        fn = fc;
+      }
+    }
+  }
   const size_t n_sys = (size_t)n_lines * n_theta0;
   if (mem == IBS_MEM_HOST) {
     const size_t in_elems = (size_t)n_lines * ld, out_elems = n_sys * N;

@@ -437,6 +437,85 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
 }
 
 
+// Chained form of the scan for batches much larger than the chip: every wave solves `chain` consecutive theta0
+// values of its line one after the other and starts each solve from the eigenvalue of the previous one (first
+// neighbour: lam_prev +- w1 |lam_prev|; from the second on: linear extrapolation +- w2 |last difference|) -- the
+// reference's own theta0 loop warm-starts its ARPACK vector the same way (ball_scan.py:265-274).  A wrong guess
+// costs sweeps, never correctness: the bracket still moves on counts only.  The staged line serves chain x wpb
+// solves instead of wpb, and without X / dX output no per-wave LDS row is allocated at all.
+template <typename T, int M>
+__global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan_chain(
+    int n_lines, int n_theta0, int N, T h, const T* __restrict__ bmag, const T* __restrict__ gradpar,
+    const T* __restrict__ cvdrift, const T* __restrict__ cvdrift0, const T* __restrict__ gds2,
+    const T* __restrict__ gds21, const T* __restrict__ gds22, long ld, const T* __restrict__ dPdrho,
+    const T* __restrict__ theta0, T* gam_out, T* lam_out, T* X_out, T* dX_out, T* dth0_out, int* info_out,
+    int chain, T w1, T w2) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  const int waves_per_line = (n_theta0 + chain - 1) / chain;
+  const int nparts = (waves_per_line + wpb - 1) / wpb;
+  int line, part;
+  {   // XCD-aware block -> (line, part) map of k_gamma_scan
+    const int b = blockIdx.x;
+    const int chunk = b / (8 * nparts), r = b - chunk * 8 * nparts;
+    const int lines_here = min(8, n_lines - chunk * 8);
+    line = chunk * 8 + r % lines_here;
+    part = r / lines_here;
+    if (part >= nparts) return;
+  }
+  const int P = lds_pitch(N);
+  T* A1 = smem; T* A3 = A1 + P; T* C0 = A3 + P; T* C1 = C0 + P; T* G0 = C1 + P; T* G1 = G0 + P; T* G2 = G1 + P;
+  T* Xs = (M < 3 || X_out || dX_out) ? G2 + P + (size_t)wave * P : nullptr;
+  {
+    const long off = (long)line * ld;
+    const T mdP = -dPdrho[line];
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const T B = bmag[off + j], gp = xabs(gradpar[off + j]);
+      const T inv = T(1) / (gp * B);
+      const int q = lpos(j);
+      A1[q] = gp / B; A3[q] = inv / (B * B);
+      C0[q] = mdP * cvdrift[off + j] * inv; C1[q] = mdP * cvdrift0[off + j] * inv;
+      G0[q] = gds2[off + j]; G1[q] = gds21[off + j]; G2[q] = gds22[off + j];
+    }
+  }
+  __syncthreads();
+  const int first = (part * wpb + wave) * chain;
+  T lam_p1 = T(0), lam_p2 = T(0);
+  int have = 0;                       // eigenvalues of this wave's previous solves in hand (0, 1, 2)
+  for (int q = 0; q < chain; ++q) {
+    const int it0 = first + q;
+    if (it0 >= n_theta0) break;       // wave-uniform
+    // N is made opaque once per solve: otherwise every LDS address of setup() and of the growth-rate stage is
+    // loop-invariant, gets hoisted out of this loop and is kept alive (spilled) across all the solves
+    int Nq = N;
+    asm volatile("" : "+s"(Nq));
+    const T th0 = theta0[it0];
+    SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
+    WaveSolver<T, M> ws;
+    SolveInfo inf{0, 0};
+    const bool bad = ws.setup(src, Nq, h);
+    const long sys = (long)line * n_theta0 + it0;
+    T lam = T(0);
+    if (!bad) {
+      const T floor_w = T(4096) * T(64) * Eps<T>::v * ws.normA;
+      const T guess = have == 2 ? T(2) * lam_p1 - lam_p2 : lam_p1;
+      const T width = have == 2 ? xmax(w2 * xabs(lam_p1 - lam_p2), floor_w) : xmax(w1 * xabs(lam_p1), floor_w);
+      lam = ws.solve(inf, have > 0, guess, width);
+      lam_p2 = lam_p1; lam_p1 = lam; have = have < 2 ? have + 1 : 2;
+    } else {
+      inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); have = 0;
+    }
+    if constexpr (M >= 3)
+      finish_chunk<T, M, SrcGeo<T>, true>(ws, src, Nq, h, Xs, lam, inf, sys, lam_out, gam_out, X_out, dX_out, dth0_out,
+                                          info_out);
+    else
+      finish<T, M, SrcGeo<T>, true>(ws, src, Nq, h, Xs, lam, inf, sys, lam_out, gam_out, X_out, dX_out, dth0_out, info_out);
+    if (Xs) wave_lds_sync();          // the row is reused by the next solve of this wave
+  }
+}
+
 // ---------------------------------------------------------------- objective + Hellmann-Feynman gradient
 // One wave per (alpha, theta0) evaluation point (utils.py:1632-1728 obj_w_grad given the three field
 // lines alpha-d/2, alpha, alpha+d/2).  geo: [n_pts][3][8][ld] in the order bmag, gradpar, cvdrift,
@@ -670,6 +749,21 @@ static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   return hipGetLastError();
 }
 template <typename T>
+static hipError_t launch_scan_chain(const ScanArgs<T>& a, hipStream_t st) {
+  const int wpb = a.wpb, chain = a.chain;
+  const bool need_x = (IBS_M < 3) || a.X || a.dX;          // (the LDS-round-trip finish of M < 3 always uses the row)
+  const size_t lds = (size_t)(7 + (need_x ? wpb : 0)) * lds_pitch(a.N) * sizeof(T);
+  auto kern = k_gamma_scan_chain<T, IBS_M>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const int waves_per_line = (a.n_theta0 + chain - 1) / chain;
+  dim3 grid((unsigned)(((waves_per_line + wpb - 1) / wpb) * a.n_lines));
+  hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
+                     a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
+                     a.dX, a.dth0, a.info, chain, a.chain_w1, a.chain_w2);
+  return hipGetLastError();
+}
+template <typename T>
 static hipError_t launch_sturm(const SturmArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
   const size_t lds = (size_t)wpb * a.N * sizeof(T);
@@ -701,6 +795,7 @@ struct IBS_CAT(Registrar, IBS_M) {
     LaunchTable& t = launch_table();
     t.gcf_f64[IBS_M] = &launch_gcf<double>;
     t.scan_f64[IBS_M] = &launch_scan<double>;
+    t.scan_chain_f64[IBS_M] = &launch_scan_chain<double>;
     t.sturm_f64[IBS_M] = &launch_sturm<double>;
     t.grad_f64[IBS_M] = &launch_grad<double>;
 #ifdef IBS_WITH_F32

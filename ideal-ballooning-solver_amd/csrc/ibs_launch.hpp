@@ -20,6 +20,7 @@ struct ScanArgs {
   const T *dPdrho, *theta0;
   T *gam, *lam, *X, *dX, *dth0; int* info; int wpb;
   const T* lam_guess; T guess_width;     // optional warm start ([n_lines][n_theta0], absolute width); null = cold
+  int chain; T chain_w1, chain_w2;       // k_gamma_scan_chain: theta0 values per wave and the widths of its warm starts
 };
 template <typename T>
 struct SturmArgs {
@@ -37,6 +38,7 @@ struct LaunchTable {
   hipError_t (*gcf_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
   hipError_t (*gcf_f32[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);
   hipError_t (*scan_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
+  hipError_t (*scan_chain_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
   hipError_t (*sturm_f64[kMaxM + 1])(const SturmArgs<double>&, hipStream_t);
   hipError_t (*grad_f64[kMaxM + 1])(const GradArgs<double>&, hipStream_t);
   // sub-wave variants (ibs_group.hpp): index 0 -> 32 lanes per system, 1 -> 16 lanes per system

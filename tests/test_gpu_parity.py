@@ -412,6 +412,36 @@ def test_config3_full_size_from_wout_tables(ctx, bo):
     assert np.array_equal(idx.cpu().numpy(), sc["gam"].reshape(ns, -1).argmax(dim=1).cpu().numpy())
 
 
+@pytest.mark.parametrize("chain,nt0", [(2, 16), (4, 15), (4, 16), (5, 7), (16, 16)])
+def test_chained_scan_matches_unchained(ctx, bo, chain, nt0, monkeypatch):
+    """k_gamma_scan_chain (several theta0 of a line solved one after the other by one wave, each warm-started from
+    the previous eigenvalue): same certified results as one wave per theta0, including X / dX / d(gam)/d(theta0)
+    outputs, ragged chains (theta0 count not a multiple of the chain) and deliberately bad warm-start widths."""
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    geo = np.tile(g3["geo_1025"], (3, 1, 1))[:14]
+    geo[:, 4:7] *= (1 + 0.02 * np.arange(len(geo)))[:, None, None]
+    dP = -0.5 * np.mean((geo[:, 2] - geo[:, 7]) * geo[:, 0] ** 2, axis=1)
+    th = bo.theta_grid(1025)
+    t0 = np.linspace(0, np.pi / 2, nt0)
+    a = [np.ascontiguousarray(geo[:, k]) for k in range(7)]
+    monkeypatch.setenv("IBS_SCAN_CHAIN", "1")
+    ref = ctx.gamma_scan(th[1] - th[0], *a, dP, t0, want_X=True, want_dtheta0=True, want_info=True)
+    for w1, w2 in (("0.5", "1.0"), ("1e-6", "1e-6"), ("50", "50")):
+        monkeypatch.setenv("IBS_SCAN_CHAIN", str(chain)); monkeypatch.setenv("IBS_CHAIN_W1", w1); monkeypatch.setenv("IBS_CHAIN_W2", w2)
+        r = ctx.gamma_scan(th[1] - th[0], *a, dP, t0, want_X=True, want_dtheta0=True, want_info=True)
+        assert r["nbad"] == 0
+        # lam is certified to 256 ulp(||A||) (~3e-11 here); gam is second order in the eigenvector error
+        assert np.abs(r["gam"] - ref["gam"]).max() < 1e-11 and np.abs(r["lam"] - ref["lam"]).max() < 1e-10
+        assert np.abs(r["dgam_dtheta0"] - ref["dgam_dtheta0"]).max() < 1e-9
+        assert np.abs(r["X"] - ref["X"]).max() < 1e-6 and np.abs(r["dX"] - ref["dX"]).max() < 1e-5
+        rn = ctx.gamma_scan(th[1] - th[0], *a, dP, t0)                       # no X: no per-wave LDS row
+        assert np.abs(rn["gam"] - ref["gam"]).max() < 1e-11
+    sw_ref = (np.asarray(ref["info"]) & 0xffff).mean()
+    monkeypatch.setenv("IBS_CHAIN_W1", "0.5"); monkeypatch.setenv("IBS_CHAIN_W2", "1.0")
+    r = ctx.gamma_scan(th[1] - th[0], *a, dP, t0, want_info=True)
+    assert (np.asarray(r["info"]) & 0xffff).mean() < sw_ref                 # the chain saves sweeps
+
+
 def test_config3_shape_ncsx_1025_tiled(ctx, bo):
     """NCSX-shape config (N_zeta = 1024, 16 theta0 per line) on tiled golden lines vs the C oracle"""
     from oracle import c_oracle as co
