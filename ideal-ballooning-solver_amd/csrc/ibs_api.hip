@@ -482,12 +482,13 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   a.n_lines = n_lines; a.n_theta0 = n_theta0; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
   // Batches much larger than the chip (one wave per system, no caller-supplied guesses): chain consecutive theta0
   // values of a line through one wave, each solve warm-started from the previous eigenvalue (k_gamma_scan_chain).
-  // 4 per wave once that still leaves two waves per SIMD, 2 from one wave per SIMD.  IBS_SCAN_CHAIN=n overrides.
+  // 4 per wave once that still leaves two waves per SIMD, 2 from there down to two waves of chained work per SIMD
+  // (tools/bench_chain_sizes.py).  IBS_SCAN_CHAIN=n overrides.
   if (G == 1 && !lam_guess) {
     const long waves = (long)n_lines * n_theta0, simds = 4L * ctx->n_cu;
     int chain = 1;
     if (n_theta0 >= 8 && waves >= 8 * simds) chain = 4;
-    else if (n_theta0 >= 4 && waves >= 2 * simds) chain = 2;
+    else if (n_theta0 >= 4 && waves >= 4 * simds) chain = 2;      // (N = 1025: 2,048 solves 70 vs 95 us, 4,096: 111 vs 105 us)
     if (const char* e = getenv("IBS_SCAN_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= n_theta0) chain = v; }
     auto fc = ibs::launch_table().scan_chain_f64[M];
     if (chain > 1 && fc) {
