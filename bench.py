@@ -266,7 +266,8 @@ def ncsx_pipeline(ctx, device):
                    mean_sweeps=float((sc["info"] & 0xffff).double().mean().item()),
                    nonconverged=int(((sc["info"] >> 16) != 0).sum().item()),
                    roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                                 traffic=None, kernel="k_gamma_scan", bytes_per_solve=bytes_per))
+                                 traffic=None, bytes_per_solve=bytes_per,
+                                 kernel="k_gamma_scan_chain (4 theta0 per wave)" if n >= 8192 else "k_gamma_scan"))
         if tag == "reference_batch":
             scan = ibs_amd.BallooningScan(ctx, None, th, svals, nalpha=na, ntheta0=nt0, tables=tabs, device=device)
             tab = sc["gam"].reshape(ns, na, nt0).cpu().numpy()
