@@ -453,12 +453,14 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   const size_t per_arr = (size_t)ibs::lds_pitch(N) * sizeof(double);
   if (8 * per_arr > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
   int G = 1, cap = ibs::scan_max_threads(M) / 64;
+  decltype(fn) fn_g_chain = nullptr;     // chained / warm-started sub-wave kernel of the same (P, M)
   {
     const int P = pick_lanes(ctx, N, (long)n_lines * n_theta0);
-    if (P != 64 && n_theta0 % (64 / P) == 0 && !lam_guess) {
+    if (P != 64 && n_theta0 % (64 / P) == 0) {
       const int Mg = (N - 2 + P - 1) / P;
       auto fg = ibs::launch_table().scan_f64_g[P == 32 ? 0 : 1][Mg];
-      if (fg) { fn = fg; M = Mg; G = 64 / P; cap = ibs::scan_max_threads_g(Mg) / 64; }
+      auto fgc = ibs::launch_table().scan_chain_f64_g[P == 32 ? 0 : 1][Mg];
+      if (fg && (fgc || !lam_guess)) { fn = fg; fn_g_chain = fgc; M = Mg; G = 64 / P; cap = ibs::scan_max_threads_g(Mg) / 64; }
     }
   }
   // wpb = waves per block; each wave solves G theta0 values of the block's line
@@ -484,6 +486,36 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   // values of a line through one wave, each solve warm-started from the previous eigenvalue (k_gamma_scan_chain).
   // 4 per wave once that still leaves two waves per SIMD, 2 from there down to two waves of chained work per SIMD
   // (tools/bench_chain_sizes.py).  IBS_SCAN_CHAIN=n overrides.
+  if (G > 1 && fn_g_chain) {
+    // sub-wave kernels: the same chain over the theta0 slots of a group; caller-supplied guesses go through the same
+    // kernel with a chain of one
+    const int slots = n_theta0 / G;                       // theta0 values per group position of a line
+    const long waves = (long)n_lines * slots, simds = 4L * ctx->n_cu;
+    int chain = 1;
+    if (!lam_guess) {
+      if (slots >= 4 && waves >= 8 * simds) chain = 4;
+      else if (slots >= 2 && waves >= 4 * simds) chain = 2;
+      if (const char* e = getenv("IBS_SCAN_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= slots) chain = v; }
+    }
+    if (chain > 1 || lam_guess) {
+      const bool need_x = X || dX;
+      const int wpl = (slots + chain - 1) / chain;          // waves per line
+      long w = need_x ? (long)(((size_t)ctx->lds_per_block - 7 * per_arr) / (per_arr * G)) : cap;
+      if (w > cap) w = cap;
+      if (w > wpl) w = wpl;
+      if (w >= 1) {
+        const int nb = (wpl + (int)w - 1) / (int)w;
+        a.wpb = (wpl + nb - 1) / nb;
+        a.chain = chain;
+        a.chain_w1 = 0.25; a.chain_w2 = 1.0;
+        if (const char* e = getenv("IBS_CHAIN_W1")) a.chain_w1 = atof(e);
+        if (const char* e = getenv("IBS_CHAIN_W2")) a.chain_w2 = atof(e);
+        fn = fn_g_chain;
+      } else if (lam_guess) {
+        return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
+      }
+    }
+  }
   if (G == 1 && !lam_guess) {
     const long waves = (long)n_lines * n_theta0, simds = 4L * ctx->n_cu;
     int chain = 1;

@@ -346,11 +346,19 @@ struct GroupSolver {
   // loops until every group is done (a finished group keeps re-evaluating its frozen shift).  Each iteration is
   // exactly ONE forward sweep for all groups, so the only divergence left is the iteration count (15 +- 2 on
   // NCSX-like systems).  `bad` groups are parked as done.  Returns lam (group-replicated).
-  __device__ __forceinline__ T solve(bool bad, int& iters_out, int& status_out) {
+  // Optional warm start per group (see WaveSolver::solve): `guess` = eigenvalue of a nearby problem, `width` its
+  // expected error (both group-replicated).  The first shift is guess + width and walks up geometrically until a
+  // count certifies an upper bound; the next one is guess - width.  Certified exactly like the cold solve.
+  __device__ __forceinline__ T solve(bool bad, int& iters_out, int& status_out, bool warm = false, T guess = T(0),
+                                     T width = T(0)) {
     using WS = WaveSolver<T, M>;
     using Pt = typename WS::Pt;
     const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
-    T sig = T(0.5) * (lo + hi), sig_prev = sig, lam = hi;
+    const bool warm_ok = warm && finite_of(guess) && width > T(0) && guess + width < hi && guess + width > lo;
+    bool expand = warm_ok, try_below = warm_ok;
+    T wstep = T(4) * width;
+    const T g_below = guess - width;
+    T sig = warm_ok ? guess + width : T(0.5) * (lo + hi), sig_prev = sig, lam = hi;
     T off_up = tol, off_dn = tol, rho_trust = hi;
     int aimed = 0, it = 0, lg_prev = 0;
     bool lo1 = false, hi_f = false, old_ok = false, was_interp = false, conv = false;
@@ -415,9 +423,18 @@ struct GroupSolver {
       const bool aim_ok = trust && (c_up || c_dn) && cand > lo && cand < hi;
       const bool interp_now = ok && !near;
       const T nxt = aim_ok ? cand : (interp_now ? rho : mid);
-      sig = go ? nxt : sig;
-      aimed = go ? (aim_ok ? (c_up ? 1 : -1) : 0) : 0;
-      was_interp = go && interp_now;
+      // warm start prologue: keep walking up while the count says lam_max is still above; afterwards, while lam_max
+      // is not yet isolated, try the lower end of the guessed interval once
+      const bool exp_go = go && expand && C != 0 && sig + wstep < hi;
+      const bool locate = go && !exp_go && !lo1;
+      const bool tb = locate && try_below && g_below > lo && g_below < hi;
+      const bool ovr = exp_go || tb;
+      sig = go ? (exp_go ? sig + wstep : (tb ? g_below : nxt)) : sig;
+      wstep = exp_go ? T(4) * wstep : wstep;
+      expand = exp_go;
+      try_below = locate ? false : try_below;
+      aimed = (go && !ovr) ? (aim_ok ? (c_up ? 1 : -1) : 0) : 0;
+      was_interp = go && interp_now && !ovr;
     }
     // eigenvector and Rayleigh-quotient polish at each group's last shift
     sweep_fwd<true>(sig);

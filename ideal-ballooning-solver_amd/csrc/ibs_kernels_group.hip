@@ -224,6 +224,78 @@ __global__ void __launch_bounds__(scan_max_threads_g(M), 2) k_gamma_scan_g(
                                       dX_out, dth0_out, info_out);
 }
 
+// Chained / warm-started form (see k_gamma_scan_chain in ibs_kernels.hip): group gid of wave w solves the theta0
+// indices ((part*wpb + w)*G + gid)*chain + q, q = 0 .. chain-1, one after the other, each solve warm-started from the
+// eigenvalue of the previous one; with lam_guess (chain = 1) every solve starts from the caller's eigenvalue of a
+// nearby problem instead (ibs_gamma_scan_warm_f64).  No X / dX output => no per-group LDS row.
+template <typename T, int M, int P>
+__global__ void __launch_bounds__(scan_max_threads_g(M), 2) k_gamma_scan_g_chain(
+    int n_lines, int n_theta0, int N, T h, const T* __restrict__ bmag, const T* __restrict__ gradpar,
+    const T* __restrict__ cvdrift, const T* __restrict__ cvdrift0, const T* __restrict__ gds2,
+    const T* __restrict__ gds21, const T* __restrict__ gds22, long ld, const T* __restrict__ dPdrho,
+    const T* __restrict__ theta0, T* gam_out, T* lam_out, T* X_out, T* dX_out, T* dth0_out, int* info_out,
+    int chain, T w1, T w2, const T* __restrict__ lam_guess, T guess_width) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  constexpr int G = 64 / P;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int gid = lane / P;
+  const int per_blk = wpb * G * chain;
+  const int nparts = (n_theta0 + per_blk - 1) / per_blk;
+  int line, part;
+  {   // XCD-aware block -> (line, part) map, see k_gamma_scan
+    const int b = blockIdx.x;
+    const int chunk = b / (8 * nparts), r = b - chunk * 8 * nparts;
+    const int lines_here = min(8, n_lines - chunk * 8);
+    line = chunk * 8 + r % lines_here;
+    part = r / lines_here;
+  }
+  const int PT = lds_pitch(N);
+  T* A1 = smem; T* A3 = A1 + PT; T* C0 = A3 + PT; T* C1 = C0 + PT; T* G0 = C1 + PT; T* G1 = G0 + PT; T* G2 = G1 + PT;
+  T* Xs = (X_out || dX_out) ? G2 + PT + ((size_t)wave * G + gid) * PT : nullptr;
+  {
+    const long off = (long)line * ld;
+    const T mdP = -dPdrho[line];
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const T B = bmag[off + j], gp = xabs(gradpar[off + j]);
+      const T inv = T(1) / (gp * B);
+      const int q = lpos(j);
+      A1[q] = gp / B; A3[q] = inv / (B * B);
+      C0[q] = mdP * cvdrift[off + j] * inv; C1[q] = mdP * cvdrift0[off + j] * inv;
+      G0[q] = gds2[off + j]; G1[q] = gds21[off + j]; G2[q] = gds22[off + j];
+    }
+  }
+  __syncthreads();
+  const int first = ((part * wpb + wave) * G + gid) * chain;
+  T lam_p1 = T(0), lam_p2 = T(0);
+  int have = 0;
+  for (int q = 0; q < chain; ++q) {
+    const int it0 = first + q;
+    const bool valid = it0 < n_theta0;
+    if (!__any(valid)) break;
+    int Nq = N;                          // opaque once per solve: keeps the LDS addresses from being hoisted out of the loop
+    asm volatile("" : "+s"(Nq));
+    const int it0c = valid ? it0 : (n_theta0 - 1);
+    const T th0 = theta0[it0c];
+    SrcGeoG<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
+    GroupSolver<T, M, P> ws;
+    const bool bad = ws.setup(src, Nq, h);
+    const long sys = (long)line * n_theta0 + it0c;
+    int iters = 0, status = 0;
+    const T floor_w = T(4096) * T(64) * Eps<T>::v * ws.normA;
+    T guess = have == 2 ? T(2) * lam_p1 - lam_p2 : lam_p1;
+    T width = have == 2 ? xmax(w2 * xabs(lam_p1 - lam_p2), floor_w) : xmax(w1 * xabs(lam_p1), floor_w);
+    bool warm = have > 0;
+    if (lam_guess) { guess = lam_guess[sys]; width = guess_width; warm = true; }
+    const T lam = ws.solve(bad, iters, status, warm, guess, width);
+    lam_p2 = lam_p1; lam_p1 = lam; have = bad ? 0 : (have < 2 ? have + 1 : 2);
+    finish_chunk_g<T, M, P, SrcGeoG<T>, true>(ws, src, Nq, h, Xs, lam, iters, status, sys, valid, lam_out, gam_out, X_out,
+                                              dX_out, dth0_out, info_out);
+    if (Xs) wave_lds_sync();
+  }
+}
+
 template <typename T>
 static hipError_t launch_gcf_g(const GcfArgs<T>& a, hipStream_t st) {
   constexpr int G = 64 / IBS_P;
@@ -254,6 +326,23 @@ static hipError_t launch_scan_g(const ScanArgs<T>& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <typename T>
+static hipError_t launch_scan_g_chain(const ScanArgs<T>& a, hipStream_t st) {
+  constexpr int G = 64 / IBS_P;
+  const int wpb = a.wpb, chain = a.chain < 1 ? 1 : a.chain;
+  const bool need_x = a.X || a.dX;
+  const size_t lds = (size_t)(7 + (need_x ? wpb * G : 0)) * lds_pitch(a.N) * sizeof(T);
+  auto kern = k_gamma_scan_g_chain<T, IBS_M, IBS_P>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const int per_blk = wpb * G * chain;
+  dim3 grid((unsigned)(((a.n_theta0 + per_blk - 1) / per_blk) * a.n_lines));
+  hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
+                     a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
+                     a.dX, a.dth0, a.info, chain, a.chain_w1, a.chain_w2, a.lam_guess, a.guess_width);
+  return hipGetLastError();
+}
+
 #define IBS_CAT3_(a, b, c) a##b##_##c
 #define IBS_CAT3(a, b, c) IBS_CAT3_(a, b, c)
 struct IBS_CAT3(RegistrarG, IBS_P, IBS_M) {
@@ -262,6 +351,7 @@ struct IBS_CAT3(RegistrarG, IBS_P, IBS_M) {
     constexpr int pi = (IBS_P == 32) ? 0 : 1;
     t.gcf_f64_g[pi][IBS_M] = &launch_gcf_g<double>;
     t.scan_f64_g[pi][IBS_M] = &launch_scan_g<double>;
+    t.scan_chain_f64_g[pi][IBS_M] = &launch_scan_g_chain<double>;
   }
 };
 static IBS_CAT3(RegistrarG, IBS_P, IBS_M) IBS_CAT3(registrar_g_instance_, IBS_P, IBS_M);

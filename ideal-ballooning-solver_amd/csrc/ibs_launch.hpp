@@ -44,6 +44,7 @@ struct LaunchTable {
   // sub-wave variants (ibs_group.hpp): index 0 -> 32 lanes per system, 1 -> 16 lanes per system
   hipError_t (*gcf_f64_g[2][kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
   hipError_t (*scan_f64_g[2][kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
+  hipError_t (*scan_chain_f64_g[2][kMaxM + 1])(const ScanArgs<double>&, hipStream_t);   // chained / warm-started
 };
 LaunchTable& launch_table();
 

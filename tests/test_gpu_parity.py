@@ -442,6 +442,46 @@ def test_chained_scan_matches_unchained(ctx, bo, chain, nt0, monkeypatch):
     assert (np.asarray(r["info"]) & 0xffff).mean() < sw_ref                 # the chain saves sweeps
 
 
+@pytest.mark.parametrize("N,P,chain,nt0", [(513, 32, 4, 16), (513, 32, 2, 8), (257, 16, 2, 8), (257, 16, 4, 16), (641, 32, 3, 12)])
+def test_subwave_chained_and_warm_scan(ctx, bo, N, P, chain, nt0, monkeypatch):
+    """sub-wave kernels (32 / 16 lanes per system): the theta0 chain and caller-supplied warm starts give the same
+    certified results as the cold one-wave-per-system scan, in fewer sweeps"""
+    rng = np.random.default_rng(N + P + chain)
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    src_th = bo.theta_grid(513)
+    th = bo.theta_grid(N)
+    geo = np.stack([[np.interp(th, src_th, g3["geo_513"][l, k]) for k in range(8)] for l in range(10)])
+    geo[:, 4:7] *= (1 + rng.uniform(-0.05, 0.05, len(geo)))[:, None, None]
+    dP = -0.5 * np.mean((geo[:, 2] - geo[:, 7]) * geo[:, 0] ** 2, axis=1)
+    t0 = np.linspace(0, np.pi / 2, nt0)
+    a = [np.ascontiguousarray(geo[:, k]) for k in range(7)]
+    h = th[1] - th[0]
+    monkeypatch.setenv("IBS_FORCE_P", "64"); monkeypatch.setenv("IBS_SCAN_CHAIN", "1")
+    ref = ctx.gamma_scan(h, *a, dP, t0, want_X=True, want_dtheta0=True, want_info=True)
+    monkeypatch.setenv("IBS_FORCE_P", str(P)); monkeypatch.setenv("IBS_SCAN_CHAIN", str(chain))
+    r = ctx.gamma_scan(h, *a, dP, t0, want_X=True, want_dtheta0=True, want_info=True)
+    rn = ctx.gamma_scan(h, *a, dP, t0, want_info=True)
+    for q in (r, rn):
+        assert q["nbad"] == 0
+        assert np.abs(q["gam"] - ref["gam"]).max() < 1e-11 and np.abs(q["lam"] - ref["lam"]).max() < 1e-10
+    assert np.abs(r["dgam_dtheta0"] - ref["dgam_dtheta0"]).max() < 1e-9
+    assert np.abs(r["X"] - ref["X"]).max() < 1e-6
+    sw = lambda q: (np.asarray(q["info"]) & 0xffff).mean()
+    assert sw(rn) < sw(ref)
+    # caller-supplied guesses (ibs_gamma_scan_warm_f64) through the sub-wave kernel
+    monkeypatch.setenv("IBS_SCAN_CHAIN", "1")
+    pert = [x.copy() for x in a]
+    for k in (4, 5, 6):
+        pert[k] *= 1.002
+    cold = ctx.gamma_scan(h, *pert, dP, t0, want_info=True)
+    width = 3 * float(np.abs(cold["lam"] - ref["lam"]).max())
+    warm = ctx.gamma_scan(h, *pert, dP, t0, want_info=True, lam_guess=ref["lam"], guess_width=width)
+    bad = ctx.gamma_scan(h, *pert, dP, t0, want_info=True, lam_guess=ref["lam"] + 0.3, guess_width=1e-7)   # wrong guesses
+    for q in (warm, bad):
+        assert q["nbad"] == 0 and np.abs(q["gam"] - cold["gam"]).max() < 1e-11
+    assert sw(warm) < sw(cold) - 3
+
+
 def test_config3_shape_ncsx_1025_tiled(ctx, bo):
     """NCSX-shape config (N_zeta = 1024, 16 theta0 per line) on tiled golden lines vs the C oracle"""
     from oracle import c_oracle as co
