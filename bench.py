@@ -228,6 +228,36 @@ def warm_rescan(ctx, device, h, geo7, dP_d, th0_d, reps=20):
                 max_abs_dgam_warm_vs_cold=float((warm["gam"] - cold["gam"]).abs().max().item()), guess_width=width)
 
 
+def scan_large(ctx, device, geo7, dP_d, reps=3):
+    """the geometry-fed scan far above the chip size: the bench step's 128 lines tiled to 8,192 lines x 16 theta0 =
+    131,072 solves at N_zeta = 512 (sub-wave kernels, theta0 chained through the groups)"""
+    import torch
+    rep = 64
+    g7 = [g.repeat(rep, 1) * (1 + 0.0005 * (torch.arange(g.shape[0] * rep, device=device) % 41).double())[:, None]
+          if k in (4, 5, 6) else g.repeat(rep, 1) for k, g in enumerate(geo7)]
+    dP = dP_d.repeat(rep)
+    t0 = torch.linspace(0, np.pi / 2, 16, dtype=torch.float64, device=device)
+    h = 8 * np.pi / (NPTS - 1)
+    out = ctx.gamma_scan(h, *g7, dP, t0, want_info=True)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        ctx.gamma_scan(h, *g7, dP, t0)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.min([a.elapsed_time(b) for a, b in evs]))
+    n = out["gam"].numel()
+    bytes_per = (7 * NPTS * 8 + 8) / 16 + 8
+    gbs = n * bytes_per / (ms * 1e-3) / 1e9
+    return dict(workload="%d lines x 16 theta0 = %d solves, N_zeta=512, f64" % (g7[0].shape[0], n),
+                solves_per_s=n / (ms * 1e-3), ms_per_launch_incl_host=ms,
+                mean_sweeps=float((out["info"] & 0xffff).double().mean().item()),
+                nonconverged=int(((out["info"] >> 16) != 0).sum().item()),
+                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                              traffic=None, kernel="k_gamma_scan_g_chain<double,16,32>", bytes_per_solve=bytes_per))
+
+
 def ncsx_pipeline(ctx, device):
     """configs[2] shape on one GPU (64 surfaces x 32 alpha x 16 theta0, N_zeta=1024) from the shipped NCSX equilibrium's
     wout tables: field-line geometry kernel (row F1) -> geometry-fed scan -> per-surface argmax, and the reference's
@@ -406,6 +436,7 @@ def main():
             out["stress_rough"] = stress(ctx, device, max(args.stress_systems // 4, 1024), "rough")
             out["sturm_sweep"] = sturm_sweep(ctx, device, args.stress_systems)
             out["warm_rescan"] = warm_rescan(ctx, device, h, geo7, dP_d, th0_d)
+            out["scan_large"] = scan_large(ctx, device, geo7, dP_d)
             out.update(ncsx_pipeline(ctx, device))
         print(json.dumps(out), flush=True)
     if use_dist:
