@@ -482,6 +482,29 @@ def test_subwave_chained_and_warm_scan(ctx, bo, N, P, chain, nt0, monkeypatch):
     assert sw(warm) < sw(cold) - 3
 
 
+@pytest.mark.parametrize("P", [64, 32])
+def test_chained_scan_flags_invalid_lines_only(ctx, bo, P, monkeypatch):
+    """a field line with non-finite / non-positive geometry inside a chained scan: its systems are flagged (status 2),
+    every other line's results are untouched and the chain restarts cold after a flagged solve"""
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    geo = g3["geo_513"][:6].copy()
+    dP = -0.5 * np.mean((geo[:, 2] - geo[:, 7]) * geo[:, 0] ** 2, axis=1)
+    th = bo.theta_grid(513)
+    t0 = np.linspace(0, np.pi / 2, 16)
+    h = th[1] - th[0]
+    monkeypatch.setenv("IBS_FORCE_P", str(P)); monkeypatch.setenv("IBS_SCAN_CHAIN", "4")
+    good = ctx.gamma_scan(h, *[np.ascontiguousarray(geo[:, k]) for k in range(7)], dP, t0, want_info=True)
+    assert good["nbad"] == 0
+    bad = geo.copy()
+    bad[2, 4, 100] = np.nan            # gds2 of line 2
+    bad[4, 0, 7] = -1.0                # bmag < 0 on line 4: f < 0
+    r = ctx.gamma_scan(h, *[np.ascontiguousarray(bad[:, k]) for k in range(7)], dP, t0, want_info=True)
+    st = np.asarray(r["info"]) >> 16
+    assert r["nbad"] == 32 and (st[[2, 4]] == 2).all() and (st[[0, 1, 3, 5]] == 0).all()
+    ok = [0, 1, 3, 5]
+    assert np.array_equal(np.asarray(r["gam"])[ok], np.asarray(good["gam"])[ok])
+
+
 def test_config3_shape_ncsx_1025_tiled(ctx, bo):
     """NCSX-shape config (N_zeta = 1024, 16 theta0 per line) on tiled golden lines vs the C oracle"""
     from oracle import c_oracle as co
