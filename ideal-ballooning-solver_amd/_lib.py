@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libibs_hip.so")
+LIB_PATH = os.environ.get("IBS_LIB_PATH") or os.path.join(_HERE, "lib", "libibs_hip.so")   # (override: compiler-flag experiments)
 
 MEM_DEVICE = 0
 MEM_HOST = 1
