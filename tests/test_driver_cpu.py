@@ -146,3 +146,24 @@ def test_two_rank_gloo_dof_allreduce():
         p.join(60)
         assert p.exitcode == 0
     assert res[0] == res[1] == [10.0 + k for k in range(7)]
+
+
+def test_surface_tables_weight_matrices_match_reference_splines():
+    """host logic of row F1: SurfaceTables.from_wout applies the radial not-a-knot splines as cached weight matrices;
+    its tables against the values the reference's own splines produced (G8), and the theta grid helper (A0)"""
+    import ibs_amd
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    ref = np.load(os.path.join(G, "G8_surface_tables.npz"))
+    tab = ibs_amd.SurfaceTables.from_wout(wout, ref["s"])
+    from ibs_amd.geometry import NAMES_MN, NAMES_NYQ
+    for q, k in enumerate(NAMES_MN):
+        assert np.abs(tab.tab_mn[:, q] - ref[k]).max() <= 1e-12 * max(1.0, np.abs(ref[k]).max()), k
+    for q, k in enumerate(NAMES_NYQ):
+        assert np.abs(tab.tab_nyq[:, q] - ref[k]).max() <= 1e-12 * max(1.0, np.abs(ref[k]).max()), k
+    for col, k in ((1, "iota"), (2, "d_iota_d_s"), (3, "d_pressure_d_s")):
+        assert np.abs(tab.scal[:, col] - ref[k]).max() <= 1e-12 * max(1.0, np.abs(ref[k]).max()), k
+    again = ibs_amd.SurfaceTables.from_wout(wout, ref["s"])            # cached weights: identical tables
+    assert np.array_equal(again.tab_mn, tab.tab_mn) and np.array_equal(again.tab_nyq, tab.tab_nyq)
+    th = ibs_amd.theta_grid(969)
+    assert len(th) == 969 and th[0] == -4 * np.pi and th[-1] == 4 * np.pi and abs((th[1] - th[0]) - 8 * np.pi / 968) < 1e-15
