@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark of the ballooning hot path on MI355X (contract: task statement, section 4).
 
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ...` the ranks come from the
+environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); run directly (`python bench.py --gpus N`) the parent spawns the
+N rank processes itself BEFORE anything touches the GPU and exits with their status.  WORLD_SIZE must equal --gpus.
 
 One step = one pass of the hot path over one batch: the D3D-shape configuration of
 BASELINE.json (configs[1]): 16 flux surfaces x 8 alpha x 8 theta0 = 1,024 field-line eigen-solves
 on N_zeta=512 (513-point) grids, FP64, geometry resident in HBM.  A step is the geometry-fed scan
 kernel + the per-surface argmax kernel (+ for N>1 one RCCL all-gather of the per-surface maxima).
-Weak scaling: every rank processes its own 16-surface batch.
+Weak scaling: every rank processes its own 16-surface batch.  With N > 1 the line also carries `ncsx_c2_sharded`:
+BASELINE.json configs[2] (64 surfaces x 32 alpha x 16 theta0, N_zeta = 1024) with the surfaces sharded round-robin over
+the ranks (geometry -> scan -> argmax on each rank's own surfaces, ONE all-gather of the per-surface rows), checked
+bitwise against the table rank 0 computes alone.
 
 Prints ONE JSON line on rank 0 (metric/unit from BASELINE.json) with `roofline` (dominant kernel
 k_gamma_scan, HIP-event timed) and `cpu_baseline` (C oracle on the host cores, bounded sample);
@@ -35,6 +42,16 @@ def pmc_traffic(kernel_prefix):
         if k.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
             return v["hbm_bytes_per_launch"]
     return None
+
+
+def pmc_set_name():
+    """name of the profile set profiles/pmc_current.json was summarised from (its "_set" entry), or 'unnamed'"""
+    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
+    if os.path.exists(fn):
+        v = json.load(open(fn)).get("_set")
+        if isinstance(v, str):
+            return v
+    return "unnamed"
 
 
 def pmc_value(kernel_prefix, key):
@@ -313,6 +330,114 @@ def ncsx_pipeline(ctx, device):
     return out
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters, so nothing has
+    touched the GPU before they start), wait for all of them, return the worst exit code.  If one rank dies the others
+    are stopped (by PID) instead of waiting in a collective for ever."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0:
+                rc = rc or (r if r > 0 else 1)
+                for q in alive:
+                    q.terminate()
+    return rc
+
+
+def sharded_surface_pass(local_rows, n_surf, rank, world, dist):
+    """one pass of a surface-sharded scan (ball_scan.py:172, 251-252: one process group per surface): this rank's
+    surfaces -> local_rows(own) = (len(own), k) tensor -> ONE all-gather -> (n_surf, k) in surface order everywhere.
+    No other collective is on the data path."""
+    import ibs_amd
+    own = ibs_amd.shard_surfaces(n_surf, rank, world)
+    return ibs_amd.gather_rows_tensor(local_rows(own), n_surf, rank, world, dist)
+
+
+class C2Sharded:
+    """BASELINE.json configs[2]: NCSX, 64 surfaces x 32 alpha x 16 theta0, N_zeta = 1024 (1,025 points), from the shipped
+    equilibrium's wout tables; rows = (gam_max, alpha*, theta0*) of the coarse scan per surface (ball_scan.py:279-295)."""
+    NS, NA, NT0, N = 64, 32, 16, 1025
+
+    def __init__(self, ctx, device):
+        import torch
+        import ibs_amd
+        wout = dict(np.load(os.path.join(ROOT, "tests", "golden", "G8_wout_ncsx_op.npz")))
+        self.ctx, self.device = ctx, device
+        self.tabs = ibs_amd.SurfaceTables.from_wout(wout, np.linspace(0.1, 0.95, self.NS))
+        self.th = ibs_amd.theta_grid(self.N)
+        self.h = float(self.th[1] - self.th[0])
+        self.alphas = np.linspace(0, np.pi, self.NA)
+        self.alphas_d = torch.from_numpy(self.alphas).to(device)
+        self.t0_d = torch.from_numpy(np.linspace(0, np.pi / 2, self.NT0)).to(device)
+
+    def local_rows(self, own):
+        import torch
+        if len(own) == 0:
+            return torch.empty((0, 3), dtype=torch.float64, device=self.device)
+        surf = np.repeat(np.asarray(own), self.NA); al = np.tile(self.alphas, len(own))
+        r = self.ctx.fieldline_geometry(self.tabs, surf, al, self.th, device=self.device)
+        sc = self.ctx.gamma_scan(self.h, *[r["geo"][k] for k in range(7)], r["dPdrho"], self.t0_d)
+        idx, val = self.ctx.surface_argmax(sc["gam"].reshape(len(own), -1))
+        idx = idx.long()
+        return torch.stack([val, self.alphas_d[idx // self.NT0], self.t0_d[idx % self.NT0]], dim=1)
+
+
+def c2_sharded_leg(ctx, device, rank, world, dist, fence, passes=20):
+    """the north-star multi-GPU leg: strong scaling of configs[2] over the ranks.  Returns the leg's dict on rank 0."""
+    import torch
+    import ibs_amd
+    job = C2Sharded(ctx, device)
+    full = sharded_surface_pass(job.local_rows, job.NS, rank, world, dist)        # warm-up + the table to check
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        full = sharded_surface_pass(job.local_rows, job.NS, rank, world, dist)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    out = None
+    if rank == 0:
+        # the same surfaces on ONE GPU: (a) with the launches the ranks made (one per shard) -- must agree bitwise, the
+        # gather only moves rows; (b) as a single 64-surface launch -- other theta0 chaining / lanes per system, i.e.
+        # other shift sequences: agreement to rounding of the solver (1e-10 asserted), not bitwise
+        per_shard = torch.empty_like(full)
+        for r in range(world):
+            own = ibs_amd.shard_surfaces(job.NS, r, world)
+            per_shard[own] = job.local_rows(own)
+        one_launch = job.local_rows(list(range(job.NS)))
+        torch.cuda.synchronize()
+        bitwise = bool(torch.equal(per_shard, full))
+        dmax = float((one_launch[:, 0] - full[:, 0]).abs().max().item())
+        same_arg = bool(torch.equal(one_launch[:, 1:], full[:, 1:]))
+        assert bitwise, "gathered per-surface table differs from the same launches on one GPU"
+        assert dmax < 1e-10, "sharded vs single-launch gam_max differ by %g" % dmax
+        n = job.NS * job.NA * job.NT0
+        out = dict(workload="configs[2]: 64 surfaces x 32 alpha x 16 theta0 = %d solves, N_zeta=1024, NCSX_op wout tables; "
+                            "surfaces round-robin over %d ranks, geometry -> scan -> argmax per rank, ONE all-gather of "
+                            "[n_surf_local, 3]" % (n, world),
+                   scaling="strong", n_gpus=world, passes=passes, ms_per_pass=dt / passes * 1e3,
+                   solves_per_s=n * passes / dt, gathered_equals_one_gpu_bitwise=bitwise,
+                   max_abs_dgam_vs_single_launch=dmax, same_argmax_as_single_launch=same_arg,
+                   gam_max_min=float(full[:, 0].min().item()), gam_max_max=float(full[:, 0].max().item()))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,19 +448,37 @@ def main():
     ap.add_argument("--stress-systems", type=int, default=262144)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import ibs_amd
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become the launcher.  Nothing GPU-related has been imported or called in this process.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    import ibs_amd
+
     force_dist = os.environ.get("IBS_BENCH_FORCE_DIST") == "1"   # rehearsal of the N > 1 path with a 1-rank RCCL group
-    if args.gpus > 1 or world > 1 or force_dist:
+    # IBS_BENCH_SHARE_GPU=1: rehearsal of N ranks on a one-GPU box (every rank on device 0; RCCL refuses two ranks on one
+    # device, so the collectives then go through gloo on host copies).  Never set by the driver.
+    share = os.environ.get("IBS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
+    backend = "gloo" if share else "nccl"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     ctx = ibs_amd.Context(local)
@@ -344,12 +487,14 @@ def main():
     plan = ibs_amd.ScanPlan(ctx, h, geo7, dP_d, th0_d, N_SURF)
     n_solves = N_SURF * N_ALPHA * N_THETA0
     use_dist = dist.is_available() and dist.is_initialized()
+    n_ranks = dist.get_world_size() if use_dist else 1
+    coll_dev = device if backend == "nccl" else torch.device("cpu")
     # N > 1: the per-surface maxima of every step are all-gathered in-stream (replaces comm_lead.Gather x3,
     # ball_scan.py:345-347; 256 B per rank, latency-bound).  Overlapping the collective with the next scan on a side
     # stream was measured (1-rank RCCL group, IBS_BENCH_FORCE_DIST=1): the two event dependencies per step cost more
     # stream time on this platform (60 us per step) than the collective they hide (39 us in-stream vs 30 us without);
     # async_op=True from a ring of buffers is host-bound in torch's Work bookkeeping (56 us per step).
-    gathered = torch.empty((world, N_SURF, 2), dtype=torch.float64, device=device) if use_dist else None
+    gathered = torch.empty((n_ranks, N_SURF, 2), dtype=torch.float64, device=coll_dev) if use_dist else None
 
     def step(k=0, ev=None):
         if ev is not None:
@@ -359,7 +504,7 @@ def main():
             ev[1].record()
         plan.argmax()
         if use_dist:
-            dist.all_gather_into_tensor(gathered, plan.pack)
+            dist.all_gather_into_tensor(gathered, plan.pack if backend == "nccl" else plan.pack.cpu())
 
     def fence():
         if use_dist:
@@ -368,10 +513,19 @@ def main():
 
     for k in range(args.warmup):
         step(k)
+    # clocks: whatever --warmup says, at least 150 ms of untimed steps run before the timed region (a 20-step driver
+    # run is 0.7 ms long: without this it would be measured on an idle chip's clocks)
+    torch.cuda.synchronize()
+    t_spin = time.perf_counter()
+    n_spin = 0
+    while time.perf_counter() - t_spin < 0.15:
+        for k in range(64):
+            step(k)
+        torch.cuda.synchronize()
+        n_spin += 64
     fence()
     # the dominant kernel is timed live with HIP events inside the timed region, on every 8th step (an event
-    # pair costs ~6 us of stream time, more than the per-surface argmax kernel: bracketing every step would
-    # measure the events)
+    # pair costs stream time: bracketing every step would measure the events)
     EV = 8
     n_ev = (args.steps + EV - 1) // EV
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
@@ -381,42 +535,69 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kern_ms_live = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # the same bracket in an UNTIMED pass on every launch, and the cost of an empty bracket (two event records with
+    # nothing between them) subtracted: the live figure above still contains it, which is how a 'kernel' could read
+    # longer than the step that contains it
+    n_un = 200
+    un = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_un)]
+    emp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_un)]
+    for (a, b), (c, d) in zip(un, emp):
+        a.record(); plan.scan(); b.record()
+        plan.argmax()
+        c.record(); d.record()
+    torch.cuda.synchronize()
+    kern_ms_raw = float(np.mean([a.elapsed_time(b) for a, b in un]))
+    empty_ms = float(np.median([c.elapsed_time(d) for c, d in emp]))
+    kern_ms = max(kern_ms_raw - empty_ms, 0.0)
     if use_dist:      # every rank holds every rank's maxima of the last step; its own row must be what it sent
-        assert torch.equal(gathered[rank], plan.pack), "all-gather result does not match the local maxima"
+        assert torch.equal(gathered[rank].to(device), plan.pack), "all-gather result does not match the local maxima"
     info = plan.info.cpu().numpy()
     nbad = int(((info >> 16) != 0).sum())
     sweeps = float((info & 0xffff).mean())
+
+    c2 = c2_sharded_leg(ctx, device, rank, world, dist, fence) if (use_dist and backend == "nccl" or (use_dist and share)) else None
 
     if rank == 0:
         bytes_per_solve = (7 * NPTS * 8 + 8) / N_THETA0 + 8            # geometry-fed path
         alg_bytes = n_solves * bytes_per_solve
         gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+        pmc_src = "profiles/pmc_current.json (committed rocprofv3 --pmc passes of this workload, set %s; replayed, " \
+                  "not measured by this run)" % pmc_set_name()
         out = {
             "metric": "field-line eigenvalue solves/sec (N_zeta=512)",
-            "value": world * n_solves * args.steps / dt,
+            "value": n_ranks * n_solves * args.steps / dt,
             "unit": "solves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (NCSX_op-derived field-line geometry, perturbed per line)",
             "config": {"workload": "configs[1] D3D-shape: 16 surfaces x 8 alpha x 8 theta0 = 1024 solves/step/GPU, "
                                    "N_zeta=512 (513 points), geometry-fed scan + per-surface argmax"
-                                   + (" + RCCL all-gather of the per-surface maxima" if use_dist else ""),
+                                   + (" + all-gather (%s, %d ranks) of the per-surface maxima" % (
+                                       "RCCL" if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
-                       "nonconverged": nbad},
+                       "nonconverged": nbad, "ranks_in_collective": n_ranks,
+                       "untimed_spinup_steps": args.warmup + n_spin},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("ibs::k_gamma_scan<double"),
+                         "traffic_source": pmc_src,
                          "kernel": "k_gamma_scan<double,8>", "kernel_ms": kern_ms,
+                         "kernel_ms_how": "HIP events around every launch of an untimed 200-step pass after the timed "
+                                          "region, minus the cost of an empty event bracket",
+                         "kernel_ms_raw_untimed": kern_ms_raw, "event_bracket_ms": empty_ms,
+                         "kernel_ms_live_raw": kern_ms_live,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          # what actually binds (committed PMC pass, profiles/pmc_current.json): VALU instructions per
                          # wave and the fraction of the wave's lifetime its SIMD's VALU is busy (1 wave per SIMD here)
                          "valu_insts_per_wave": pmc_value("ibs::k_gamma_scan<double", "valu_insts_per_wave"),
                          "valu_busy_frac": pmc_value("ibs::k_gamma_scan<double", "valu_busy_frac_of_wave_lifetime"),
-                         "note": "FP64-VALU-issue bound, not HBM bound: see DESIGN.md"},
+                         "counters_source": pmc_src,
+                         "note": "FP64-VALU-issue bound, not HBM bound (DESIGN.md 4); every step re-scans the same "
+                                 "3.7 MB of geometry, which stays in L2 / Infinity Cache: 'HBM' is nominal for this leg"},
         }
         # the bound that does bind: wave64 VALU instructions issued per second against one instruction per SIMD per
         # 4 clocks (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz), instruction count from the committed PMC pass
@@ -426,6 +607,8 @@ def main():
             ach = vi * n_solves / (kern_ms * 1e-3)
             out["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak_issue, "unit": "wave-instructions/s",
                                              "frac": ach / peak_issue}
+        if c2 is not None:
+            out["ncsx_c2_sharded"] = c2
         if world == 1 and not args.no_cpu:
             cb, gam_cpu = cpu_baseline(h, base, dP, theta0)
             out["cpu_baseline"] = cb

@@ -24,6 +24,7 @@ SYMBOLS = {
     "ibs_destroy": (C.c_int, [_P]),
     "ibs_set_stream": (C.c_int, [_P, _P]),
     "ibs_synchronize": (C.c_int, [_P]),
+    "ibs_set_option": (C.c_int, [_P, C.c_char_p, _D]),
     "ibs_device_count": (C.c_int, []),
     "ibs_solve_gcf_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
     "ibs_solve_gcfh_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),

@@ -14,17 +14,6 @@
 #include "ibs_wave.hpp"
 
 namespace ibs {
-struct GeoArgs {
-  int n_surf, mnmax, mnmax_nyq, n_lines, N;
-  const double *xm, *xn, *xm_nyq, *xn_nyq;
-  const double* tab_mn; const double* tab_nyq; const double* scal;
-  const int* line_surf; const double* line_alpha; const double* theta;
-  long ld; double* geo; double* dPdrho;
-  int nrows_mn, nrows_nyq; const int* rows_mn; const int* rows_nyq;
-  double dn_mn, dn_nyq;
-};
-hipError_t launch_geometry(const GeoArgs& a, hipStream_t st);   // ibs_geometry.hip
-
 LaunchTable& launch_table() {
   static LaunchTable t{};
   return t;
@@ -47,7 +36,18 @@ static int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(IBS_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+// Diagnostic overrides of the dispatch heuristics (0 = automatic).  Read ONCE from the environment when the context is
+// created (IBS_FORCE_P, IBS_SCAN_CHAIN, IBS_CHAIN_W1, IBS_CHAIN_W2, IBS_GEO_LPP), changed afterwards only through
+// ibs_set_option(): no getenv() on the call path, nothing process-global.
+struct ibs_options {
+  int force_p = 0;        // lanes per system: 64 | 32 | 16
+  int scan_chain = 0;     // theta0 values chained through one wave / group
+  int geo_lpp = 0;        // lanes per grid point of the geometry kernel: 1 | 2 | 4
+  double chain_w1 = 0.25, chain_w2 = 1.0;   // relative widths of the chain's warm starts
+};
+
 struct ibs_ctx {
+  ibs_options opt, opt_created;
   int device = 0;
   hipStream_t stream = nullptr;
   // staging workspace for IBS_MEM_HOST calls (grown on demand, reused)
@@ -58,6 +58,21 @@ struct ibs_ctx {
 };
 
 namespace {
+
+// every entry point runs on the context's device and leaves the caller's current device as it found it
+struct DeviceGuard {
+  int prev = -1; hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) err = hipSetDevice(dev); else prev = -1;     // (nothing to restore)
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(ctx_)                                                                                     \
+  DeviceGuard dev_guard_((ctx_)->device);                                                                   \
+  if (dev_guard_.err != hipSuccess) return fail(IBS_ERR_HIP, "hipSetDevice(%d) -> %s", (ctx_)->device, hipGetErrorString(dev_guard_.err))
 
 struct Arena {  // carve device buffers out of the context workspace
   ibs_ctx* c; size_t off = 0;
@@ -89,12 +104,12 @@ int rows_per_lane(int N) { return (N - 2 + 63) / 64; }
 
 // lanes per system.  64 = one wave per system (lowest latency, any N).  Large batches of short grids are
 // throughput (VALU-issue) bound: 32 / 16 lanes per system amortise the scan over 2 / 4 systems per wave.
-// IBS_FORCE_P=64|32|16 overrides (tests).
+// option force_p = 64|32|16 overrides (tests).
 int pick_lanes(const ibs_ctx* ctx, int N, long n_sys) {
   const int n = N - 2;
   const bool can32 = n <= 32 * 20 && n >= 32 * 3 + 1, can16 = n <= 16 * 16 && n >= 16 * 3 + 1;
-  if (const char* e = getenv("IBS_FORCE_P")) {
-    const int f = atoi(e);
+  if (ctx->opt.force_p) {
+    const int f = ctx->opt.force_p;
     if (f == 32 && can32) return 32;
     if (f == 16 && can16) return 16;
     return 64;
@@ -184,7 +199,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   if (n_sys == 0) return 0;
   int M = rows_per_lane(N);
   if (!table[M]) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   auto launch = table[M];
   size_t per_wave = (size_t)3 * ibs::lds_pitch(N) * sizeof(T);
   if constexpr (sizeof(T) == 8) {
@@ -380,7 +395,6 @@ int ibs_create(ibs_ctx** out, int device_id) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) return fail(IBS_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
   if (device_id < 0 || device_id >= n) return fail(IBS_ERR_ARG, "device %d out of range (0..%d)", device_id, n - 1);
-  HIPCHK(hipSetDevice(device_id));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_id));
   ibs_ctx* c = new ibs_ctx();
@@ -389,13 +403,19 @@ int ibs_create(ibs_ctx** out, int device_id) {
   if (prop.maxSharedMemoryPerMultiProcessor > (size_t)c->lds_per_block) c->lds_per_block = (int)prop.maxSharedMemoryPerMultiProcessor;
   if (c->lds_per_block > 160 * 1024) c->lds_per_block = 160 * 1024;
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("IBS_FORCE_P")) c->opt.force_p = atoi(e);
+  if (const char* e = getenv("IBS_SCAN_CHAIN")) c->opt.scan_chain = atoi(e);
+  if (const char* e = getenv("IBS_GEO_LPP")) c->opt.geo_lpp = atoi(e);
+  if (const char* e = getenv("IBS_CHAIN_W1")) c->opt.chain_w1 = atof(e);
+  if (const char* e = getenv("IBS_CHAIN_W2")) c->opt.chain_w2 = atof(e);
+  c->opt_created = c->opt;
   *out = c;
   return 0;
 }
 
 int ibs_destroy(ibs_ctx* c) {
   if (!c) return 0;
-  hipSetDevice(c->device);
+  DeviceGuard g(c->device);
   if (c->ws) hipFree(c->ws);
   delete c;
   return 0;
@@ -407,9 +427,23 @@ int ibs_set_stream(ibs_ctx* c, void* s) {
   return 0;
 }
 
+int ibs_set_option(ibs_ctx* c, const char* name, double value) {
+  if (!c || !name) return fail(IBS_ERR_ARG, "null context / name");
+  const bool reset = !(value == value);          // NaN: back to what ibs_create() read from the environment
+  const std::string n(name);
+  if (n == "force_p") c->opt.force_p = reset ? c->opt_created.force_p : (int)value;
+  else if (n == "scan_chain") c->opt.scan_chain = reset ? c->opt_created.scan_chain : (int)value;
+  else if (n == "geo_lpp") c->opt.geo_lpp = reset ? c->opt_created.geo_lpp : (int)value;
+  else if (n == "chain_w1") c->opt.chain_w1 = reset ? c->opt_created.chain_w1 : value;
+  else if (n == "chain_w2") c->opt.chain_w2 = reset ? c->opt_created.chain_w2 : value;
+  else if (n == "all" && reset) c->opt = c->opt_created;
+  else return fail(IBS_ERR_ARG, "unknown option '%s'", name);
+  return 0;
+}
+
 int ibs_synchronize(ibs_ctx* c) {
   if (!c) return fail(IBS_ERR_ARG, "null context");
-  HIPCHK(hipSetDevice(c->device));
+  ON_DEVICE(c);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -449,7 +483,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   int M = rows_per_lane(N);
   auto fn = ibs::launch_table().scan_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const size_t per_arr = (size_t)ibs::lds_pitch(N) * sizeof(double);
   if (8 * per_arr > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
   int G = 1, cap = ibs::scan_max_threads(M) / 64;
@@ -485,7 +519,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   // Batches much larger than the chip (one wave per system, no caller-supplied guesses): chain consecutive theta0
   // values of a line through one wave, each solve warm-started from the previous eigenvalue (k_gamma_scan_chain).
   // 4 per wave once that still leaves two waves per SIMD, 2 from there down to two waves of chained work per SIMD
-  // (tools/bench_chain_sizes.py).  IBS_SCAN_CHAIN=n overrides.
+  // (tools/bench_chain_sizes.py).  option scan_chain = n overrides.
   if (G > 1 && fn_g_chain) {
     // sub-wave kernels: the same chain over the theta0 slots of a group; caller-supplied guesses go through the same
     // kernel with a chain of one
@@ -495,7 +529,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
     if (!lam_guess) {
       if (slots >= 4 && waves >= 8 * simds) chain = 4;
       else if (slots >= 2 && waves >= 4 * simds) chain = 2;
-      if (const char* e = getenv("IBS_SCAN_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= slots) chain = v; }
+      if (ctx->opt.scan_chain >= 1 && ctx->opt.scan_chain <= slots) chain = ctx->opt.scan_chain;
     }
     if (chain > 1 || lam_guess) {
       const bool need_x = X || dX;
@@ -507,9 +541,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
         const int nb = (wpl + (int)w - 1) / (int)w;
         a.wpb = (wpl + nb - 1) / nb;
         a.chain = chain;
-        a.chain_w1 = 0.25; a.chain_w2 = 1.0;
-        if (const char* e = getenv("IBS_CHAIN_W1")) a.chain_w1 = atof(e);
-        if (const char* e = getenv("IBS_CHAIN_W2")) a.chain_w2 = atof(e);
+        a.chain_w1 = ctx->opt.chain_w1; a.chain_w2 = ctx->opt.chain_w2;
         fn = fn_g_chain;
       } else if (lam_guess) {
         return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
@@ -521,7 +553,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
     int chain = 1;
     if (n_theta0 >= 8 && waves >= 8 * simds) chain = 4;
     else if (n_theta0 >= 4 && waves >= 4 * simds) chain = 2;      // (N = 1025: 2,048 solves 70 vs 95 us, 4,096: 111 vs 105 us)
-    if (const char* e = getenv("IBS_SCAN_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= n_theta0) chain = v; }
+    if (ctx->opt.scan_chain >= 1 && ctx->opt.scan_chain <= n_theta0) chain = ctx->opt.scan_chain;
     auto fc = ibs::launch_table().scan_chain_f64[M];
     if (chain > 1 && fc) {
       const bool need_x = (M < 3) || X || dX;
@@ -533,9 +565,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
         const int nb = (wpl + (int)w - 1) / (int)w;
         a.wpb = (wpl + nb - 1) / nb;
         a.chain = chain;
-        a.chain_w1 = 0.25; a.chain_w2 = 1.0;     // measured on the NCSX shapes (tools/bench_chain.py): 9.2 sweeps per solve instead of 15.7
-        if (const char* e = getenv("IBS_CHAIN_W1")) a.chain_w1 = atof(e);
-        if (const char* e = getenv("IBS_CHAIN_W2")) a.chain_w2 = atof(e);
+        a.chain_w1 = ctx->opt.chain_w1; a.chain_w2 = ctx->opt.chain_w2;     // defaults 0.25 / 1.0 measured on the NCSX shapes (tools/bench_chain.py): 9.2 sweeps per solve instead of 15.7
         fn = fc;
       }
     }
@@ -616,7 +646,7 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
   const int M = rows_per_lane(N);
   auto fn = ibs::launch_table().grad_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const size_t per_wave = (size_t)8 * ibs::lds_pitch(N) * sizeof(double);
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
@@ -672,9 +702,10 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
       !tab_mn || !tab_nyq || !scal || !line_surf || !line_alpha || !theta || !geo)
     return fail(IBS_ERR_ARG, "bad arguments");
   if (n_lines == 0) return 0;
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   ibs::GeoArgs a{};
   a.n_surf = n_surf; a.mnmax = mnmax; a.mnmax_nyq = mnmax_nyq; a.n_lines = n_lines; a.N = N; a.ld = ld;
+  a.lpp = ctx->opt.geo_lpp;
   if (mem == IBS_MEM_HOST) {
     for (int i = 0; i < n_lines; ++i)
       if (line_surf[i] < 0 || line_surf[i] >= n_surf) return fail(IBS_ERR_ARG, "line_surf[%d]=%d out of range", i, line_surf[i]);
@@ -722,7 +753,7 @@ int ibs_hf_grad_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, const double* X, con
     return fail(IBS_ERR_ARG, "bad arguments");
   if (N < 3 || !(N & 1)) return fail(IBS_ERR_UNSUPPORTED, "N=%d: the Simpson rule of the reference needs N odd", N);
   if (n_sys == 0) return 0;
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const dim3 grid((unsigned)((n_sys + 3) / 4));
   if (mem == IBS_MEM_HOST) {
     const size_t ne = (size_t)n_sys * ld;
@@ -759,7 +790,7 @@ int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const 
   const int M = rows_per_lane(N);
   auto fn = ibs::launch_table().sturm_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const size_t per_wave = (size_t)N * sizeof(double);
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
@@ -793,7 +824,7 @@ int ibs_surface_argmax_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per, const do
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
   if (n_surf < 0 || n_per <= 0 || !gam || !idx || !val) return fail(IBS_ERR_ARG, "bad arguments");
   if (n_surf == 0) return 0;
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   if (mem == IBS_MEM_HOST) {
     const size_t ne = (size_t)n_surf * n_per;
     if (int r = ensure_ws(ctx, pad256(ne * 8) + pad256(n_surf * 8) + pad256(n_surf * 4) + 4096)) return r;
@@ -816,7 +847,7 @@ int ibs_surface_argmax_pack_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_per, con
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
   if (n_surf < 0 || n_per <= 0 || !gam || !pack) return fail(IBS_ERR_ARG, "bad arguments");
   if (n_surf == 0) return 0;
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(argmax_threads(n_per)), 0, ctx->stream, n_per, gam, (int*)nullptr, (double*)nullptr, pack);
   HIPCHK(hipGetLastError());
   return 0;
@@ -835,7 +866,7 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
       !tab_nyq || !scal || !pt_surf || !start || !theta || !x_opt || !f_opt || !(del_alpha > 0) || maxiter < 0)
     return fail(IBS_ERR_ARG, "bad arguments");
   if (n_pts == 0) return 0;
-  HIPCHK(hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const bool host = (mem == IBS_MEM_HOST);
   // theta must be uniform; h from its ends (checked on the host copy)
   std::vector<double> th_h(N > 0 ? N : 0);
@@ -874,6 +905,7 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   auto up = [&](const void* src, size_t bytes, void* dst) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st); };
   ibs::GeoArgs ga{};
   ga.n_surf = n_surf; ga.mnmax = mnmax; ga.mnmax_nyq = mnmax_nyq; ga.n_lines = n_lines; ga.N = N; ga.ld = ld;
+  ga.lpp = ctx->opt.geo_lpp;
   if (host) {
     double* d_xm = ar.take<double>(mnmax); double* d_xn = ar.take<double>(mnmax);
     double* d_xmq = ar.take<double>(mnmax_nyq); double* d_xnq = ar.take<double>(mnmax_nyq);

@@ -15,25 +15,6 @@
 
 namespace ibs {
 
-struct GeoArgs {     // must match the declaration in ibs_api.hip
-  int n_surf, mnmax, mnmax_nyq, n_lines, N;
-  const double *xm, *xn, *xm_nyq, *xn_nyq;
-  const double* tab_mn;    // [n_surf][6][mnmax]      rmnc zmns lmns d_rmnc_d_s d_zmns_d_s d_lmns_d_s
-  const double* tab_nyq;   // [n_surf][7][mnmax_nyq]  gmnc bmnc d_bmnc_d_s bsupvmnc bsubsmns bsubumnc bsubvmnc
-  const double* scal;      // [n_surf][6]             s iota d_iota_d_s d_pressure_d_s phiedge Aminor_p
-  const int* line_surf; const double* line_alpha; const double* theta;
-  long ld;
-  double* geo;             // [8][n_lines][ld]  bmag gradpar cvdrift cvdrift0 gds2 gds21 gds22 gbdrift
-  double* dPdrho;          // [n_lines]
-  // optional row structure of the mode lists (VMEC order: modes grouped by m, consecutive n inside a group):
-  // rows_*[r] = {first mode index, number of modes}; the angle then advances by -dphi_n per mode and only
-  // one sincos per row is needed.  nrows_* = 0 selects the generic one-sincos-per-mode kernel.
-  int nrows_mn, nrows_nyq;
-  const int* rows_mn;      // [nrows_mn][2]
-  const int* rows_nyq;     // [nrows_nyq][2]
-  double dn_mn, dn_nyq;    // common n-spacing inside the rows of each set (rows with another spacing are split by the host)
-};
-
 // metric algebra shared by both kernels: utils.py:474 (flux sign), :480-508 (dual relations), :515-538
 // (grad psi, grad alpha), :603-618 / :646-650 (B x grad B . grad alpha / psi), :654-720 (GS2 normalisation)
 #define GEO_TAIL \
@@ -75,7 +56,7 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry(GeoArgs a) {
   const int line = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= a.N) return;
-  const int js = a.line_surf[line];
+  const int js = min(max(a.line_surf[line], 0), a.n_surf - 1);   // (device-resident indices are not range-checked by the C ABI)
   const double* sc = a.scal + 6 * js;
   const double s = sc[0], iota = sc[1], diota = sc[2], dp = sc[3], phiedge = sc[4], L = sc[5];
   const double alpha = a.line_alpha[line];
@@ -232,7 +213,7 @@ template <int LPP>
 __device__ __forceinline__ void geo_rows_body(const GeoArgs& a) {
   extern __shared__ __align__(16) unsigned char geo_smem[];
   const int line = blockIdx.y;
-  const int js = a.line_surf[line];
+  const int js = min(max(a.line_surf[line], 0), a.n_surf - 1);   // (device-resident indices are not range-checked by the C ABI)
   const int nr1 = a.nrows_mn, nr2 = a.nrows_nyq;
   const int P = geo_cap(a.mnmax, nr1), Q = geo_cap(a.mnmax_nyq, nr2);
   double* lm_s = reinterpret_cast<double*>(geo_smem);
@@ -456,7 +437,7 @@ hipError_t launch_geometry(const GeoArgs& a, hipStream_t st) {
     }
     const long blocks1 = (long)((a.N + kGeoBlock - 1) / kGeoBlock) * a.n_lines;
     int lpp = blocks1 * 4 <= n_cu ? 4 : (blocks1 * 2 <= n_cu ? 2 : 1);
-    if (const char* e = getenv("IBS_GEO_LPP")) lpp = atoi(e);
+    if (a.lpp == 1 || a.lpp == 2 || a.lpp == 4) lpp = a.lpp;
     auto go = [&](auto kern, int l) {
       hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e1 != hipSuccess) return e1;

@@ -34,6 +34,28 @@ struct GradArgs {
   long arr_stride, line_stride;   // 0 = the [n_pts][3][8][ld] layout (ld, 8 ld); see k_obj_w_grad
 };
 
+// field-line geometry kernel (ibs_geometry.hip)
+struct GeoArgs {
+  int n_surf, mnmax, mnmax_nyq, n_lines, N;
+  const double *xm, *xn, *xm_nyq, *xn_nyq;
+  const double* tab_mn;    // [n_surf][6][mnmax]      rmnc zmns lmns d_rmnc_d_s d_zmns_d_s d_lmns_d_s
+  const double* tab_nyq;   // [n_surf][7][mnmax_nyq]  gmnc bmnc d_bmnc_d_s bsupvmnc bsubsmns bsubumnc bsubvmnc
+  const double* scal;      // [n_surf][6]             s iota d_iota_d_s d_pressure_d_s phiedge Aminor_p
+  const int* line_surf; const double* line_alpha; const double* theta;
+  long ld;
+  double* geo;             // [8][n_lines][ld]  bmag gradpar cvdrift cvdrift0 gds2 gds21 gds22 gbdrift
+  double* dPdrho;          // [n_lines]
+  // optional row structure of the mode lists (VMEC order: modes grouped by m, consecutive n inside a group):
+  // rows_*[r] = {first mode index, number of modes}; the angle then advances by -dphi_n per mode and only
+  // one sincos per row is needed.  nrows_* = 0 selects the generic one-sincos-per-mode kernel.
+  int nrows_mn, nrows_nyq;
+  const int* rows_mn;      // [nrows_mn][2]
+  const int* rows_nyq;     // [nrows_nyq][2]
+  double dn_mn, dn_nyq;    // common n-spacing inside the rows of each set (rows with another spacing are split by the host)
+  int lpp;                 // lanes per grid point: 0 = chosen from the batch size, else 1 | 2 | 4
+};
+hipError_t launch_geometry(const GeoArgs& a, hipStream_t st);
+
 struct LaunchTable {
   hipError_t (*gcf_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
   hipError_t (*gcf_f32[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);

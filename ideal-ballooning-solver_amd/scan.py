@@ -34,27 +34,35 @@ def pick_start(gam_table, alpha_scan, theta0_scan):
     return float(alpha_scan[i]), float(theta0_scan[j]), 1.3 * abs(float(gam_table[i, j])) + 0.05, (i, j)
 
 
+def gather_rows_tensor(local, n_surf, rank, world, dist):
+    """ONE all-gather of per-surface rows held as a torch tensor (device tensor: RCCL, in-stream; CPU tensor: gloo).
+    local: (n_local, k) rows of the surfaces shard_surfaces(n_surf, rank, world) lists.  Returns (n_surf, k) in surface
+    order on every rank (replaces the three comm_lead.Gather of ball_scan.py:345-347)."""
+    import torch
+    k = local.shape[1]
+    if world == 1:
+        return local.clone()
+    n_max = (n_surf + world - 1) // world
+    pad = torch.full((n_max, k), float("nan"), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * n_max, k), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    # row of surface j: rank j % world, slot j // world
+    j = torch.arange(n_surf, device=local.device)
+    return out[(j % world) * n_max + j // world]
+
+
 def gather_surfaces(local, n_surf, rank, world, dist=None, device=None):
     """all-gather of per-surface rows.  local: (n_local, k) rows of the surfaces shard_surfaces() lists.
     Returns (n_surf, k) on every rank (replaces ball_scan.py:345-347)."""
     local = np.asarray(local, dtype=np.float64)
-    k = local.shape[1]
     if world == 1:
         return local.copy()
     import torch
-    n_max = (n_surf + world - 1) // world
-    pad = torch.full((n_max, k), float("nan"), dtype=torch.float64)
-    pad[: local.shape[0]] = torch.from_numpy(local)
+    t = torch.from_numpy(np.ascontiguousarray(local))
     if device is not None:
-        pad = pad.to(device)
-    out = torch.empty((world * n_max, k), dtype=torch.float64, device=pad.device)
-    dist.all_gather_into_tensor(out, pad)
-    out = out.cpu().numpy().reshape(world, n_max, k)
-    full = np.empty((n_surf, k))
-    for r in range(world):
-        own = shard_surfaces(n_surf, r, world)
-        full[own] = out[r, : len(own)]
-    return full
+        t = t.to(device)
+    return gather_rows_tensor(t, n_surf, rank, world, dist).cpu().numpy()
 
 
 class BallooningScan:

@@ -86,6 +86,15 @@ class Context:
     def synchronize(self):
         check(self._lib.ibs_synchronize(self._h), "ibs_synchronize")
 
+    def set_option(self, name, value):
+        """diagnostic override of a dispatch heuristic of this context (include/ibs.h: ibs_set_option);
+        value None = back to the context's default"""
+        check(self._lib.ibs_set_option(self._h, name.encode(), float("nan") if value is None else float(value)),
+              "ibs_set_option")
+
+    def reset_options(self):
+        self.set_option("all", None)
+
     # ---- raw (g, c, f) systems --------------------------------------------------------------
     def solve_gcf(self, h, g, c, f, want_X=False, want_info=False, dtype=np.float64, gh=None):
         """g, c, f: (n_sys, N).  Returns dict(lam, gam[, X, dX][, info]).  gh (n_sys, N) optional half-grid g
@@ -349,12 +358,20 @@ class ScanPlan:
                            MEM_DEVICE)
         self._amax_args = [(ctx._h, n_surf, (n_lines // n_surf) * n_t0, p(self.gam), p(pk)) for pk in self.packs]
 
+    def _use_current_stream(self):
+        # the Context's stream is shared mutable state: launch on the caller's CURRENT torch stream, like every other
+        # Context call (a plan used under torch.cuda.stream(s) must be ordered against that stream's tensors)
+        import torch
+        self.lib.ibs_set_stream(self.ctx._h, C.c_void_p(torch.cuda.current_stream(self.gam.device).cuda_stream))
+
     def scan(self):
+        self._use_current_stream()
         rc = self.lib.ibs_gamma_scan_f64(*self._scan_args)
         if rc < 0:
             check(rc, "ibs_gamma_scan_f64")
 
     def argmax(self, slot=0):
+        self._use_current_stream()
         rc = self.lib.ibs_surface_argmax_pack_f64(*self._amax_args[slot])
         if rc < 0:
             check(rc, "ibs_surface_argmax_pack_f64")

@@ -363,6 +363,80 @@ def make_G8():
          phiedge=np.array(vs.phiedge), Aminor_p=np.array(vs.Aminor_p), nfp=np.array(vs.nfp), **out)
 
 
+def _scan_and_refine(vs, s, N, tight):
+    """the per-surface body of ball_scan.py:223-339 (coarse 24 x 15 scan with the warm-start chain, argmax rule,
+    L-BFGS-B refinement, final solve with the stale start vector and sigma = 0.42), run through the reference's own
+    gamma_ball_full / obj_w_grad / vmec_fieldlines; every objective evaluation of the refinement is recorded."""
+    from scipy.optimize import minimize
+    import contextlib
+    ctx = tight_arpack() if tight else contextlib.nullcontext()
+    th = theta_grid(N)
+    vguess = vguess_of(th)
+    theta0_scan = np.linspace(0.0, 0.5 * np.pi, 15)
+    alpha_scan = np.linspace(0, np.pi, 24)
+    with ctx:
+        G = line_geometry(vs, s, alpha_scan, th)
+        gam_tab = np.zeros((24, 15))
+        vg_tab = np.zeros((24, 15, N - 2))
+        for i in range(24):
+            for j in range(15):
+                dP, gam, X, dX, g, c, f = solve_line(G[i], th, theta0_scan[j], vguess, 1.0)
+                vguess = X[1:-1]                                   # ball_scan.py:272-274
+                vg_tab[i, j] = vguess
+                gam_tab[i, j] = gam
+        idx = np.where(gam_tab == np.max(gam_tab))                 # ball_scan.py:283-295 (first maximum on ties)
+        i0, j0 = idx[0][0], idx[1][0]
+        vg0 = vg_tab[i0, j0]
+        sigma0 = 1.3 * abs(gam_tab[i0, j0]) + 0.05
+        trace = []
+
+        def fun(x):
+            val, jac = ref.obj_w_grad(x, vs, s, th, vg0, sigma0)
+            trace.append((x[0], x[1], val, jac[0], jac[1]))
+            return val, jac
+
+        res = minimize(fun, x0=(alpha_scan[i0], theta0_scan[j0]), jac=True,
+                       bounds=((0.0, np.pi), (0.0, 0.5 * np.pi)),
+                       options={"ftol": 5.0e-11, "gtol": 2.0e-08, "maxiter": 30})
+        Gf = line_geometry(vs, s, res.x[0], th)
+        gam_f = solve_line(Gf[0], th, res.x[1], vg0, 0.42)[1]
+    return dict(gam_table=gam_tab, argmax=np.array([i0, j0]), trace=np.array(trace), x_opt=np.array(res.x),
+                gam_opt=float(gam_f), fun=float(res.fun), nit=int(res.nit), nfev=int(res.nfev), status=int(res.status),
+                message=str(res.message))
+
+
+def make_G5T():
+    """G5 again with the reference's ARPACK call converged (tight_arpack): the L-BFGS-B trajectory is then free of
+    ARPACK noise and can be compared point for point.  Same surface, grid and geometry as G5 (not stored again)."""
+    vs = ncsx_splines()
+    r = _scan_and_refine(vs, 0.8483, 513, tight=True)
+    print("G5T", r["x_opt"], r["gam_opt"], len(r["trace"]), r["message"], flush=True)
+    save("G5_scan_trace_tight.npz", s=np.array(0.8483), N=np.array(513), gam_table=r["gam_table"], argmax=r["argmax"],
+         trace=r["trace"], x_opt=r["x_opt"], gam_opt=np.array(r["gam_opt"]), fun=np.array(r["fun"]),
+         nit=np.array(r["nit"]), nfev=np.array(r["nfev"]), status=np.array(r["status"]), message=np.array(r["message"]))
+
+
+def make_G9():
+    """Refinement goldens on the reference's own NCSX grid (N = 969, ball_scan.py:203-208) for several surfaces:
+    coarse table, argmax, the FULL evaluation trace of scipy's L-BFGS-B (ball_scan.py:305-314), x_opt and the final
+    gam (ball_scan.py:322-339) -- once with ARPACK converged ('tight': the pin) and once as shipped (tol 5e-7: shows
+    how far the reference's own ARPACK noise moves its optimum)."""
+    vs = ncsx_splines()
+    svals = [0.5, 0.6125, 0.7, 0.8483, 0.95]
+    out = {}
+    for k, s in enumerate(svals):
+        for tag, tight in (("tight", True), ("shipped", False)):
+            t = time.time()
+            r = _scan_and_refine(vs, s, 969, tight=tight)
+            print("G9 s=%g %s: x_opt=%s gam_opt=%.12e evals=%d nit=%d '%s' (%.0f s)" %
+                  (s, tag, r["x_opt"], r["gam_opt"], len(r["trace"]), r["nit"], r["message"], time.time() - t), flush=True)
+            for name in ("gam_table", "argmax", "trace", "x_opt"):
+                out["%s_%s_%d" % (name, tag, k)] = r[name]
+            for name in ("gam_opt", "fun", "nit", "nfev", "status", "message"):
+                out["%s_%s_%d" % (name, tag, k)] = np.array(r[name])
+    save("G9_refine_traces.npz", s=np.array(svals), N=np.array(969), **out)
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
     for name in todo:

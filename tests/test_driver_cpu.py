@@ -167,3 +167,92 @@ def test_surface_tables_weight_matrices_match_reference_splines():
     assert np.array_equal(again.tab_mn, tab.tab_mn) and np.array_equal(again.tab_nyq, tab.tab_nyq)
     th = ibs_amd.theta_grid(969)
     assert len(th) == 969 and th[0] == -4 * np.pi and th[-1] == 4 * np.pi and abs((th[1] - th[0]) - 8 * np.pi / 968) < 1e-15
+
+
+def test_history_files_with_the_reference_0d_placeholder(tmp_path):
+    # arr_create2.py:87-97 creates np.empty([]) (0-d) placeholders; ball_scan.py:369-375 replaces them at iteration 0
+    ibs_amd.create_history_placeholders(str(tmp_path), 2)
+    assert np.load(tmp_path / "ball_gam2.npy").shape == ()
+    g = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    out = ibs_amd.append_history(str(tmp_path), 2, 0, g, g + 10, g + 20)
+    for k, off in (("ball_gam", 0), ("ball_theta0", 10), ("ball_alpha", 20)):
+        assert out[k].shape == (5,) and np.array_equal(np.load(tmp_path / ("%s2.npy" % k)), g + off)
+    out = ibs_amd.append_history(str(tmp_path), 2, 1, 2 * g, g, g)
+    assert out["ball_gam"].shape == (2, 5)
+    # what sims_runner_NCSX.py:198 reads: the last row
+    assert np.array_equal(np.load(tmp_path / "ball_gam2.npy")[-1], 2 * g)
+
+
+def test_params_dict_reader_and_grid_rule(tmp_path):
+    import pickle
+    # the dict create_dict.py:143-160 writes for eqbm_option = 1 (NCSX): 72 boundary DOFs (create_dict.py:29-34, 47-55)
+    d = dict(maxf=100, eqbm_option=1, pol_idxs=np.array([0, 1, 2, 3, 4, 5, 6]), tor_idxs=np.array([4, 3, 3, 2, 2, 2, 1]),
+             iotaidxs=np.array([]), isphifree=0, totalndofs=72, nsurfs=5, abs_step=1.0e-3, rel_step=2.0e-3,
+             username="u", nprocspernode=96, nodesperball=8, totalnexecball=73, njobsball=2, nodespersimsopt=1)
+    assert set(d) == set(ibs_amd.PARAMS_KEYS)
+    with open(tmp_path / "params_dict.pkl", "wb") as f:
+        pickle.dump(d, f)
+    cfg = ibs_amd.load_params_dict(str(tmp_path / "params_dict.pkl"))
+    assert cfg.n_equilibria == 73 and cfg.nsurfs == 5 and (cfg.nalpha, cfg.ntheta0) == (24, 15)
+    assert np.array_equal(cfg.rho_arr, np.linspace(0.5, 0.95, 5))                       # ball_scan.py:197
+    assert (cfg.gamma_thresh, cfg.prefac) == (-2.0e-4, 50.0)                            # sims_runner_NCSX.py:56-57
+    assert cfg.dof_step(5e-3) == 1e-3 and abs(cfg.dof_step(0.5) - 1e-3) < 1e-18        # ball_scan.py:129-139
+    d3d = dict(d, eqbm_option=0, pol_idxs=np.array([1, 2, 3]), tor_idxs=np.array([1, 3, 5]), totalndofs=6)
+    assert ibs_amd.ScanConfig(d3d).n_equilibria == 7 and ibs_amd.ScanConfig(d3d).prefac == 2.0
+    with pytest.raises(ibs_amd.IbsError):
+        ibs_amd.ScanConfig(dict(d, totalndofs=70))
+    # ball_scan.py:201-208: D3D (mpol 80, ntor 0) -> 641 points, NCSX / HBERG (mpol = ntor = 11) -> 969
+    assert len(ibs_amd.theta_grid_for(80, 0)) == 641 and len(ibs_amd.theta_grid_for(11, 11)) == 969
+    th = ibs_amd.theta_grid_for(11, 11)
+    assert th[0] == -4 * np.pi and th[-1] == 4 * np.pi and np.array_equal(th, ibs_amd.theta_grid(969))
+
+
+def _worker_bench(rank, world, port, q):
+    """bench.py's own sharded pass (sharded_surface_pass + gather_rows_tensor) under gloo with CPU tensors"""
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_surf = 7
+
+    def local_rows(own):     # what C2Sharded.local_rows returns on a GPU: (gam_max, alpha*, theta0*) per own surface
+        return torch.tensor([[100.0 + s, 0.5 * s, 0.25 * s] for s in own], dtype=torch.float64).reshape(len(own), 3)
+
+    full = bench.sharded_surface_pass(local_rows, n_surf, rank, world, dist)
+    q.put((rank, full.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_sharded_pass_gloo(world):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_bench, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [[100.0 + s, 0.5 * s, 0.25 * s] for s in range(7)]
+    for r in range(world):
+        assert res[r] == want
+
+
+def test_bench_refuses_mismatched_world_and_spawns_before_gpu():
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not match --gpus" in r.stderr
+    # without a launcher --gpus 2 starts two rank processes (which fail here: no GPU), and the parent reports it
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

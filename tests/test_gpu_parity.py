@@ -17,6 +17,15 @@ def ctx():
     return ibs_amd.Context(0)
 
 
+@pytest.fixture(autouse=True)
+def _default_dispatch(ctx):
+    """tests steer kernel variants through the context's option setter (ibs_set_option); every test starts and ends
+    with the library's own dispatch"""
+    ctx.reset_options()
+    yield
+    ctx.reset_options()
+
+
 @pytest.fixture(scope="module")
 def bo():
     from oracle import ballooning_oracle
@@ -424,10 +433,10 @@ def test_chained_scan_matches_unchained(ctx, bo, chain, nt0, monkeypatch):
     th = bo.theta_grid(1025)
     t0 = np.linspace(0, np.pi / 2, nt0)
     a = [np.ascontiguousarray(geo[:, k]) for k in range(7)]
-    monkeypatch.setenv("IBS_SCAN_CHAIN", "1")
+    ctx.set_option("scan_chain", "1")
     ref = ctx.gamma_scan(th[1] - th[0], *a, dP, t0, want_X=True, want_dtheta0=True, want_info=True)
     for w1, w2 in (("0.5", "1.0"), ("1e-6", "1e-6"), ("50", "50")):
-        monkeypatch.setenv("IBS_SCAN_CHAIN", str(chain)); monkeypatch.setenv("IBS_CHAIN_W1", w1); monkeypatch.setenv("IBS_CHAIN_W2", w2)
+        ctx.set_option("scan_chain", str(chain)); ctx.set_option("chain_w1", w1); ctx.set_option("chain_w2", w2)
         r = ctx.gamma_scan(th[1] - th[0], *a, dP, t0, want_X=True, want_dtheta0=True, want_info=True)
         assert r["nbad"] == 0
         # lam is certified to 256 ulp(||A||) (~3e-11 here); gam is second order in the eigenvector error
@@ -437,7 +446,7 @@ def test_chained_scan_matches_unchained(ctx, bo, chain, nt0, monkeypatch):
         rn = ctx.gamma_scan(th[1] - th[0], *a, dP, t0)                       # no X: no per-wave LDS row
         assert np.abs(rn["gam"] - ref["gam"]).max() < 1e-11
     sw_ref = (np.asarray(ref["info"]) & 0xffff).mean()
-    monkeypatch.setenv("IBS_CHAIN_W1", "0.5"); monkeypatch.setenv("IBS_CHAIN_W2", "1.0")
+    ctx.set_option("chain_w1", "0.5"); ctx.set_option("chain_w2", "1.0")
     r = ctx.gamma_scan(th[1] - th[0], *a, dP, t0, want_info=True)
     assert (np.asarray(r["info"]) & 0xffff).mean() < sw_ref                 # the chain saves sweeps
 
@@ -456,9 +465,9 @@ def test_subwave_chained_and_warm_scan(ctx, bo, N, P, chain, nt0, monkeypatch):
     t0 = np.linspace(0, np.pi / 2, nt0)
     a = [np.ascontiguousarray(geo[:, k]) for k in range(7)]
     h = th[1] - th[0]
-    monkeypatch.setenv("IBS_FORCE_P", "64"); monkeypatch.setenv("IBS_SCAN_CHAIN", "1")
+    ctx.set_option("force_p", "64"); ctx.set_option("scan_chain", "1")
     ref = ctx.gamma_scan(h, *a, dP, t0, want_X=True, want_dtheta0=True, want_info=True)
-    monkeypatch.setenv("IBS_FORCE_P", str(P)); monkeypatch.setenv("IBS_SCAN_CHAIN", str(chain))
+    ctx.set_option("force_p", str(P)); ctx.set_option("scan_chain", str(chain))
     r = ctx.gamma_scan(h, *a, dP, t0, want_X=True, want_dtheta0=True, want_info=True)
     rn = ctx.gamma_scan(h, *a, dP, t0, want_info=True)
     for q in (r, rn):
@@ -469,7 +478,7 @@ def test_subwave_chained_and_warm_scan(ctx, bo, N, P, chain, nt0, monkeypatch):
     sw = lambda q: (np.asarray(q["info"]) & 0xffff).mean()
     assert sw(rn) < sw(ref)
     # caller-supplied guesses (ibs_gamma_scan_warm_f64) through the sub-wave kernel
-    monkeypatch.setenv("IBS_SCAN_CHAIN", "1")
+    ctx.set_option("scan_chain", "1")
     pert = [x.copy() for x in a]
     for k in (4, 5, 6):
         pert[k] *= 1.002
@@ -492,7 +501,7 @@ def test_chained_scan_flags_invalid_lines_only(ctx, bo, P, monkeypatch):
     th = bo.theta_grid(513)
     t0 = np.linspace(0, np.pi / 2, 16)
     h = th[1] - th[0]
-    monkeypatch.setenv("IBS_FORCE_P", str(P)); monkeypatch.setenv("IBS_SCAN_CHAIN", "4")
+    ctx.set_option("force_p", str(P)); ctx.set_option("scan_chain", "4")
     good = ctx.gamma_scan(h, *[np.ascontiguousarray(geo[:, k]) for k in range(7)], dP, t0, want_info=True)
     assert good["nbad"] == 0
     bad = geo.copy()
@@ -531,13 +540,13 @@ def test_subwave_variants_match_full_wave(ctx, bo, N, P):
     th, g, c = salpha_batch(bo, N, params)
     f = g * (1 + 0.3 * np.cos(th))[None]
     h = th[1] - th[0]
-    os.environ["IBS_FORCE_P"] = "64"
+    ctx.set_option("force_p", "64")
     try:
         ref = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
-        os.environ["IBS_FORCE_P"] = str(P)
+        ctx.set_option("force_p", str(P))
         r = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
     finally:
-        os.environ.pop("IBS_FORCE_P", None)
+        ctx.set_option("force_p", None)
     assert r["nbad"] == 0 and ((r["info"] >> 16) == 0).all()
     assert np.abs(r["lam"] - ref["lam"]).max() < 1e-10 and np.abs(r["gam"] - ref["gam"]).max() < 1e-10
     assert np.abs(r["X"] - ref["X"]).max() < 1e-7 and np.abs(r["dX"] - ref["dX"]).max() < 1e-6
@@ -552,14 +561,14 @@ def test_subwave_scan_matches_full_wave(ctx, bo):
     th = bo.theta_grid(513)
     a = [np.ascontiguousarray(geo[:, k, :]) for k in range(7)]
     t0 = np.linspace(0, np.pi / 2, 8)
-    os.environ["IBS_FORCE_P"] = "64"
+    ctx.set_option("force_p", "64")
     try:
         ref = ctx.gamma_scan(th[1] - th[0], *a, g3["dPdrho_513"], t0, want_X=True, want_dtheta0=True)
-        os.environ["IBS_FORCE_P"] = "32"
+        ctx.set_option("force_p", "32")
         r = ctx.gamma_scan(th[1] - th[0], *a, g3["dPdrho_513"], t0, want_X=True, want_dtheta0=True, want_info=True)
         r5 = ctx.gamma_scan(th[1] - th[0], *a, g3["dPdrho_513"], t0[:5])     # 5 theta0: falls back to full waves
     finally:
-        os.environ.pop("IBS_FORCE_P", None)
+        ctx.set_option("force_p", None)
     assert r["nbad"] == 0
     assert np.abs(r["gam"] - ref["gam"]).max() < 1e-10 and np.abs(r["lam"] - ref["lam"]).max() < 1e-10
     assert np.abs(r["dgam_dtheta0"] - ref["dgam_dtheta0"]).max() < 1e-9
@@ -620,10 +629,10 @@ def test_F1_geometry_lanes_per_point_variants_agree(ctx, bo, monkeypatch):
     surf = [0, 0, 1, 1, 1]; al = [0.0, 1.3, 0.4, 2.0, np.pi]
     out = {}
     for lpp in ("1", "2", "4"):
-        monkeypatch.setenv("IBS_GEO_LPP", lpp)
+        ctx.set_option("geo_lpp", lpp)
         r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))
         out[lpp] = (r["geo"].cpu().numpy(), r["dPdrho"].cpu().numpy())
-    monkeypatch.delenv("IBS_GEO_LPP")
+    ctx.set_option("geo_lpp", None)
     r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))     # automatic choice (4 here)
     auto = r["geo"].cpu().numpy()
     scale = np.abs(out["1"][0]).max(axis=2, keepdims=True)

@@ -9,3 +9,8 @@ eps = rng.uniform(-0.03, 0.03, size=(nl, 2))
 base[:, 4:7, :] *= (1 + eps[:, 0])[:, None, None]; base[:, 2:4, :] *= (1 + eps[:, 1])[:, None, None]; base[:, 7, :] *= (1 + eps[:, 1])[:, None]
 dP = -0.5 * np.mean((base[:, 2] - base[:, 7]) * base[:, 0] ** 2, axis=1); th0 = np.linspace(0, 0.5 * np.pi, nt)
 np.concatenate([np.ascontiguousarray(base[:, k, :]).ravel() for k in range(7)] + [dP, th0]).tofile(os.path.join(ROOT, "tools", "d3d_geo.bin" if N == 513 and nl == 128 else "geo_%d_%d_%d.bin" % (N, nl, nt)))
+# raw (g, c, f) dumps of single systems of that batch for tools/trace_solve.hip:  python tools/make_d3d_geo.py 513 128 8 --sys 17 402
+if "--sys" in sys.argv:
+    for k in (int(v) for v in sys.argv[sys.argv.index("--sys") + 1:]):
+        l, t = divmod(k, nt); b = base[l]; gp = np.abs(b[1]); gd = b[4] + 2 * th0[t] * b[5] + th0[t] ** 2 * b[6]
+        np.concatenate([gp * gd / b[0], -dP[l] * (b[2] + th0[t] * b[3]) / (gp * b[0]), gd / b[0] ** 2 / (gp * b[0])]).tofile(os.path.join(ROOT, "tools", "sys_%d_%d.bin" % (N, k)))

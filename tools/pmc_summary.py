@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 --pmc CSVs (separate FETCH_SIZE / WRITE_SIZE / SQ passes of tools/profile_run.py)
-into profiles/<tag>_pmc.json.   usage: tools/pmc_summary.py gpurun_out/pmc_r01 profiles/r01_pmc.json"""
+into profiles/<tag>_pmc.json.   usage: tools/pmc_summary.py gpurun_out/pmc_r01 profiles/r01_pmc.json [set-name]
+(the set name is stored under "_set": bench.py quotes it next to every counter it replays from this file)"""
 import collections
 import csv
 import json
@@ -23,7 +24,7 @@ for tag in ("fetch", "write", "sq"):
     for k, v in acc.items():
         for c, vals in v.items():
             out[k][c] = dict(mean=sum(vals) / len(vals), n=len(vals))
-for k, v in out.items():
+for k, v in list(out.items()):
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of
         # the bytes of a coalesced streaming read -> double it; WRITE_SIZE is exact.
@@ -31,5 +32,6 @@ for k, v in out.items():
     if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
         v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"]["mean"] / v["SQ_WAVES"]["mean"]
         v["valu_busy_frac_of_wave_lifetime"] = v["SQ_ACTIVE_INST_VALU"]["mean"] / v["SQ_WAVE_CYCLES"]["mean"]
+out["_set"] = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(dst).replace("_pmc.json", "")
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
