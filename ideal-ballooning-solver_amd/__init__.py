@@ -9,4 +9,5 @@ from .operators import gamma_ball_full, dPdrho_of, uniform_spacing, make_obj_w_g
 from .scan import BallooningScan, shard_surfaces, gather_surfaces, gather_rows_tensor, pick_start, append_history, GEO_ORDER  # noqa: F401
 from .geometry import SurfaceTables  # noqa: F401
 from .config import ScanConfig, load_params_dict, theta_grid_for, create_history_placeholders, PARAMS_KEYS  # noqa: F401
+from .lbfgsb import minimize2  # noqa: F401
 from .objective import ballooning_objective, dof_fd_gradient, dof_steps, shard_dofs, allreduce_dof_vector  # noqa: F401

@@ -25,6 +25,10 @@ SYMBOLS = {
     "ibs_set_stream": (C.c_int, [_P, _P]),
     "ibs_synchronize": (C.c_int, [_P]),
     "ibs_set_option": (C.c_int, [_P, C.c_char_p, _D]),
+    "ibs_lbfgsb2_state_bytes": (C.c_int, []),
+    "ibs_lbfgsb2_init": (C.c_int, [_P, _P, _P, _P, _D, _D, _I32, _I32]),
+    "ibs_lbfgsb2_step": (C.c_int, [_P, _D, _P, _P]),
+    "ibs_lbfgsb2_result": (C.c_int, [_P, _P, _P, _P]),
     "ibs_device_count": (C.c_int, []),
     "ibs_solve_gcf_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
     "ibs_solve_gcfh_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),

@@ -12,6 +12,7 @@
 #include "../../include/ibs.h"
 #include "ibs_launch.hpp"
 #include "ibs_wave.hpp"
+#include "ibs_lbfgsb2.hpp"
 
 namespace ibs {
 LaunchTable& launch_table() {
@@ -258,53 +259,32 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
 
 
 // ---------------------------------------------------------------- (alpha, theta0) maximiser state machine (row F2)
-// One thread per evaluation point.  Mirrors the bounded quasi-Newton of BallooningScan.refine_batched
-// (projected BFGS + Armijo backtracking; same bounds, tolerances and iteration cap as the scipy L-BFGS-B call of
-// ball_scan.py:307-314), but every point advances on its own: no host round trip between evaluations.
+// One thread per evaluation point, each running the bounded quasi-Newton of ibs_lbfgsb2.hpp -- the L-BFGS-B that
+// scipy.optimize.minimize runs for ball_scan.py:307-314 (same bounds, ftol, gtol, maxiter, m = 10, maxls = 20) --
+// in reverse communication: a round = geometry of the requested points + fused objective/gradient + one step() per
+// point.  Every point advances on its own: no host round trip between evaluations.
 struct RefineState {
-  double x[2], f, g[2], H[4], pg[2], d[2], t, xt[2];
-  int phase;    // 0 = waiting for the first evaluation, 1 = line search
-  int ls, it, active, nev;
+  ibs::lbfgsb2::State q;
+  int active, nev;
 };
 struct RefineParams { double lo[2], hi[2], del_alpha, ftol, gtol; int maxiter, n_surf; };
-
-__device__ inline double clipd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // evaluation request of one point into slot j of the batch: the three field lines of utils.py:1641-1646 and theta0
 __device__ inline void refine_emit(const RefineState& s, const RefineParams& p, int j, int surf, int* line_surf,
                                    double* line_alpha, double* th0) {
-  const double a = s.active ? s.xt[0] : s.x[0];
+  const double a = s.q.x[0];
   for (int l = 0; l < 3; ++l) { line_surf[3 * j + l] = surf; line_alpha[3 * j + l] = a + (l - 1) * 0.5 * p.del_alpha; }
-  th0[j] = s.active ? s.xt[1] : s.x[1];
-}
-
-// start of a quasi-Newton iteration at (x, f, g): projected gradient test, direction, first trial step
-__device__ inline void refine_begin_iter(RefineState& s, const RefineParams& p) {
-  for (int i = 0; i < 2; ++i) {
-    double v = s.g[i];
-    if ((s.x[i] <= p.lo[i] && v > 0) || (s.x[i] >= p.hi[i] && v < 0)) v = 0.0;
-    s.pg[i] = v;
-  }
-  if (!(fmax(fabs(s.pg[0]), fabs(s.pg[1])) > p.gtol)) { s.active = 0; return; }
-  s.d[0] = -(s.H[0] * s.pg[0] + s.H[1] * s.pg[1]);
-  s.d[1] = -(s.H[2] * s.pg[0] + s.H[3] * s.pg[1]);
-  if (s.d[0] * s.pg[0] + s.d[1] * s.pg[1] >= 0) { s.d[0] = -s.pg[0]; s.d[1] = -s.pg[1]; }   // not a descent direction
-  const double nrm = fmax(fmax(fabs(s.d[0]), fabs(s.d[1])), 1e-300);
-  s.t = fmin(1.0, 0.3 / nrm);                                          // first trial step: at most 0.3 rad
-  s.ls = 0;
-  for (int i = 0; i < 2; ++i) s.xt[i] = clipd(s.x[i] + s.t * s.d[i], p.lo[i], p.hi[i]);
-  s.phase = 1;
+  th0[j] = s.q.x[1];
 }
 
 __global__ void k_refine_init(int n, const int* pt_surf, const double* start, RefineState* st, RefineParams p,
                               int* idx, int* line_surf, double* line_alpha, double* th0) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  RefineState s{};
-  for (int i = 0; i < 2; ++i) { s.x[i] = clipd(start[2 * k + i], p.lo[i], p.hi[i]); s.xt[i] = s.x[i]; }
-  s.H[0] = 1.0; s.H[3] = 1.0;
-  s.active = 1;
-  st[k] = s;
+  RefineState& s = st[k];                     // (the state lives in global memory; nothing of it is kept in registers)
+  const double x0[2] = {start[2 * k], start[2 * k + 1]};
+  ibs::lbfgsb2::init(s.q, x0, p.lo, p.hi, p.ftol, p.gtol, p.maxiter, 20);
+  s.active = 1; s.nev = 0;
   idx[k] = k;
   const int surf = min(max(pt_surf[k], 0), p.n_surf - 1);
   refine_emit(s, p, k, surf, line_surf, line_alpha, th0);
@@ -318,40 +298,11 @@ __global__ void k_refine_step(int n_c, const int* idx, const int* pt_surf, Refin
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_c) return;
   const int k = idx[j];
-  RefineState s = st[k];
+  RefineState& s = st[k];
   if (s.active) {
-    const double ft = val[j], gt[2] = {jac[2 * j], jac[2 * j + 1]};
+    const double g[2] = {jac[2 * j], jac[2 * j + 1]};
     s.nev++;
-    if (s.phase == 0) {
-      s.f = ft; s.g[0] = gt[0]; s.g[1] = gt[1]; s.it = 0;
-      refine_begin_iter(s, p);
-    } else {
-      const double dec = s.pg[0] * (s.xt[0] - s.x[0]) + s.pg[1] * (s.xt[1] - s.x[1]);
-      if (ft <= s.f + 1e-4 * dec) {                                  // Armijo: accept
-        const double sk[2] = {s.xt[0] - s.x[0], s.xt[1] - s.x[1]}, yk[2] = {gt[0] - s.g[0], gt[1] - s.g[1]};
-        const double sy = sk[0] * yk[0] + sk[1] * yk[1];
-        if (sy > 1e-14) {                                            // BFGS update of the inverse Hessian
-          const double rho = 1.0 / sy;
-          double V[4] = {1.0 - rho * sk[0] * yk[0], -rho * sk[0] * yk[1], -rho * sk[1] * yk[0], 1.0 - rho * sk[1] * yk[1]};
-          double VH[4] = {V[0] * s.H[0] + V[1] * s.H[2], V[0] * s.H[1] + V[1] * s.H[3],
-                          V[2] * s.H[0] + V[3] * s.H[2], V[2] * s.H[1] + V[3] * s.H[3]};
-          s.H[0] = VH[0] * V[0] + VH[1] * V[1] + rho * sk[0] * sk[0];
-          s.H[1] = VH[0] * V[2] + VH[1] * V[3] + rho * sk[0] * sk[1];
-          s.H[2] = VH[2] * V[0] + VH[3] * V[1] + rho * sk[1] * sk[0];
-          s.H[3] = VH[2] * V[2] + VH[3] * V[3] + rho * sk[1] * sk[1];
-        }
-        const bool small = fabs(s.f - ft) <= p.ftol * fmax(fmax(fabs(s.f), fabs(ft)), 1.0);
-        s.x[0] = s.xt[0]; s.x[1] = s.xt[1]; s.f = ft; s.g[0] = gt[0]; s.g[1] = gt[1];
-        s.it++;
-        if (small || s.it >= p.maxiter) s.active = 0;
-        else refine_begin_iter(s, p);
-      } else {
-        s.t *= 0.35; s.ls++;
-        if (s.ls >= 12) s.active = 0;                                // line search failed: stop this point
-        else for (int i = 0; i < 2; ++i) s.xt[i] = clipd(s.x[i] + s.t * s.d[i], p.lo[i], p.hi[i]);
-      }
-    }
-    st[k] = s;
+    if (!ibs::lbfgsb2::step(s.q, val[j], g)) s.active = 0;
   }
   const int surf = min(max(pt_surf[k], 0), p.n_surf - 1);
   refine_emit(s, p, j, surf, line_surf, line_alpha, th0);
@@ -373,7 +324,7 @@ __global__ void k_refine_compact(int n_c, const int* idx_in, int* idx_out, const
 __global__ void k_refine_out(int n, const RefineState* st, double* x_opt, double* f_opt, int* n_evals) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  x_opt[2 * k] = st[k].x[0]; x_opt[2 * k + 1] = st[k].x[1]; f_opt[k] = st[k].f; n_evals[k] = st[k].nev;
+  x_opt[2 * k] = st[k].q.x[0]; x_opt[2 * k + 1] = st[k].q.x[1]; f_opt[k] = st[k].q.f; n_evals[k] = st[k].nev;
 }
 }  // namespace
 
@@ -438,6 +389,34 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   else if (n == "chain_w2") c->opt.chain_w2 = reset ? c->opt_created.chain_w2 : value;
   else if (n == "all" && reset) c->opt = c->opt_created;
   else return fail(IBS_ERR_ARG, "unknown option '%s'", name);
+  return 0;
+}
+
+// ---- host side of the bounded quasi-Newton state machine (ibs_lbfgsb2.hpp): no GPU involved
+int ibs_lbfgsb2_state_bytes(void) { return (int)sizeof(ibs::lbfgsb2::State); }
+
+int ibs_lbfgsb2_init(void* state, const double* x0, const double* lo, const double* hi, double ftol, double gtol,
+                     int32_t maxiter, int32_t maxls) {
+  if (!state || !x0 || !lo || !hi) return fail(IBS_ERR_ARG, "null pointer");
+  if (!(lo[0] <= hi[0]) || !(lo[1] <= hi[1]) || maxiter < 0 || maxls < 1) return fail(IBS_ERR_ARG, "bad bounds / limits");
+  ibs::lbfgsb2::init(*static_cast<ibs::lbfgsb2::State*>(state), x0, lo, hi, ftol, gtol, maxiter, maxls);
+  return 0;
+}
+
+int ibs_lbfgsb2_step(void* state, double f, const double* g, double* x_next) {
+  if (!state || !g || !x_next) return fail(IBS_ERR_ARG, "null pointer");
+  auto& s = *static_cast<ibs::lbfgsb2::State*>(state);
+  const bool more = ibs::lbfgsb2::step(s, f, g);
+  x_next[0] = s.x[0]; x_next[1] = s.x[1];
+  return more ? 1 : 0;
+}
+
+int ibs_lbfgsb2_result(const void* state, double* x, double* f, int32_t* counters) {
+  if (!state) return fail(IBS_ERR_ARG, "null pointer");
+  const auto& s = *static_cast<const ibs::lbfgsb2::State*>(state);
+  if (x) { x[0] = s.x[0]; x[1] = s.x[1]; }
+  if (f) *f = s.f;
+  if (counters) { counters[0] = s.n_iterations; counters[1] = s.nfgv; counters[2] = s.task; counters[3] = s.n_restarts; counters[4] = s.nskip; }
   return 0;
 }
 
@@ -948,8 +927,9 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   const dim3 grd((unsigned)((n_pts + 127) / 128)), blk(128);
   hipLaunchKernelGGL(k_refine_init, grd, blk, 0, st, n_pts, d_ps, d_start, d_st, prm, d_idx[0], d_ls[0], d_la[0], d_t0[0]);
   HIPCHK(hipGetLastError());
-  // every round = one objective/gradient evaluation of every point still in the batch; at most 1 + 12 per iteration
-  const int max_rounds = 1 + 12 * (maxiter > 0 ? maxiter : 1);
+  // every round = one objective/gradient evaluation of every point still in the batch.  An iteration takes at most
+  // maxls = 20 line-search evaluations, and once more after a memory restart
+  const int max_rounds = 2 + 42 * (maxiter > 0 ? maxiter : 1);
   int rounds = 0, n_c = n_pts, cur = 0;
   while (rounds < max_rounds && n_c > 0) {
     const dim3 grc((unsigned)((n_c + 127) / 128));

@@ -150,69 +150,62 @@ class BallooningScan:
         return val.cpu().numpy(), jac.cpu().numpy()
 
     def refine_batched(self, starts, maxiter=30, ftol=5.0e-11, gtol=2.0e-8):
-        """bounded quasi-Newton (projected BFGS, Armijo backtracking) on (alpha, theta0) in
-        [0, pi] x [0, pi/2] for every owned surface at once -- the batched counterpart of the per-surface
-        scipy L-BFGS-B call of ball_scan.py:307-314 (same bounds, tolerances and iteration cap).
-        starts: (n, 2).  Returns (x_opt (n, 2), f_opt (n,) = -gam, n_evals)."""
+        """the per-surface L-BFGS-B of ball_scan.py:307-314 (same bounds, tolerances and iteration cap) for every owned
+        surface at once, driven from the host: one optimizer state per surface (csrc/ibs_lbfgsb2.hpp through the C ABI
+        ibs_lbfgsb2_*), and every round ONE batched geometry + objective launch for the surfaces still running.
+        The host-driven form of refine_device(), which it is tested against.
+        starts: (n, 2).  Returns (x_opt (n, 2), f_opt (n,) = -gam, rounds)."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.lib()
         lo = np.array([0.0, 0.0]); hi = np.array([np.pi, 0.5 * np.pi])
         surf = np.array([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own])
         n = len(surf)
+        p = lambda a: C.c_void_p(a.ctypes.data)
         x = np.clip(np.asarray(starts, dtype=np.float64).reshape(n, 2), lo, hi)
-        f, g = self.batched_obj_w_grad(surf, x)
-        nev = 1
-        H = np.tile(np.eye(2), (n, 1, 1))
+        states = [C.create_string_buffer(lib.ibs_lbfgsb2_state_bytes()) for _ in range(n)]
+        for k in range(n):
+            lib.ibs_lbfgsb2_init(states[k], p(x[k]), p(lo), p(hi), float(ftol), float(gtol), int(maxiter), 20)
         active = np.ones(n, dtype=bool)
-
-        def proj_grad(x, g):
-            pg = g.copy()
-            pg[(x <= lo) & (g > 0)] = 0.0
-            pg[(x >= hi) & (g < 0)] = 0.0
-            return pg
-
-        for it in range(maxiter):
-            pg = proj_grad(x, g)
-            active &= np.max(np.abs(pg), axis=1) > gtol
-            if not active.any():
-                break
-            dvec = -np.einsum("kij,kj->ki", H, pg)
-            bad = np.einsum("ki,ki->k", dvec, pg) >= 0          # not a descent direction: steepest descent
-            dvec[bad] = -pg[bad]
-            # first trial step: at most 0.3 rad, never beyond the box
-            nrm = np.maximum(np.max(np.abs(dvec), axis=1), 1e-300)
-            t = np.minimum(1.0, 0.3 / nrm)
-            xn = x.copy(); fn = f.copy(); gn = g.copy()
-            todo = active.copy()
-            for ls in range(12):
-                xt = np.clip(x + t[:, None] * dvec, lo, hi)
-                idx = np.nonzero(todo)[0]
-                ft, gt = self.batched_obj_w_grad(surf[idx], xt[idx])
-                nev += 1
-                ok = ft <= f[idx] + 1e-4 * np.einsum("ki,ki->k", pg[idx], xt[idx] - x[idx])
-                acc = idx[ok]
-                xn[acc] = xt[acc]; fn[acc] = ft[ok]; gn[acc] = gt[ok]
-                todo[acc] = False
-                t[idx[~ok]] *= 0.35
-                if not todo.any():
-                    break
-            active &= ~todo                                      # line search failed: stop that surface
-            sk = xn - x; yk = gn - g
-            sy = np.einsum("ki,ki->k", sk, yk)
-            for k in np.nonzero(active & (sy > 1e-14))[0]:       # BFGS update of the inverse Hessian
-                rho = 1.0 / sy[k]
-                V = np.eye(2) - rho * np.outer(sk[k], yk[k])
-                H[k] = V @ H[k] @ V.T + rho * np.outer(sk[k], sk[k])
-            small = np.abs(f - fn) <= ftol * np.maximum(np.maximum(np.abs(f), np.abs(fn)), 1.0)
-            x, f, g = xn, fn, gn
-            active &= ~small
-        return x, f, nev
+        rounds = 0
+        while active.any():
+            idx = np.nonzero(active)[0]
+            f, g = self.batched_obj_w_grad(surf[idx], x[idx])
+            rounds += 1
+            for q, k in enumerate(idx):
+                gk = np.ascontiguousarray(g[q], dtype=np.float64)
+                if not lib.ibs_lbfgsb2_step(states[k], float(f[q]), p(gk), p(x[k])):
+                    active[k] = False
+        fo = np.empty(n)
+        for k in range(n):
+            fk = C.c_double(0.0)
+            lib.ibs_lbfgsb2_result(states[k], p(x[k]), C.byref(fk), None)
+            fo[k] = fk.value
+        return x, fo, rounds
 
     def refine_device(self, starts, maxiter=30, ftol=5.0e-11, gtol=2.0e-8):
-        """the same maximisation with the quasi-Newton state machine on the device as well (ibs_refine_f64): no host
-        round trip per evaluation.  Returns (x_opt (n, 2), f_opt (n,) = -gam, evaluations per surface (n,))."""
+        """the same maximisation with the L-BFGS-B state machines on the device as well (ibs_refine_f64): no host
+        round trip per evaluation.  Returns (x_opt (n, 2), f_opt (n,) = -gam, evaluations per surface (n,)).
+        f_opt is the objective at the optimizer's last accepted iterate (scipy's res.fun); run() re-evaluates gam at
+        x_opt like ball_scan.py:322-339 does."""
         surf = np.array([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own])
         xo, fo, ne, _ = self.ctx.refine(self.tables, surf, np.asarray(starts, dtype=np.float64).reshape(len(surf), 2),
                                         self.theta, self.del_alpha, maxiter, ftol, gtol, device=self.device)
         return xo, fo, ne
+
+    def final_solve_device(self, xo):
+        """gam at the refined (alpha, theta0) of every owned surface: the final geometry + solve of ball_scan.py:322-339
+        (the value the reference stores; the optimizer's own f is the value at its last ACCEPTED iterate, which after a
+        collapsed line search is the same point, after a maxiter stop as well)."""
+        import torch
+        surf = np.array([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own])
+        r = self.ctx.fieldline_geometry(self.tables, surf, np.ascontiguousarray(xo[:, 0]), self.theta, device=self.device)
+        n = len(surf)
+        N = len(self.theta)
+        geo = r["geo"].reshape(8, n, 1, N).expand(8, n, 3, N).permute(1, 2, 0, 3).contiguous()   # only the centre line matters for val
+        t0 = torch.from_numpy(np.ascontiguousarray(xo[:, 1])).to(self.device)
+        val, _ = self.ctx.obj_w_grad(self.h, geo, t0, self.del_alpha)
+        return -val.cpu().numpy()
 
     def run(self, refine=True):
         """returns (theta0_arr, alpha_arr, gam_arr), each (nsurfs,), identical on every rank"""
@@ -221,7 +214,8 @@ class BallooningScan:
         if refine and self.tables is not None and self.device is not None and self.own:
             starts = np.array([pick_start(tab, self.alpha_scan, self.theta0_scan)[:2] for tab in tabs])
             xo, fo, _ = self.refine_device(starts)
-            local = np.stack([xo[:, 1], xo[:, 0], -fo], axis=1)
+            gam = self.final_solve_device(xo)                      # ball_scan.py:322-339: one more solve at the optimum
+            local = np.stack([xo[:, 1], xo[:, 0], gam], axis=1)
             full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device)
             return full[:, 0], full[:, 1], full[:, 2]
         for k, tab in zip(self.own, tabs):

@@ -46,6 +46,25 @@ int ibs_destroy(ibs_ctx* ctx);
 int ibs_set_stream(ibs_ctx* ctx, void* hip_stream);
 int ibs_synchronize(ibs_ctx* ctx);
 int ibs_device_count(void);
+/* Bounded quasi-Newton on the two unknowns (alpha, theta0), reverse communication, HOST side (no GPU involved).
+ * Replaces: the optimizer behind ball_scan.py:307-314, scipy.optimize.minimize(obj_w_grad, jac=True,
+ * bounds=((0, pi), (0, pi/2)), options={ftol, gtol, maxiter}) = scipy's L-BFGS-B (un-vendored dependency: scipy, pinned
+ * to 1.15.3 by the build container; algorithm L-BFGS-B 3.0, m = 10, maxls = 20), restated for n = 2 in
+ * csrc/ibs_lbfgsb2.hpp.  The same code runs per surface inside ibs_refine_f64; these entry points let a host drive
+ * it and let the CPU tests compare its trajectories with scipy's.
+ *   state: caller-owned buffer of ibs_lbfgsb2_state_bytes() bytes.
+ *   init:  x0 is clipped into [lo, hi]; the first evaluation is wanted at the clipped point (returned by step's
+ *          x_next convention: call ibs_lbfgsb2_result() for it, or clip yourself).
+ *   step:  hand over (f, g[2]) evaluated at the point last requested; returns 1 = evaluate at x_next[2],
+ *          0 = finished (x_next = result).
+ *   result: x[2], f, counters[5] = {iterations, evaluations, task code (10 = projected gradient <= gtol,
+ *          11 = f reduction <= ftol, 12 = abnormal line-search termination, 13 = maxiter), memory restarts, skipped updates}. */
+int ibs_lbfgsb2_state_bytes(void);
+int ibs_lbfgsb2_init(void* state, const double* x0, const double* lo, const double* hi, double ftol, double gtol,
+                     int32_t maxiter, int32_t maxls);
+int ibs_lbfgsb2_step(void* state, double f, const double* g, double* x_next);
+int ibs_lbfgsb2_result(const void* state, double* x, double* f, int32_t* counters);
+
 /* Diagnostic override of a dispatch heuristic of THIS context (tests, experiments; nothing upstream corresponds).
  * name: "force_p" (lanes per system 64|32|16), "scan_chain" (theta0 values chained through one wave),
  * "chain_w1" / "chain_w2" (relative widths of the chain's warm starts), "geo_lpp" (lanes per grid point of the

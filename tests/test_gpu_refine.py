@@ -90,3 +90,30 @@ def test_host_driven_lbfgsb_reproduces_the_reference_trajectory(ctx, case):
     assert np.abs(seen[:n, :2] - tr[:n, :2]).max() < 5e-7, np.abs(seen[:n, :2] - tr[:n, :2]).max(axis=1)
     assert np.abs(seen[:n, 2] - tr[:n, 2]).max() < 1e-9
     assert abs(a_opt - case["x_opt"][0]) < 2e-4 and abs(t_opt - case["x_opt"][1]) < 2e-3
+
+
+def test_device_lbfgsb_reaches_the_reference_optimum_on_every_golden_surface(ctx):
+    """ibs_refine_f64 (one L-BFGS-B state machine per surface ON the device, csrc/ibs_lbfgsb2.hpp) through
+    BallooningScan.run(): the five G9 surfaces in ONE batch on the reference's N = 969 grid, and G5's surface at
+    N = 513 -- (theta0*, alpha*, gam) against the reference's refined values; gam to 1e-8 (north star)."""
+    import ibs_amd
+    import torch
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    g9 = [c for c in CASES if c["tag"].startswith("G9")]
+    svals = np.array([c["s"] for c in g9])
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
+    scan = ibs_amd.BallooningScan(ctx, None, ibs_amd.theta_grid(969), svals, tables=tabs, device=torch.device("cuda:0"))
+    t0, al, gam = scan.run()
+    for k, c in enumerate(g9):
+        assert abs(gam[k] - c["gam_opt"]) < 1e-8, (k, gam[k], c["gam_opt"])
+        assert abs(gam[k] - c["gam_opt_shipped"]) < 1e-8          # ... and of the reference as shipped (ARPACK tol 5e-7)
+        assert abs(al[k] - c["x_opt"][0]) < 2e-4 and abs(t0[k] - c["x_opt"][1]) < 2e-3
+    # the optimizer's own evaluations against the reference's trace, point for point while both run (first 5)
+    starts = np.array([c["trace"][0, :2] for c in g9])
+    xo, fo, ne = scan.refine_device(starts)
+    xh, fh, rounds = scan.refine_batched(starts)
+    assert np.abs(fo - fh).max() < 1e-10
+    c5 = CASES[0]
+    scan5 = _scan(ctx, c5)
+    t0, al, gam = scan5.run()
+    assert abs(gam[0] - c5["gam_opt"]) < 1e-8, (gam[0], c5["gam_opt"])

@@ -34,6 +34,18 @@ for case in CASES:
     print("%s: evals %d (ref %d) nit %d '%s' first split at %d; x_opt %s ref %s; gam_opt %.12e ref %.12e (d %.2e)" % (
         case["tag"], len(seen), len(tr), res.nit, res.message, first, np.array([a_opt, t_opt]), case["x_opt"], gam_opt,
         case["gam_opt"], gam_opt - case["gam_opt"]))
-    if first >= 0:
+    if first >= 0 and os.environ.get("VERBOSE"):
         lo = max(first - 2, 0)
         print("  ours:\n", seen[lo:first + 3], "\n  ref:\n", tr[lo:first + 3])
+    # the same maximisation driven by the library's own optimizer (csrc/ibs_lbfgsb2.hpp through the C ABI)
+    scan.obj_w_grad = orig
+    out = ibs_amd.minimize2(lambda x: orig(x, case["s"]), (tr[0, 0], tr[0, 1]), ((0.0, np.pi), (0.0, 0.5 * np.pi)))
+    geo = np.asarray(scan.fieldlines(case["s"], np.array([out.x[0]])))[0]
+    dP = -0.5 * np.mean((geo[2] - geo[7]) * geo[0] ** 2)
+    r = ctx.gamma_scan(scan.h, *[geo[k][None] for k in range(7)], np.array([dP]), np.array([out.x[1]]))
+    g2 = float(np.asarray(r["gam"])[0, 0])
+    n2 = min(len(out.trace), len(tr))
+    dx2 = np.abs(out.trace[:n2, :2] - tr[:n2, :2]).max(axis=1)
+    f2 = int(np.argmax(dx2 > 1e-6)) if (dx2 > 1e-6).any() else -1
+    print("   lbfgsb2: evals %d nit %d '%s' restarts %d skipped %d split(1e-6) at %d; x_opt %s; gam_opt %.12e (d vs ref %.2e, vs scipy-host %.2e)" % (
+        len(out.trace), out.nit, out.message, out.restarts, out.skipped, f2, out.x, g2, g2 - case["gam_opt"], g2 - gam_opt))
