@@ -197,13 +197,16 @@ struct GroupSolver {
     zu_m1 = um;
     if constexpr (STORE) u0_in = u0;
     T zc = u0, zp = um;
-    int count = 0;
+    // (sign changes counted from ONE incoming pair per lane; the step into the next lane's first row belongs to that
+    //  lane: see WaveSolver::sweep_fwd)
+    const int ncount = (has_last ? M : M - 1) - (lg == P - 1 ? 0 : 1);
+    int count = sign_differs(u0, um) ? 1 : 0;                  // first lane of a group: (1, 0), no change
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const T t = xfma(-sig, Ph[i], D[i]);
       const bool act = (i < M - 1) || has_last;
       const T zn = xfma(-t, zc, -zp);
-      count += (act && sign_differs(zn, zc)) ? 1 : 0;
+      count += ((i < M - 2 || i < ncount) && sign_differs(zn, zc)) ? 1 : 0;
       if (act) { zp = zc; zc = zn; }
     }
     return GP::sum_i(count, lane);

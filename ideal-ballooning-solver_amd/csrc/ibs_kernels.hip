@@ -710,12 +710,15 @@ __global__ void __launch_bounds__(256) k_sturm_count(long n_sys, int N, T h, con
     { const M2s<T> F = dpp_fetch_s<T, 0x143, 0xC>(P); if (rw >= 2) P = muls(P, F, true); }
   }
   T zc = dpp_t<0x138, 0xF>(T(1), P.a), zp = dpp_t<0x138, 0xF>(T(0), P.c);   // incoming (u_a, u_{a-1})
-  int cnt = 0;
+  // (sign changes counted from ONE incoming pair per lane; the step into the next lane's first row belongs to that lane:
+  //  see WaveSolver::sweep_fwd)
+  const int ncount = (has_last ? M : M - 1) - (lane == kWave - 1 ? 0 : 1);
+  int cnt = __popcll(__ballot(sign_differs(zc, zp)));
 #pragma unroll
   for (int i = 0; i < M; ++i) {
     const bool act = (i < M - 1) || has_last;
     const T zn = xfma(-t[i], zc, -(e2[i] * zp));
-    const bool flip = act && sign_differs(zn, zc);
+    const bool flip = (i < M - 2 || i < ncount) && sign_differs(zn, zc);
     cnt += __popcll(__ballot(flip));
     if (act) { zp = zc; zc = zn; }
   }

@@ -386,14 +386,21 @@ struct WaveSolver {
     Eu = dpp_i<0x138, 0xF>(0, P.e);
     zu_m1 = um;
     T zc = u0, zp = um;
-    int count = 0;
+    // Every sign change is counted between two values that ONE lane derives from ONE incoming pair: first
+    // (u_{a-1}, u_a) as the scan delivers them, then the lane's own rows.  The step from a lane's last row into the
+    // next lane's first row is counted by that next lane: if each lane used "its" version of that value (replayed
+    // here, scanned there), a value near zero could carry different signs in the two lanes and a crossing would be
+    // counted twice or not at all (FP32: 1e-4 of the config-5 systems locked onto lam_2 that way).  Only the last
+    // lane also counts its final step (into u_n, the shooting value).
+    const int ncount = (has_last ? M : M - 1) - (lane == kWave - 1 ? 0 : 1);
+    int count = __popcll(__ballot(sign_differs(u0, um)));      // lane 0: (1, 0), no change
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const T t = xfma(-sig, Ph[i], D[i]);
       const bool act = (i < M - 1) || has_last;
       zu[i] = act ? zc : T(0);
       const T zn = xfma(-t, zc, -zp);
-      const bool flip = act && sign_differs(zn, zc);
+      const bool flip = (i < M - 2 || i < ncount) && sign_differs(zn, zc);
       count += __popcll(__ballot(flip));
       if (act) { zp = zc; zc = zn; }
     }

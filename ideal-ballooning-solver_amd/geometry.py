@@ -78,6 +78,25 @@ class SurfaceTables:
                    d["iota"], d["d_iota_d_s"], d["d_pressure_d_s"], float(d["phiedge"]), float(d["Aminor_p"]))
 
     @classmethod
+    def concat(cls, tables):
+        """one table set holding the surfaces of several equilibria (the base equilibrium and its DOF-perturbed
+        copies, sims_runner_NCSX.py:151-276): surface index = i_equilibrium * n_surf + i_surface.  All members must share
+        the mode tables; phiedge / Aminor_p are per-surface scalars in the packed layout, so they may differ."""
+        t0 = tables[0]
+        for t in tables[1:]:
+            if not (np.array_equal(t.xm, t0.xm) and np.array_equal(t.xn, t0.xn) and np.array_equal(t.xm_nyq, t0.xm_nyq)
+                    and np.array_equal(t.xn_nyq, t0.xn_nyq)):
+                raise ValueError("SurfaceTables.concat: mode tables differ")
+        out = cls.__new__(cls)
+        out.s = np.concatenate([t.s for t in tables])
+        out.xm, out.xn, out.xm_nyq, out.xn_nyq = t0.xm, t0.xn, t0.xm_nyq, t0.xn_nyq
+        out.tab_mn = np.ascontiguousarray(np.concatenate([t.tab_mn for t in tables]))
+        out.tab_nyq = np.ascontiguousarray(np.concatenate([t.tab_nyq for t in tables]))
+        out.scal = np.ascontiguousarray(np.concatenate([t.scal for t in tables]))
+        out.rows_mn, out.dn_mn, out.rows_nyq, out.dn_nyq = t0.rows_mn, t0.dn_mn, t0.rows_nyq, t0.dn_nyq
+        return out
+
+    @classmethod
     def from_wout(cls, wout, svals):
         """wout: mapping with rmnc, zmns, lmns, gmnc, bmnc, bsupvmnc, bsubsmns, bsubumnc, bsubvmnc stored
         (mn, ns) as in simsopt's Vmec.wout, pres, iotas, phi (ns,), xm, xn, xm_nyq, xn_nyq, Aminor_p, ns."""

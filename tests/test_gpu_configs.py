@@ -1,0 +1,228 @@
+"""GPU: BASELINE.json configs at their FULL shapes (the small-shape parity tests are in test_gpu_parity.py).
+
+  configs[3]  full adjoint step: 73 equilibria (base + 72 DOF perturbations) x 5 surfaces x 24 alpha x 15 theta0,
+              N = 969, geometry -> scan -> per-surface maximum -> objective -> forward-difference gradient
+  configs[4]  10^6 random (g, c, f) systems at N_zeta in {256, 512, 1024, 2048}, FP64 and FP32
+Checked against the C oracle / numpy oracles where they finish in seconds, otherwise through size-independent
+properties (Sturm-count certificates, covariance under scaling and shifts)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ibs_amd
+    return ibs_amd.Context(0)
+
+
+def c5_family(dev, family, n, N, seed):
+    """'smooth' = s-alpha coefficients (bishop_ball_s-alpha.py:30-45, f = g), shat ~ U(0.1, 2), alpha ~ U(0, 1.2),
+    theta0 ~ U(0, pi/2); 'rough' = iid per point inside the measured NCSX_op envelopes."""
+    import torch
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    u = lambda lo, hi, shape: lo + (hi - lo) * torch.rand(shape, dtype=torch.float64, device=dev, generator=gen)
+    h = 8 * np.pi / (N - 1)
+    if family == "smooth":
+        th = torch.linspace(-4 * np.pi, 4 * np.pi, N, dtype=torch.float64, device=dev)
+        sh, al, t0 = u(0.1, 2.0, (n, 1)), u(0.0, 1.2, (n, 1)), u(0.0, np.pi / 2, (n, 1))
+        lam = sh * (th[None] - t0) - al * (torch.sin(th)[None] - torch.sin(t0))
+        g = 1 + lam ** 2
+        c = al * (torch.cos(th)[None] + torch.sin(th)[None] * lam)
+        del lam
+        return h, g, c, g
+    g = torch.exp(u(np.log(0.01), np.log(50.0), (n, N)))
+    c = u(-2.5, 3.5, (n, N))
+    f = torch.exp(u(np.log(0.2), np.log(3e3), (n, N)))
+    return h, g, c, f
+
+
+def norm_a(h, g, c, f, chunk=65536):
+    """the solver's ||A|| bound per system: max_r (|d_r| + e_r + e_{r+1}) / f_r   (utils.py:1584-1592 rows)"""
+    import torch
+    out = torch.empty(g.shape[0], dtype=torch.float64, device=g.device)
+    for a in range(0, g.shape[0], chunk):
+        gg, cc, ff = g[a:a + chunk], c[a:a + chunk], f[a:a + chunk]
+        e = 0.5 * (gg[:, :-1] + gg[:, 1:]) / h ** 2
+        d = cc[:, 1:-1] - (e[:, :-1] + e[:, 1:])
+        out[a:a + chunk] = ((d.abs() + e[:, :-1] + e[:, 1:]) / ff[:, 1:-1]).amax(dim=1)
+    return out
+
+
+@pytest.mark.parametrize("nz", [256, 1024, 2048])
+@pytest.mark.parametrize("family", ["rough", "smooth"])
+def test_config5_fp64_one_million_systems(ctx, nz, family):
+    """10^6 systems per (N_zeta, family), FP64: nothing flagged; the Sturm count is 0 just above the returned eigenvalue and
+    >= 1 just below it (1 for all but near-degenerate pairs); lam is covariant under (g, c, f) -> (2g, 2c + 0.5 f, 2f);
+    a sample against the C oracle."""
+    import torch
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    n, N = 1000000, nz + 1
+    h, g, c, f = c5_family(dev, family, n, N, seed=20240 + nz)
+    r = ctx.solve_gcf(h, g, c, f, want_info=True)
+    lam = r["lam"]
+    assert int(((r["info"] >> 16) != 0).sum()) == 0
+    nA = norm_a(h, g, c, f)
+    # the certified bracket is 256 ulp(||A||) = 5.7e-14 ||A|| wide; the counts themselves are certificates for a matrix
+    # perturbed by ~n eps (scan-form recurrence), so the probe distance grows with the number of rows
+    eps = max(2e-13, 4 * N * 1.1e-16) * nA
+    above = ctx.sturm_count(h, g, c, f, lam + eps)
+    below = ctx.sturm_count(h, g, c, f, lam - eps)
+    odd = torch.nonzero((above != 0) | (below < 1)).flatten().cpu().numpy()
+    assert len(odd) <= n // 5000, len(odd)    # floating-point counts of rough systems are not perfectly monotone in the shift
+    pick = np.unique(np.concatenate([odd[:64], np.random.default_rng(nz).choice(n, size=96, replace=False)]))
+    pk = torch.from_numpy(pick).to(dev)
+    gam_c, lam_c, _ = co.solve_gcf_batch(h, g[pk].cpu().numpy(), c[pk].cpu().numpy(), f[pk].cpu().numpy())
+    # (the counts of the scan-form recurrence certify eigenvalues of a matrix perturbed by ~n eps; the systems with
+    #  non-monotone counts sit at the upper end of that)
+    # measured on the worst (non-monotone) systems of the rough family: 1e-11 ||A|| up to N_zeta = 1024, 1.1e-10 ||A|| at 2048
+    # (iid-random coefficients: ||A|| ~ 3e6 with lam ~ 2e-3, i.e. the problem itself is conditioned like 1e9)
+    tol = max(1e-11, 1e-13 * N)
+    assert (np.abs(lam[pk].cpu().numpy() - lam_c) / nA[pk].cpu().numpy()).max() < tol
+    if family == "smooth":                  # well separated top eigenvalue: the growth rate is pinned too
+        assert np.abs(r["gam"][pk].cpu().numpy() - gam_c).max() < 1e-8
+        assert float((below == 1).double().mean()) > 0.9999
+    else:
+        assert float((below == 1).double().mean()) > (0.999 if nz <= 1024 else 0.99)   # (near-degenerate pairs inside the probe distance give 2)
+    m = 8192
+    r2 = ctx.solve_gcf(h, 2 * g[:m], 2 * c[:m] + 0.25 * 2 * f[:m], 2 * f[:m])
+    assert float(((r2["lam"] - (lam[:m] + 0.25)).abs() / nA[:m]).max()) < 3e-13
+
+
+# FP32 tolerances of config 5, measured with tests/tools/fp32_probe.py (65,536 systems per leg) and stated with margin.
+#   lam: the scan-form Sturm counts certify eigenvalues of a matrix perturbed by ~n eps, n = N_zeta rows:
+#        median <= 16 eps32 ||A||,  99.9 % <= n eps32 ||A||,  every system <= 16 n eps32 ||A||
+#        (the outliers beyond n eps32 ||A|| -- 1e-4 of the smooth family at N_zeta <= 512 -- sit on lam_2: an FP32 count
+#        off by one between lam_2 and lam_1; FP64 is the parity path)
+#   gam (smooth family only; SURVEY 8d C5-ii pins lam alone on the rough one): the FD4 / Simpson growth rate subtracts
+#        two sums of size ||A|| ~ 4/h^2, so FP32 eigenvector noise is multiplied by ~N_zeta^2: usable at N_zeta <= 512,
+#        noise above (stated so; the FP32 variant exists for throughput / stress, not for the growth rate)
+EPS32 = 1.1920929e-07
+GAM32_TOL = {256: (2e-5, 1e-3), 512: (5e-4, 5e-2), 1024: (5e-2, 20.0), 2048: (5.0, 2e3)}     # (median, 99 %) of |gam32 - gam64|
+
+
+@pytest.mark.parametrize("nz", [256, 512, 1024, 2048])
+def test_config5_fp32_stated_tolerances(ctx, nz):
+    """FP32 legs of config 5 against FP64 on the same systems: 2 families x 131,072 systems per N_zeta"""
+    import torch
+    dev = torch.device("cuda:0")
+    n, N = 131072, nz + 1
+    q = lambda t, pr: float(torch.quantile(t, pr))
+    for family in ("smooth", "rough"):
+        h, g, c, f = c5_family(dev, family, n, N, seed=20240 + nz)
+        r64 = ctx.solve_gcf(h, g, c, f)
+        r32 = ctx.solve_gcf(h, g.float(), c.float(), f.float(), want_info=True, dtype=np.float32)
+        assert r32["lam"].dtype == torch.float32 and int(((r32["info"] >> 16) != 0).sum()) == 0
+        nA = norm_a(h, g, c, f)
+        el = (r32["lam"].double() - r64["lam"]).abs() / nA
+        assert float(el.median()) < 16 * EPS32 and q(el, 0.999) < nz * EPS32 and float(el.max()) < 16 * nz * EPS32, \
+            (float(el.median()), q(el, 0.999), float(el.max()))
+        if family == "smooth":
+            eg = (r32["gam"].double() - r64["gam"]).abs()
+            assert float(eg.median()) < GAM32_TOL[nz][0] and q(eg, 0.99) < GAM32_TOL[nz][1], (float(eg.median()), q(eg, 0.99))
+
+
+# ---------------------------------------------------------------------------------------------- configs[3]
+def ncsx_boundary_dofs(xm, xn, nfp):
+    """the 72 boundary DOFs of the NCSX / HBERG set-up (create_dict.py:29-34, 47-55): RBC(m, n) and ZBS(m, n) for
+    m = 0..6 with |n| <= (4, 3, 3, 2, 2, 2, 1)[m] (m = 0: n = 1..tor only) -> list of (table name, row in the wout mode list)"""
+    pol = [0, 1, 2, 3, 4, 5, 6]; tor = [4, 3, 3, 2, 2, 2, 1]
+    dofs = []
+    for name in ("rmnc", "zmns"):
+        for m, t in zip(pol, tor):
+            for n in (range(1, t + 1) if m == 0 else range(-t, t + 1)):
+                row = np.nonzero((xm == m) & (xn == n * nfp))[0]
+                assert len(row) == 1, (m, n)
+                dofs.append((name, int(row[0])))
+    return dofs
+
+
+def emulated_equilibria(wout0):
+    """without VMEC the 72 DOF-perturbed equilibria are emulated on the shipped NCSX_op tables: the boundary
+    value x of DOF k is stepped by abs 1e-3 if |x| <= 1e-2 else rel 2e-3 (create_dict.py:67, 70; ball_scan.py:129-139)
+    and the change carried inward with an s^2 profile.  Identical arithmetic, not a consistent equilibrium."""
+    nfp = int(wout0["nfp"])
+    dofs = ncsx_boundary_dofs(np.asarray(wout0["xm"]), np.asarray(wout0["xn"]), nfp)
+    assert len(dofs) == 72
+    prof = np.linspace(0, 1, wout0["rmnc"].shape[1]) ** 2
+    wouts, steps, x0 = [wout0], [1.0], []
+    for name, row in dofs:
+        w = dict(wout0)
+        w[name] = wout0[name].copy()
+        x = w[name][row, -1]
+        step = 1.0e-3 if abs(x) <= 1.0e-2 else 2.0e-3 * x
+        w[name][row, :] += step * prof
+        wouts.append(w); steps.append(step); x0.append(x)
+    return wouts, np.array(steps), np.array(x0)
+
+
+def test_config4_full_adjoint_step_73_equilibria(ctx):
+    """BASELINE configs[3] at its shape: 73 equilibria x 5 surfaces x 24 alpha x 15 theta0 = 131,400 solves on the
+    reference's N = 969 grid, ONE geometry launch + ONE scan launch + ONE argmax launch, then the objective and its
+    forward-difference gradient over the 72 DOFs.
+      * all 8,760 x 15 growth rates and all 73 x 5 maxima (value 1e-8, index exact) against the C-oracle pipeline run on the
+        same field-line geometry;
+      * the geometry itself: 64 random lines against the numpy geometry oracle built from each line's own (perturbed) tables;
+      * the 72-vector gradient against sims_runner_NCSX.py:249-261 written out line by line."""
+    import ibs_amd
+    import torch
+    from oracle import c_oracle as co
+    from oracle import geometry_oracle as go
+    dev = torch.device("cuda:0")
+    wout0 = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    wouts, steps, x0 = emulated_equilibria(wout0)
+    n_eq, ns, na, nt0, N = len(wouts), 5, 24, 15, 969
+    assert n_eq == 73
+    svals = np.linspace(0.5, 0.95, ns)                                   # ball_scan.py:197
+    th = ibs_amd.theta_grid_for(11, 11)                                  # ball_scan.py:201-208: 969 points
+    assert len(th) == N
+    alphas = np.linspace(0, np.pi, na); t0 = np.linspace(0, np.pi / 2, nt0)      # ball_scan.py:223-226
+    big = ibs_amd.SurfaceTables.concat([ibs_amd.SurfaceTables.from_wout(w, svals) for w in wouts])
+    surf = np.repeat(np.arange(n_eq * ns), na); al = np.tile(alphas, n_eq * ns)
+    h = float(th[1] - th[0])
+    r = ctx.fieldline_geometry(big, surf, al, th, device=dev)
+    sc = ctx.gamma_scan(h, *[r["geo"][k] for k in range(7)], r["dPdrho"], torch.from_numpy(t0).to(dev), want_info=True)
+    idx, val = ctx.surface_argmax(sc["gam"].reshape(n_eq * ns, -1))
+    assert int(((sc["info"] >> 16) != 0).sum()) == 0
+    gam = sc["gam"].cpu().numpy()
+    # --- C-oracle pipeline on the same geometry: scan, per-surface first maximum
+    geo_h = r["geo"].cpu().numpy()
+    gam_c, lam_c, _ = co.gamma_scan(h, *[geo_h[k] for k in range(7)], r["dPdrho"].cpu().numpy(), t0)
+    assert np.abs(gam - gam_c).max() < 1e-8, np.abs(gam - gam_c).max()
+    tab_c = gam_c.reshape(n_eq * ns, na * nt0)
+    assert np.array_equal(idx.cpu().numpy(), tab_c.argmax(axis=1))           # np.argmax = first maximum (ball_scan.py:283-288)
+    gmax = val.cpu().numpy().reshape(n_eq, ns)
+    assert np.abs(gmax - tab_c.max(axis=1).reshape(n_eq, ns)).max() < 1e-8
+    # --- geometry of 64 random lines against the numpy oracle (each from its own equilibrium's tables)
+    rng = np.random.default_rng(4)
+    for ln in rng.choice(len(surf), size=64, replace=False):
+        q, js = divmod(int(surf[ln]), ns)
+        ref = go.fieldline_geometry(go.surface_tables_from_wout(wouts[q], svals[js:js + 1]), 0, np.array([al[ln]]), th)[0]
+        scale = np.abs(ref).max(axis=1, keepdims=True)
+        assert (np.abs(geo_h[:, ln, :] - ref) / scale).max() < 1e-10
+    # --- objective and forward-difference gradient, sims_runner_NCSX.py:249-261 written out
+    f_other = 0.8 + 0.01 * np.arange(n_eq)                                # the non-ballooning part f{i}.npy (out of scope), any numbers
+    thresh, prefac = -2.0e-4, 50.0                                         # sims_runner_NCSX.py:56-57
+    f0_arr = np.zeros(n_eq); df0 = np.zeros(n_eq - 1)
+    step_arr = np.zeros(n_eq)
+    for i in range(n_eq):
+        if i > 0:
+            step_arr[i] = 1.0e-3 if abs(x0[i - 1]) <= 1.0e-2 else 2.0e-3 * x0[i - 1]      # sims_runner_NCSX.py:190-196
+        f0 = f_other[i]
+        f0 = f0 + prefac * np.sum(np.maximum(tab_c.max(axis=1).reshape(n_eq, ns)[i] - thresh, 0.0))   # :254-256
+        f0_arr[i] = f0
+        if i > 0:
+            df0[i - 1] = (f0_arr[i] - f0_arr[0]) / step_arr[i] * 0.5 * 1 / np.sqrt(f0_arr[0])       # :258-261
+    assert np.array_equal(step_arr[1:], steps[1:])
+    f_gpu = ibs_amd.ballooning_objective(f_other, gmax, gamma_thresh=thresh, prefac=prefac)
+    d_gpu = ibs_amd.dof_fd_gradient(f_gpu, ibs_amd.dof_steps(x0, (np.abs(np.concatenate([[0.0], x0])) <= 1.0e-2).astype(int)))
+    assert np.abs(f_gpu - f0_arr).max() < 1e-6 * 50 and np.abs(d_gpu).max() > 0
+    # a 1e-8 error of one gam moves f by 5e-7 and a gradient entry by 5e-7 / step / (2 sqrt f): the bound below is that
+    assert np.abs(d_gpu - df0).max() < 5 * 5e-7 / np.abs(steps[1:]).min() / (2 * np.sqrt(f0_arr[0]))
+    assert np.abs(d_gpu - df0).max() < 1e-6 * np.abs(df0).max() + 1e-3
