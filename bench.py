@@ -10,7 +10,8 @@ N rank processes itself BEFORE anything touches the GPU and exits with their sta
 One step = one pass of the hot path over one batch: the D3D-shape configuration of
 BASELINE.json (configs[1]): 16 flux surfaces x 8 alpha x 8 theta0 = 1,024 field-line eigen-solves
 on N_zeta=512 (513-point) grids, FP64, geometry resident in HBM.  A step is the geometry-fed scan
-kernel + the per-surface argmax kernel (+ for N>1 one RCCL all-gather of the per-surface maxima).
+kernel, whose epilogue also reduces every completed surface to its first maximum (+ for N>1 one RCCL all-gather of
+the per-surface maxima).
 Weak scaling: every rank processes its own 16-surface batch.  With N > 1 the line also carries `ncsx_c2_sharded`:
 BASELINE.json configs[2] (64 surfaces x 32 alpha x 16 theta0, N_zeta = 1024) with the surfaces sharded round-robin over
 the ranks (geometry -> scan -> argmax on each rank's own surfaces, ONE all-gather of the per-surface rows), checked
@@ -497,12 +498,12 @@ def main():
     gathered = torch.empty((n_ranks * N_SURF, 2), dtype=torch.float64, device=coll_dev) if use_dist else None
 
     def step(k=0, ev=None):
+        # scan + per-surface first maximum: ONE kernel (the block that completes a surface reduces it)
         if ev is not None:
             ev[0].record()
-        plan.scan()
+        plan.scan_argmax()
         if ev is not None:
             ev[1].record()
-        plan.argmax()
         if use_dist:
             dist.all_gather_into_tensor(gathered, plan.pack if backend == "nccl" else plan.pack.cpu())
 
@@ -547,8 +548,7 @@ def main():
     un = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_un)]
     emp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_un)]
     for (a, b), (c, d) in zip(un, emp):
-        a.record(); plan.scan(); b.record()
-        plan.argmax()
+        a.record(); plan.scan_argmax(); b.record()
         c.record(); d.record()
     torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in un]))
@@ -576,7 +576,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (NCSX_op-derived field-line geometry, perturbed per line)",
             "config": {"workload": "configs[1] D3D-shape: 16 surfaces x 8 alpha x 8 theta0 = 1024 solves/step/GPU, "
-                                   "N_zeta=512 (513 points), geometry-fed scan + per-surface argmax"
+                                   "N_zeta=512 (513 points), geometry-fed scan with fused per-surface argmax (one launch)"
                                    + (" + all-gather (%s, %d ranks) of the per-surface maxima" % (
                                        "RCCL" if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,

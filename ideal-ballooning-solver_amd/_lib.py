@@ -37,6 +37,8 @@ SYMBOLS = {
                                      _P, _P, _P, _P, _P, _P, _I32]),
     "ibs_gamma_scan_warm_f64": (C.c_int, [_P, _I32, _I32, _I32, _D, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _D,
                                           _P, _P, _P, _P, _P, _P, _I32]),
+    "ibs_gamma_scan_argmax_f64": (C.c_int, [_P, _I32, _I32, _I32, _D, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I32,
+                                            _P, _P, _P, _P]),
     "ibs_obj_w_grad_f64": (C.c_int, [_P, _I32, _I32, _D, _P, _I64, _P, _D, _P, _P, _P, _I32]),
     "ibs_hf_grad_f64": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I32]),
     "ibs_fieldline_geometry_f64": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _I32, _P,

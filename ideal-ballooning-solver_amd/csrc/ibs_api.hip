@@ -44,6 +44,7 @@ struct ibs_options {
   int force_p = 0;        // lanes per system: 64 | 32 | 16
   int scan_chain = 0;     // theta0 values chained through one wave / group
   int geo_lpp = 0;        // lanes per grid point of the geometry kernel: 1 | 2 | 4
+  int pack_mode = 0;      // hand-off of the fused scan + argmax: 1 = write-through + sc1 loads, 2 = release / acquire fences
   double chain_w1 = 0.25, chain_w2 = 1.0;   // relative widths of the chain's warm starts
 };
 
@@ -56,6 +57,9 @@ struct ibs_ctx {
   size_t ws_bytes = 0;
   int lds_per_block = 160 * 1024;
   int n_cu = 256;
+  // per-surface arrival counters of the fused scan + argmax kernel (zero between launches)
+  int* surf_counter = nullptr;
+  int surf_counter_n = 0;
 };
 
 namespace {
@@ -368,6 +372,7 @@ int ibs_destroy(ibs_ctx* c) {
   if (!c) return 0;
   DeviceGuard g(c->device);
   if (c->ws) hipFree(c->ws);
+  if (c->surf_counter) hipFree(c->surf_counter);
   delete c;
   return 0;
 }
@@ -385,6 +390,7 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   if (n == "force_p") c->opt.force_p = reset ? c->opt_created.force_p : (int)value;
   else if (n == "scan_chain") c->opt.scan_chain = reset ? c->opt_created.scan_chain : (int)value;
   else if (n == "geo_lpp") c->opt.geo_lpp = reset ? c->opt_created.geo_lpp : (int)value;
+  else if (n == "pack_mode") c->opt.pack_mode = reset ? c->opt_created.pack_mode : (int)value;
   else if (n == "chain_w1") c->opt.chain_w1 = reset ? c->opt_created.chain_w1 : value;
   else if (n == "chain_w2") c->opt.chain_w2 = reset ? c->opt_created.chain_w2 : value;
   else if (n == "all" && reset) c->opt = c->opt_created;
@@ -451,9 +457,11 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
                            const double* gds2, const double* gds21, const double* gds22, int64_t ld,
                            const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
                            double* dX, double* dth0, int32_t* info, int32_t mem, const double* lam_guess,
-                           double guess_width) {
+                           double guess_width, int32_t n_surf = 0, double* pack = nullptr) {
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
   if (lam_guess && !(guess_width > 0)) return fail(IBS_ERR_ARG, "guess_width must be > 0");
+  if (pack && (mem != IBS_MEM_DEVICE || n_surf <= 0 || n_lines % n_surf != 0 || !gam))
+    return fail(IBS_ERR_ARG, "fused argmax: device pointers, gam output and n_lines %% n_surf == 0 required (n_lines=%d n_surf=%d)", n_lines, n_surf);
   if (n_lines < 0 || n_theta0 < 0 || !bmag || !gradpar || !cvdrift || !cvdrift0 || !gds2 || !gds21 || !gds22 ||
       !dPdrho || !theta0 || ld < N)
     return fail(IBS_ERR_ARG, "bad arguments (n_lines=%d n_theta0=%d ld=%lld N=%d)", n_lines, n_theta0, (long long)ld, N);
@@ -592,7 +600,30 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   a.bmag = bmag; a.gradpar = gradpar; a.cvdrift = cvdrift; a.cvdrift0 = cvdrift0; a.gds2 = gds2; a.gds21 = gds21; a.gds22 = gds22;
   a.dPdrho = dPdrho; a.theta0 = theta0; a.gam = gam; a.lam = lam; a.X = X; a.dX = dX; a.dth0 = dth0; a.info = info;
   a.lam_guess = lam_guess; a.guess_width = guess_width;
+  if (pack && fn == ibs::launch_table().scan_f64[M] && G == 1) {
+    // one launch: the block that completes a surface reduces it (k_gamma_scan's epilogue)
+    if (ctx->surf_counter_n < n_surf) {
+      if (ctx->surf_counter) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->surf_counter)); ctx->surf_counter = nullptr; }
+      const int cap_n = n_surf > 1024 ? n_surf : 1024;
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->surf_counter), (size_t)cap_n * sizeof(int)));
+      HIPCHK(hipMemsetAsync(ctx->surf_counter, 0, (size_t)cap_n * sizeof(int), ctx->stream));
+      ctx->surf_counter_n = cap_n;
+    }
+    a.lines_per_surf = n_lines / n_surf; a.surf_counter = ctx->surf_counter; a.pack = pack;
+    {
+      const long nblocks = (long)((n_theta0 + a.wpb - 1) / a.wpb) * n_lines;
+      a.pack_mode = (nblocks <= ctx->n_cu && ctx->opt.pack_mode != 2) ? 1 : 2;
+      if (ctx->opt.pack_mode == 1) a.pack_mode = 1;
+    }
+    HIPCHK(fn(a, ctx->stream));
+    return 0;
+  }
   HIPCHK(fn(a, ctx->stream));
+  if (pack) {                                    // chained / sub-wave scan kernels: the reduction is a second launch
+    const int n_per = (n_lines / n_surf) * n_theta0;
+    hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(argmax_threads(n_per)), 0, ctx->stream, n_per, gam, (int*)nullptr, (double*)nullptr, pack);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -613,6 +644,16 @@ int ibs_gamma_scan_warm_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int
   if (!lam_guess) return fail(IBS_ERR_ARG, "lam_guess is null");
   return gamma_scan_impl(ctx, n_lines, n_theta0, N, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, ld, dPdrho,
                          theta0, gam, lam, X, dX, dth0, info, mem, lam_guess, guess_width);
+}
+
+int ibs_gamma_scan_argmax_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
+                              const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
+                              const double* gds2, const double* gds21, const double* gds22, int64_t ld,
+                              const double* dPdrho, const double* theta0, int32_t n_surf, double* gam, double* lam,
+                              double* pack, int32_t* info) {
+  if (!pack) return fail(IBS_ERR_ARG, "pack is null");
+  return gamma_scan_impl(ctx, n_lines, n_theta0, N, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, ld, dPdrho,
+                         theta0, gam, lam, nullptr, nullptr, nullptr, info, IBS_MEM_DEVICE, nullptr, 0.0, n_surf, pack);
 }
 
 int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const double* geo, int64_t ld,

@@ -112,11 +112,11 @@ template <typename T, int M, class Src, bool HF, class Tan = NoTangent>
 __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int N, T h, T* Xs,
                                        T lam, const SolveInfo& inf, long sys, T* lam_out, T* gam_out,
                                        T* X_out, T* dX_out, T* dth0_out, int* info_out,
-                                       const Tan* tan = nullptr, T* dalpha_out = nullptr) {
+                                       const Tan* tan = nullptr, T* dalpha_out = nullptr, const T* gh = nullptr) {
   const int lane = ws.lane;
   const int n = N - 2;
   T x[M];
-  ws.assemble(x);
+  ws.assemble(src, gh, N, h, x);
   T m = T(0);
 #pragma unroll
   for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
@@ -189,7 +189,8 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
   }
   if (lane == 0) {
     if (lam_out) lam_out[sys] = lam;
-    if (gam_out) gam_out[sys] = gam;
+    // (write-through, agent scope: the fused per-surface reduction of k_gamma_scan reads it from another CU)
+    if (gam_out) __hip_atomic_store(gam_out + sys, gam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (info_out) info_out[sys] = inf.iters | (inf.status << 16);
   }
 }
@@ -219,13 +220,13 @@ __device__ __forceinline__ void simpson_point(const Src& src, int j, T w, T X, T
 template <typename T, int M, class Src, bool HF>
 __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& src, int N, T h, T* Xs, T lam,
                                              const SolveInfo& inf, long sys, T* lam_out, T* gam_out,
-                                             T* X_out, T* dX_out, T* dth0_out, int* info_out) {
+                                             T* X_out, T* dX_out, T* dth0_out, int* info_out, const T* gh = nullptr) {
   static_assert(M >= 3, "the halo exchange takes two rows from each neighbour lane");
   const int lane = ws.lane;
   const int n = N - 2;
   const bool hl = ws.has_last;
   T x[M];
-  ws.assemble(x);
+  ws.assemble(src, gh, N, h, x);
   T m = T(0);
 #pragma unroll
   for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
@@ -290,7 +291,8 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& sr
   }
   if (lane == 0) {
     if (lam_out) lam_out[sys] = lam;
-    if (gam_out) gam_out[sys] = gam;
+    // (write-through, agent scope: the fused per-surface reduction of k_gamma_scan reads it from another CU)
+    if (gam_out) __hip_atomic_store(gam_out + sys, gam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (info_out) info_out[sys] = inf.iters | (inf.status << 16);
   }
   if (X_out || dX_out) {                   // wave-uniform
@@ -348,12 +350,14 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   if constexpr (M >= 3) {                  // f is read from its LDS slot, which X / dX reuse afterwards
     finish_chunk<T, M, SrcGCF<T>, false>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                          valid ? gam_out : nullptr, valid ? X_out : nullptr,
-                                         valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
+                                         valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr,
+                                         gh ? gh + sysc * ld : nullptr);
   } else {
     const SrcGCFG<T> srcf{gs, cs, fg};     // growth-rate stage: f from global memory
     finish<T, M, SrcGCFG<T>, false>(ws, srcf, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                    valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
-                                   nullptr, valid ? info_out : nullptr);
+                                   nullptr, valid ? info_out : nullptr, static_cast<const NoTangent*>(nullptr), nullptr,
+                                   gh ? gh + sysc * ld : nullptr);
   }
 }
 
@@ -368,7 +372,8 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
                                                      const T* __restrict__ gds22, long ld,
                                                      const T* __restrict__ dPdrho, const T* __restrict__ theta0,
                                                      T* gam_out, T* lam_out, T* X_out, T* dX_out, T* dth0_out,
-                                                     int* info_out, const T* __restrict__ lam_guess, T guess_width) {
+                                                     int* info_out, const T* __restrict__ lam_guess, T guess_width,
+                                                     int lines_per_surf, int* surf_counter, T* pack, int pack_mode) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -434,6 +439,65 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
                                   valid ? dth0_out : nullptr, valid ? info_out : nullptr);
   }
   IBS_PROBE_AT(4);
+  // ---- fused per-surface argmax (ball_scan.py:279-295: first maximum of the surface's (alpha, theta0) table).
+  // Last-block-done: every block publishes its growth rates (plain stores -> each wave drains its stores -> block
+  // barrier -> ONE lane: agent-scope release, drain, relaxed agent-scope add on the surface's counter); the block whose
+  // add completes the surface acquires (agent scope), then reduces the table.  Placement-independent (no assumption
+  // on dispatch order or XCD co-location: cdna_hip_programming.md G16); the counter word is reset by the last arriver.
+  if (pack) {                                   // (kernel argument: uniform over the grid)
+    int* flag = reinterpret_cast<int*>(smem + (size_t)(7 + wpb) * P);   // 128 B behind the staging rows (launcher adds them)
+    double* sv = reinterpret_cast<double*>(flag + 4);
+    int* si = flag + 4 + 2 * 8;
+    const int surf = line / lines_per_surf;
+    const int nblk_surf = lines_per_surf * nparts;
+    // pack_mode 1 (one block per CU: the regime MI355X_MICROARCH.md measured this hand-off in): the growth rates were
+    // stored write-through (sc1) by finish(), every storing wave drains its stores, and the add follows the block barrier;
+    // the last arriver reads them back with sc1 loads -- no fences.  pack_mode 2 (any placement): agent-scope release
+    // before the add, agent-scope acquire in the block that completes the surface.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (pack_mode != 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const int old = __hip_atomic_fetch_add(&surf_counter[surf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (old == nblk_surf - 1) ? 1 : 0;
+      if (last) {
+        __hip_atomic_store(&surf_counter[surf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pack_mode != 1) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      flag[0] = last;
+    }
+    __syncthreads();
+    if (flag[0]) {                              // block-uniform
+      const int n_per = lines_per_surf * n_theta0;
+      const T* gsurf = gam_out + (size_t)surf * n_per;
+      T best = -T(1.7976931348623157e308);
+      int bi = 0x7fffffff;
+      for (int i = threadIdx.x; i < n_per; i += blockDim.x) {
+        // (agent-scope loads: served by L2, never by this CU's L1, which other CUs' stores do not refresh)
+        const T v = __hip_atomic_load(gsurf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const T v2 = __shfl_xor(best, d);
+        const int i2 = __shfl_xor(bi, d);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+      }
+      if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int k = 1; k < wpb; ++k)
+          if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        pack[2 * surf] = best; pack[2 * surf + 1] = (T)bi;
+      }
+    }
+  }
 }
 
 
@@ -741,14 +805,14 @@ static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
 template <typename T>
 static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
-  const size_t lds = (size_t)(7 + wpb) * lds_pitch(a.N) * sizeof(T);
+  const size_t lds = (size_t)(7 + wpb) * lds_pitch(a.N) * sizeof(T) + (a.pack ? 128 : 0);
   auto kern = k_gamma_scan<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   dim3 grid((unsigned)(((a.n_theta0 + wpb - 1) / wpb) * a.n_lines));
   hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
                      a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
-                     a.dX, a.dth0, a.info, a.lam_guess, a.guess_width);
+                     a.dX, a.dth0, a.info, a.lam_guess, a.guess_width, a.lines_per_surf, a.surf_counter, a.pack, a.pack_mode);
   return hipGetLastError();
 }
 template <typename T>

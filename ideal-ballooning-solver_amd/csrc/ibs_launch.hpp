@@ -21,6 +21,11 @@ struct ScanArgs {
   T *gam, *lam, *X, *dX, *dth0; int* info; int wpb;
   const T* lam_guess; T guess_width;     // optional warm start ([n_lines][n_theta0], absolute width); null = cold
   int chain; T chain_w1, chain_w2;       // k_gamma_scan_chain: theta0 values per wave and the widths of its warm starts
+  // fused per-surface argmax (k_gamma_scan only): lines_per_surf consecutive lines form a surface; the block that
+  // completes a surface reduces its [lines_per_surf * n_theta0] growth rates into pack[surf] = (max, first index).
+  // surf_counter[n_surf]: zero between launches (the last arriver resets its word).  null pack = no fusion.
+  int lines_per_surf; int* surf_counter; T* pack;
+  int pack_mode;                         // 1 = write-through stores + sc1 loads (one block per CU), 2 = release / acquire fences
 };
 template <typename T>
 struct SturmArgs {

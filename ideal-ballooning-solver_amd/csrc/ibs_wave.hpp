@@ -275,20 +275,26 @@ struct SolveInfo {
 
 template <typename T, int M>
 struct WaveSolver {
-  // chunk of this lane, symmetric scaling (see header comment)
-  T D[M], Ph[M], S[M];
+  // chunk of this lane, symmetric scaling (see header comment).  Register budget: during the shift iteration only D and
+  // Ph (4M VGPRs) are live; the backward solution zw is stored once, after convergence; the forward solution is never
+  // stored but replayed from its incoming pair (M fma per replay), and the diagonal scaling s is rebuilt from g when the
+  // eigenvector is assembled -- so the peak is 6M + temporaries instead of 10M (256 VGPRs + scratch at M = 16 before).
+  T D[M], Ph[M];
   T kap, ikap;
   bool has_last;   // this lane owns M rows (else M-1)
   int lane;
   // sweep products
-  T zu[M], zw[M];
-  T zu_m1, zw_p1;  // z_{-1} of the forward solution, z_{cnt} of the backward solution (local scaling)
+  T zw[M];
+  T u0_in, zu_m1;  // (z_0, z_{-1}) of the forward solution: the pair the lane's rows are replayed from
+  T zw_p1;         // z_{cnt} of the backward solution (local scaling)
   int Eu, Ew;      // power-of-two exponents of this lane's forward / backward solutions
+  T sig_vec;       // shift of the last twisted() call (assemble() replays the forward solution at it)
   // bounds
   T lo, hi, normA;
   // shooting value of the last forward sweep (mantissa-like, power-of-two exponent)
   T shoot_m; int shoot_e;
 
+  static constexpr int kSetupRows = 4;
   // rows of this lane: [start, start+cnt)
   __device__ __forceinline__ static int rows_start(int lane, int n) {
     const int rem = n - kWave * (M - 1);
@@ -332,7 +338,7 @@ struct WaveSolver {
         const T cj = src.c(j), fj = src.f(j);
         const T d = cj - (e_lo + e_hi);
         const T s2 = sc * sc;
-        S[i] = sc; D[i] = d * s2; Ph[i] = fj * s2;
+        D[i] = d * s2; Ph[i] = fj * s2;
         const T rf = fast_rcp(fj);          // bounds only (margins added below)
         vhi = xmax(vhi, cj * rf);
         vlo = xmax(vlo, d * rf);
@@ -342,8 +348,11 @@ struct WaveSolver {
         sc = fast_rcp(e_hi * sc);           // e s_i s_{i+1} = 1 to rounding (two Newton steps on the hardware seed)
         gcur = gnext; e_lo = e_hi;
       } else {
-        S[i] = T(0); D[i] = T(0); Ph[i] = T(0);
+        D[i] = T(0); Ph[i] = T(0);
       }
+      // the rows hang on one dependent chain (sc), so the scheduler would put EVERY row's LDS reads in flight first
+      // (3 to 7 values per row: > 400 VGPRs at M = 32); at most kSetupRows rows at a time
+      if constexpr (M > 8) { if ((i % kSetupRows) == kSetupRows - 1) __builtin_amdgcn_sched_barrier(0); }
     }
     IBS_PROBE_AT(8);
     kap = sc; ikap = fast_rcp(sc);
@@ -384,7 +393,7 @@ struct WaveSolver {
     const T u0 = dpp_t<0x138, 0xF>(T(1), P.a);   // wave_shr:1
     const T um = dpp_t<0x138, 0xF>(T(0), P.c);
     Eu = dpp_i<0x138, 0xF>(0, P.e);
-    zu_m1 = um;
+    zu_m1 = um; u0_in = u0;
     T zc = u0, zp = um;
     // Every sign change is counted between two values that ONE lane derives from ONE incoming pair: first
     // (u_{a-1}, u_a) as the scan delivers them, then the lane's own rows.  The step from a lane's last row into the
@@ -398,7 +407,6 @@ struct WaveSolver {
     for (int i = 0; i < M; ++i) {
       const T t = xfma(-sig, Ph[i], D[i]);
       const bool act = (i < M - 1) || has_last;
-      zu[i] = act ? zc : T(0);
       const T zn = xfma(-t, zc, -zp);
       const bool flip = (i < M - 2 || i < ncount) && sign_differs(zn, zc);
       count += __popcll(__ballot(flip));
@@ -449,23 +457,34 @@ struct WaveSolver {
     return c;
   }
 
-  // twisted estimate from the last sweep.  Returns rho (Rayleigh/Newton update of sig); fills the
-  // per-lane normalisation (fu, fw, thr) that assemble() uses.
+  // twisted estimate from the last forward sweep (replayed) and the stored backward solution.  Returns rho
+  // (Rayleigh/Newton update of sig); fills the per-lane normalisation (fu, fw, thr) that assemble() uses.
+  //   rho = sig + gamma_k / sum_r f_r x_r^2,   gamma_k = [(T - sig F) x]_k,   x = u / u_k (r <= k), w / w_k (r >= k)
+  // In the scaled variables (x = s z, Ph = f s^2) the scaling of row k cancels:
+  //   rho = sig + num / (z_u,k z_w,k sum_r Ph_r zhat_r^2),  num = row-k residual of (z_u,k z_w,k) zhat,  zhat = z / z_k.
   T fu, fw;
   int thr;
-  __device__ __forceinline__ T twisted(T sig) { return twisted(sig, sig); }
-  // sig = shift of the forward solution (rows <= k), sig_w = shift of the backward solution (rows > k).  With
-  // (T x)_r = sig f_r x_r below k and sig_w f_r x_r above, the Rayleigh quotient of the twisted vector is
-  //   rho = sig + [gamma_k + (sig_w - sig) sum_{r>k} f_r x_r^2] / sum_r f_r x_r^2 ,   gamma_k = [(T - sig F) x]_k.
-  __device__ __forceinline__ T twisted(T sig, T sig_w) {
-    // k = argmax |u_k w_k| (= argmin |gamma_k|, discrete Wronskian): per-lane candidate first
+  __device__ __forceinline__ T twisted(T sig) {
+    // pass A: replay the forward solution; per-lane candidate for the twist row k = argmax f |u w| (any row with a large
+    // product will do: discrete Wronskian, gamma_r = W / (u_r w_r)) together with the entries around it, so that no
+    // dynamically indexed access is needed afterwards
     T best = T(0);
     int bi = 0;
+    T zu_b = T(1), zum_b = T(0), zw_b = T(1), zwp_b = T(0), t_b = T(0);
+    {
+      T zc = u0_in, zp = zu_m1;
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      const T a = xabs(S[i] * S[i] * (zu[i] * zw[i]));
-      const bool better = a > best;
-      best = better ? a : best; bi = better ? i : bi;
+      for (int i = 0; i < M; ++i) {
+        const T t = xfma(-sig, Ph[i], D[i]);
+        const bool act = (i < M - 1) || has_last;
+        const T a = act ? xabs(Ph[i] * (zc * zw[i])) : T(0);
+        const bool better = a > best;
+        best = better ? a : best; bi = better ? i : bi;
+        zu_b = better ? zc : zu_b; zum_b = better ? zp : zum_b; t_b = better ? t : t_b;
+        zw_b = better ? zw[i] : zw_b; zwp_b = better ? (i == M - 1 ? zw_p1 : zw[i < M - 1 ? i + 1 : M - 1]) : zwp_b;
+        const T zn = xfma(-t, zc, -zp);
+        if (act) { zp = zc; zc = zn; }
+      }
     }
     // wave argmax in (exponent, mantissa) form; the lane id rides in the low 6 mantissa bits
     // key = (exponent of the product incl. the lanes' scan exponents) + mantissa in [1, 2): integer-built
@@ -482,51 +501,63 @@ struct WaveSolver {
       Lk = __float_as_int(wave_max(key)) & 63;
     }
     const int ik = readlane_i(bi, Lk);
-    // fetch the entries around (Lk, ik): ik is wave-uniform, so this is a scalar branch chain
-    T zu_k = T(1), zw_k = T(1), S_k = T(1), t_k = T(0), um1 = T(0), wp1 = T(0);
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-      if (i == ik) {
-        zu_k = readlane_t(zu[i], Lk); zw_k = readlane_t(zw[i], Lk); S_k = readlane_t(S[i], Lk);
-        t_k = readlane_t(xfma(-sig, Ph[i], D[i]), Lk);
-        um1 = readlane_t(i == 0 ? zu_m1 : zu[i > 0 ? i - 1 : 0], Lk);
-        wp1 = readlane_t(i == M - 1 ? zw_p1 : zw[i < M - 1 ? i + 1 : M - 1], Lk);
-      }
-    }
+    const T zu_k = readlane_t(zu_b, Lk), zw_k = readlane_t(zw_b, Lk), t_k = readlane_t(t_b, Lk);
+    const T um1 = readlane_t(zum_b, Lk), wp1 = readlane_t(zwp_b, Lk);
     const T uw = zu_k * zw_k;
     const T num = xfma(um1, zw_k, xfma(t_k, uw, wp1 * zu_k));   // row-k residual of the twisted vector (x u_k w_k)
-    const T gam_k = num * fast_rcp(S_k * S_k * uw);
     const int Euk = readlane_i(Eu, Lk), Ewk = readlane_i(Ew, Lk);
     int du = Eu - Euk, dw = Ew - Ewk;
     du = du > 1000 ? 1000 : (du < -2000 ? -2000 : du);
     dw = dw > 1000 ? 1000 : (dw < -2000 ? -2000 : dw);
-    fu = xldexp(fast_rcp(S_k * zu_k), du);
-    fw = xldexp(fast_rcp(S_k * zw_k), dw);
+    fu = xldexp(fast_rcp(zu_k), du);
+    fw = xldexp(fast_rcp(zw_k), dw);
     thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
-    T acc = T(0), acc_w = T(0);
+    // pass B: sum f x^2 over the twisted vector (forward solution replayed again)
+    T acc = T(0);
+    {
+      T zc = u0_in, zp = zu_m1;
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      const T xu = zu[i] * fu, xw = zw[i] * fw;
-      const bool below = i <= thr;
-      const T x = below ? xu : xw;
-      if ((i < M - 1) || has_last) {
-        acc = xfma(Ph[i] * x, x, acc);
-        acc_w = below ? acc_w : xfma(Ph[i] * x, x, acc_w);
+      for (int i = 0; i < M; ++i) {
+        const T t = xfma(-sig, Ph[i], D[i]);
+        const bool act = (i < M - 1) || has_last;
+        const T xu = zc * fu, xw = zw[i] * fw;
+        const T x = (i <= thr) ? xu : xw;
+        if (act) acc = xfma(Ph[i] * x, x, acc);
+        const T zn = xfma(-t, zc, -zp);
+        if (act) { zp = zc; zc = zn; }
       }
     }
+    sig_vec = sig;
     const T tot = wave_sum(acc);
-    const T dsig = sig_w - sig;
-    T corr = T(0);
-    if (U(dsig != T(0))) corr = dsig * wave_sum(acc_w);      // wave-uniform: only the mixed-shift finish pays for it
-    return sig + (gam_k + corr) * fast_rcp(tot);
+    return sig + num * fast_rcp(uw * tot);
   }
 
-  // eigenvector entries of this lane's rows (twisted, x_k = 1) from the last sweep/twisted() call
-  __device__ __forceinline__ void assemble(T (&x)[M]) {
+  // eigenvector entries of this lane's rows up to a common factor (normalised by the caller).  The diagonal scaling s is
+  // rebuilt here from g with the arithmetic of setup() (s_0 = 1, s_{i+1} = 1 / (e_{i+1} s_i)), the forward solution is
+  // replayed at the shift of the last twisted() call.  D, Ph and zw are consumed row by row: x[] replaces them.
+  // gh: the caller-supplied half-grid g of setup() (Src::kHasGh), or null = mean of the neighbouring g.
+  template <class Src>
+  __device__ __forceinline__ void assemble(const Src& src, const T* gh, int N, T h, T (&x)[M]) {
+    int a = rows_start(lane, N - 2);
+    asm volatile("" : "+v"(a));          // (keeps the compiler from carrying setup()'s LDS addresses across the iteration)
+    const T ih2 = T(1) / (h * h);
+    T sc = T(1);
+    T gcur = src.g(a + 1);
+    T zc = u0_in, zp = zu_m1;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-      const T xu = S[i] * zu[i] * fu, xw = S[i] * zw[i] * fw;
-      x[i] = ((i < M - 1) || has_last) ? ((i <= thr) ? xu : xw) : T(0);
+      const bool act = (i < M - 1) || has_last;
+      const T xu = sc * zc * fu, xw = sc * zw[i] * fw;
+      x[i] = act ? ((i <= thr) ? xu : xw) : T(0);
+      if (act) {
+        T e_hi;
+        if (gh) e_hi = gh[a + i + 1] * ih2;                    // (wave-uniform branch)
+        else { const T gnext = src.g(a + i + 2); e_hi = T(0.5) * (gcur + gnext) * ih2; gcur = gnext; }
+        sc = fast_rcp(e_hi * sc);
+        const T zn = xfma(-xfma(-sig_vec, Ph[i], D[i]), zc, -zp);
+        zp = zc; zc = zn;
+      }
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most 4 rows of LDS reads in flight (registers)
     }
   }
 

@@ -357,6 +357,8 @@ class ScanPlan:
                            p(self.gam), p(self.lam), C.c_void_p(None), C.c_void_p(None), p(self.dth0), p(self.info),
                            MEM_DEVICE)
         self._amax_args = [(ctx._h, n_surf, (n_lines // n_surf) * n_t0, p(self.gam), p(pk)) for pk in self.packs]
+        self._fused_args = [(ctx._h, n_lines, n_t0, N, float(h), *[p(g) for g in self.geo], N, p(self.dP), p(self.t0), n_surf,
+                             p(self.gam), p(self.lam), p(pk), p(self.info)) for pk in self.packs]
 
     def _use_current_stream(self):
         # the Context's stream is shared mutable state: launch on the caller's CURRENT torch stream, like every other
@@ -376,6 +378,12 @@ class ScanPlan:
         if rc < 0:
             check(rc, "ibs_surface_argmax_pack_f64")
 
+    def scan_argmax(self, slot=0):
+        """scan + per-surface first maximum in one C call (ibs_gamma_scan_argmax_f64: one kernel launch for small batches)"""
+        self._use_current_stream()
+        rc = self.lib.ibs_gamma_scan_argmax_f64(*self._fused_args[slot])
+        if rc < 0:
+            check(rc, "ibs_gamma_scan_argmax_f64")
+
     def __call__(self):
-        self.scan()
-        self.argmax()
+        self.scan_argmax()

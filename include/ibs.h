@@ -115,6 +115,19 @@ int ibs_gamma_scan_warm_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int
                             double* gam, double* lam, double* X, double* dX, double* dgam_dtheta0, int32_t* info,
                             int32_t mem);
 
+/* Scan + per-surface first maximum in ONE call (device pointers only): the lines are ordered surface-major,
+ * n_lines / n_surf consecutive lines form a surface, and pack[n_surf][2] = (max gam of the surface's (alpha, theta0)
+ * table, its first row-major index as a double) -- the buffer the per-surface all-gather sends.
+ * Replaces: ball_scan.py:248-295 (coarse scan loops + argmax with the first-maximum rule :283-288) for all surfaces of a
+ * rank at once.  For small batches this is a single kernel launch: the thread block that completes a surface reduces
+ * it (agent-scope release / acquire on a per-surface arrival counter); large batches run the chained / sub-wave scan
+ * kernels followed by the reduction kernel. */
+int ibs_gamma_scan_argmax_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
+                              const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
+                              const double* gds2, const double* gds21, const double* gds22, int64_t ld,
+                              const double* dPdrho, const double* theta0, int32_t n_surf, double* gam, double* lam,
+                              double* pack, int32_t* info);
+
 /* Objective and Hellmann-Feynman ("adjoint") gradient at n_pts points (alpha, theta0).
  * Replaces: utils.py:1632-1728 obj_w_grad, given the geometry of the three field lines
  * (alpha - del_alpha/2, alpha, alpha + del_alpha/2) that utils.py:1641-1646 obtains from vmec_fieldlines.

@@ -833,3 +833,50 @@ def test_gamma_ball_full_nonuniform_grid_regrids_like_reference(ctx, bo):
         assert np.abs(a - b).max() < 1e-7
     uni = ibs_amd.gamma_ball_full(-1.0, tu, B, gp, cv, gds2, ctx=ctx)
     assert abs(uni[0] - out[0]) > 1e-6                             # the regrid actually matters here
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("ns,na,nt0,N", [(16, 8, 8, 513), (5, 24, 15, 969), (3, 5, 7, 257), (32, 8, 16, 1025)])
+def test_fused_scan_argmax_equals_two_launches(ctx, bo, ns, na, nt0, N, mode):
+    """ibs_gamma_scan_argmax_f64 (scan whose epilogue reduces every completed surface: agent-scope release / acquire on a
+    per-surface arrival counter) against scan + ibs_surface_argmax_pack_f64: bitwise, over many launches that alternate
+    between two geometries (a stale read of the other launch's growth rates would show), with the surfaces' blocks
+    finishing unevenly (ragged theta0 counts, different sweep counts per line)."""
+    import ibs_amd
+    import torch
+    dev = torch.device("cuda:0")
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    src_th = bo.theta_grid(513)
+    th = bo.theta_grid(N)
+    rng = np.random.default_rng(ns * 1000 + N)
+    plans = []
+    for variant in range(2):
+        geo = np.stack([[np.interp(th, src_th, g3["geo_513"][l % 16, k]) for k in range(8)] for l in range(ns * na)])
+        geo[:, 4:7] *= (1 + rng.uniform(-0.08, 0.08, len(geo)))[:, None, None]
+        geo[:, 2:4] *= (1 + rng.uniform(-0.08, 0.08, len(geo)))[:, None, None]
+        dP = -0.5 * np.mean((geo[:, 2] - geo[:, 7]) * geo[:, 0] ** 2, axis=1)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        plans.append(ibs_amd.ScanPlan(ctx, th[1] - th[0], [t(geo[:, k]) for k in range(7)], t(dP),
+                                      t(np.linspace(0, np.pi / 2, nt0)), ns))
+    want = []
+    for p in plans:
+        p.scan(); p.argmax()
+        torch.cuda.synchronize()
+        want.append((p.pack.clone(), p.gam.clone()))
+        p.pack.fill_(-7.0)
+    assert not torch.equal(want[0][0], want[1][0])
+    ctx.set_option("pack_mode", mode)              # 0 = the library's choice, 1 = write-through + sc1 loads, 2 = fences
+    got = []
+    reps = 60 if ns * na * nt0 <= 4096 else 6
+    for r in range(reps):
+        for k, p in enumerate(plans):
+            p.scan_argmax()
+            got.append((k, p.pack.clone()))        # (stream-ordered copy)
+    torch.cuda.synchronize()
+    for k, pk in got:
+        assert torch.equal(pk, want[k][0])
+    for k, p in enumerate(plans):
+        assert torch.equal(p.gam, want[k][1])
+        idx = p.pack[:, 1].long().cpu().numpy()
+        tab = p.gam.reshape(ns, -1).cpu().numpy()
+        assert np.array_equal(idx, tab.argmax(axis=1))                   # first maximum (ball_scan.py:283-288)
