@@ -60,16 +60,35 @@ struct Grp {
     if constexpr (P == 64) v = xmax(v, dpp_t<0x143, 0xC>(v, v));
     return bcast_last(v, lane);
   }
-  // inclusive prefix product inside each group
+  // inclusive prefix product inside each group (range and first-column remarks: scan_fwd in ibs_wave.hpp -- FP64 needs no
+  // renormalisation inside the scan; only (a, c, e) of the result are defined, the last step forms the first column only)
   template <typename T>
   __device__ __forceinline__ static M2<T> scan_fwd(M2<T> Q, int lane) {
+    constexpr bool RN = ScanNorm<T>::v;
     const int l16 = lane & 15, row = lane >> 4;
+    auto last_step = [&](const T Fa, const T Fc, const int Fe, const bool on) {
+      if (on) {
+        const T na = xfma(Q.a, Fa, Q.b * Fc);
+        Q.c = xfma(Q.c, Fa, Q.d * Fc);
+        Q.a = na;
+        Q.e += Fe;
+        if (RN) { const T m = xmax(xabs(Q.a), xabs(Q.c)); int ex; const T sc = pow2_scale_of(m, ex); Q.a *= sc; Q.c *= sc; Q.e += ex; }
+      }
+    };
     { const M2<T> F = dpp_fetch<T, 0x111, 0xF>(Q); if (l16 >= 1) Q = mul<T, false>(Q, F); }
-    { const M2<T> F = dpp_fetch<T, 0x112, 0xF>(Q); if (l16 >= 2) Q = mul<T, true>(Q, F); }
+    { const M2<T> F = dpp_fetch<T, 0x112, 0xF>(Q); if (l16 >= 2) Q = mul<T, RN>(Q, F); }
     { const M2<T> F = dpp_fetch<T, 0x114, 0xF>(Q); if (l16 >= 4) Q = mul<T, false>(Q, F); }
-    { const M2<T> F = dpp_fetch<T, 0x118, 0xF>(Q); if (l16 >= 8) Q = mul<T, true>(Q, F); }
-    if constexpr (P >= 32) { const M2<T> F = dpp_fetch<T, 0x142, 0xA>(Q); if (row & 1) Q = mul<T, P == 32>(Q, F); }
-    if constexpr (P == 64) { const M2<T> F = dpp_fetch<T, 0x143, 0xC>(Q); if (row >= 2) Q = mul<T, true>(Q, F); }
+    if constexpr (P == 16) {
+      last_step(dppz_t<0x118, 0xF>(Q.a), dppz_t<0x118, 0xF>(Q.c), dppz_i<0x118, 0xF>(Q.e), l16 >= 8);
+    } else {
+      { const M2<T> F = dpp_fetch<T, 0x118, 0xF>(Q); if (l16 >= 8) Q = mul<T, RN>(Q, F); }
+      if constexpr (P == 32) {
+        last_step(dppz_t<0x142, 0xA>(Q.a), dppz_t<0x142, 0xA>(Q.c), dppz_i<0x142, 0xA>(Q.e), (row & 1) != 0);
+      } else {
+        { const M2<T> F = dpp_fetch<T, 0x142, 0xA>(Q); if (row & 1) Q = mul<T, false>(Q, F); }
+        last_step(dppz_t<0x143, 0xC>(Q.a), dppz_t<0x143, 0xC>(Q.c), dppz_i<0x143, 0xC>(Q.e), row >= 2);
+      }
+    }
     return Q;
   }
   // inclusive suffix product inside each group

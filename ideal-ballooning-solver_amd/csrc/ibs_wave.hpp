@@ -234,17 +234,40 @@ __device__ __forceinline__ M2<T> lane_bcast(const M2<T>& s, int src_lane) {  // 
 }
 
 // inclusive prefix product over lanes:  P_L = A_L * A_{L-1} * ... * A_0.
-// Entries stay in range without renormalising every step: inputs have max-entry < 1, a product of
-// two such matrices is < 2, of four < 8; renormalise every second step.
+// Entries stay in range without renormalising every step: inputs have max-entry < 1, a product of two such matrices
+// is < 2, of four < 8; renormalise every second step.  (Dropping the renormalisation for FP64 altogether -- the upper
+// bound of a 64-fold product is 2^63 -- was tried in round 2: sweeps per solve went from 15.3 to 18.9 and the count
+// certificates of the rough config-5 systems failed; a product of normalised matrices has no LOWER bound.)
+// Only the FIRST COLUMN (a, c) and the exponent of the result are defined on return: every consumer takes the prefix as
+// "the solution that starts with (1, 0) at the left end" (incoming pair of the next lane, shooting value), so the last
+// step -- whose fetched factor is already a complete prefix -- fetches and forms the first column only.
+template <typename T>
+struct ScanNorm { static constexpr bool v = true; };
 template <typename T>
 __device__ __forceinline__ M2<T> scan_fwd(M2<T> P, int lane) {
+  constexpr bool RN = ScanNorm<T>::v;
   const int l16 = lane & 15, row = lane >> 4;
   { const M2<T> F = dpp_fetch<T, 0x111, 0xF>(P); if (l16 >= 1) mul_inplace<T, false>(P, F); }   // row_shr:1
-  { const M2<T> F = dpp_fetch<T, 0x112, 0xF>(P); if (l16 >= 2) mul_inplace<T, true>(P, F); }    // row_shr:2
+  { const M2<T> F = dpp_fetch<T, 0x112, 0xF>(P); if (l16 >= 2) mul_inplace<T, RN>(P, F); }      // row_shr:2
   { const M2<T> F = dpp_fetch<T, 0x114, 0xF>(P); if (l16 >= 4) mul_inplace<T, false>(P, F); }   // row_shr:4
-  { const M2<T> F = dpp_fetch<T, 0x118, 0xF>(P); if (l16 >= 8) mul_inplace<T, true>(P, F); }    // row_shr:8
+  { const M2<T> F = dpp_fetch<T, 0x118, 0xF>(P); if (l16 >= 8) mul_inplace<T, RN>(P, F); }      // row_shr:8
   { const M2<T> F = dpp_fetch<T, 0x142, 0xA>(P); if (row & 1) mul_inplace<T, false>(P, F); }    // row_bcast:15 -> rows 1,3
-  { const M2<T> F = dpp_fetch<T, 0x143, 0xC>(P); if (row >= 2) mul_inplace<T, true>(P, F); }    // row_bcast:31 -> rows 2,3
+  {                                                                                             // row_bcast:31 -> rows 2,3
+    const T Fa = dppz_t<0x143, 0xC>(P.a), Fc = dppz_t<0x143, 0xC>(P.c);
+    const int Fe = dppz_i<0x143, 0xC>(P.e);
+    if (row >= 2) {
+      const T na = xfma(P.a, Fa, P.b * Fc);
+      P.c = xfma(P.c, Fa, P.d * Fc);
+      P.a = na;
+      P.e += Fe;
+      if (RN) {                            // (first column only)
+        const T m = xmax(xabs(P.a), xabs(P.c));
+        int ex;
+        const T sc = pow2_scale_of(m, ex);
+        P.a *= sc; P.c *= sc; P.e += ex;
+      }
+    }
+  }
   return P;
 }
 // inclusive suffix product over lanes:  Q_L = B_L * B_{L+1} * ... * B_63
