@@ -26,6 +26,9 @@ def shard_surfaces(n_surf, rank, world):
 def pick_start(gam_table, alpha_scan, theta0_scan):
     """ball_scan.py:279-295: start point of the refinement from the coarse table (first maximum on ties;
     an all-zero table starts from (0, 0) with sigma0 = 0.05)."""
+    if not np.all(np.isfinite(gam_table)):
+        raise IbsError("coarse table holds %d non-finite growth rates (invalid geometry?)"
+                       % int(np.sum(~np.isfinite(gam_table))))
     m = np.max(gam_table)
     if m == 0.0:
         return 0.0, 0.0, 0.05, None
@@ -104,7 +107,12 @@ class BallooningScan:
             r = self.ctx.fieldline_geometry(self.tables, surf, np.tile(self.alpha_scan, len(self.own)), self.theta,
                                             device=self.device)
             t0 = torch.from_numpy(self.theta0_scan).to(self.device)
-            out = self.ctx.gamma_scan(self.h, *[r["geo"][k] for k in range(7)], r["dPdrho"], t0)
+            out = self.ctx.gamma_scan(self.h, *[r["geo"][k] for k in range(7)], r["dPdrho"], t0, want_info=True)
+            # device-pointer calls are asynchronous and return no count of flagged systems: read the info words
+            nbad = int(((out["info"] >> 16) != 0).sum().item())
+            if nbad:
+                raise IbsError("%d of %d coarse-scan solves were flagged (status word != 0: invalid data or iteration cap)"
+                               % (nbad, out["info"].numel()))
             return out["gam"].cpu().numpy().reshape(len(self.own), na, len(self.theta0_scan))
         geos = [np.asarray(self.fieldlines(self.rho_arr[k], self.alpha_scan)) for k in self.own]
         if not geos:
@@ -112,6 +120,8 @@ class BallooningScan:
         geo = np.concatenate(geos, axis=0)                                 # (n_own*nalpha, 8, N)
         dP = -0.5 * np.mean((geo[:, 2] - geo[:, 7]) * geo[:, 0] ** 2, axis=1)   # ball_scan.py:262
         r = self.ctx.gamma_scan(self.h, *[np.ascontiguousarray(geo[:, k]) for k in range(7)], dP, self.theta0_scan)
+        if r.get("nbad", 0):
+            raise IbsError("%d coarse-scan solves were flagged (status word != 0: invalid data or iteration cap)" % r["nbad"])
         return np.asarray(r["gam"]).reshape(len(self.own), len(self.alpha_scan), len(self.theta0_scan))
 
     # -- A6: objective with gradient at one point of one surface (utils.py:1632-1728)

@@ -7,7 +7,8 @@
  *
  * Conventions
  *   - return value: 0 = ok; < 0 = argument/runtime error (text via ibs_last_error());
- *     > 0 = number of systems whose info word reports a non-zero status.
+ *     > 0 = number of systems whose info word reports a non-zero status (IBS_MEM_HOST calls only: a device-pointer
+ *     call is asynchronous and returns 0 -- request the info words and look at their status bits).
  *   - `mem`: IBS_MEM_DEVICE = all data pointers are device (HBM) pointers, the call is
  *     asynchronous on the context's stream; IBS_MEM_HOST = host pointers, the library stages
  *     through its own device workspace and the call returns after the results are back.

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libibs_oracle.so")
+_SO = os.environ.get("IBS_ORACLE_SO") or os.path.join(_HERE, "_build", "libibs_oracle.so")   # (override: sanitizer build)
 _lib = None
 
 

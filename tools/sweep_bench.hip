@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) k(int N, double h, const double* g, const
       if (C == 0) hi = sig; else lo = sig;
       if (hi - lo < 1e-13) { lo = lo0; hi = hi0; }
       sig = 0.5 * (lo + hi);
-      acc += ws.zu[3];
+      acc += ws.u0_in;
     }
     if (lane == 0) out[blockIdx.x * 4 + wave] = acc + sig;
     return;
