@@ -44,6 +44,7 @@ struct ibs_options {
   int force_p = 0;        // lanes per system: 64 | 32 | 16
   int scan_chain = 0;     // theta0 values chained through one wave / group
   int geo_lpp = 0;        // lanes per grid point of the geometry kernel: 1 | 2 | 4
+  int gcf_rows = -1;      // raw systems on long grids: -1 / 1 = row-streamed kernel, 0 = the 3-row staging of k_solve_gcf
   int pack_mode = 0;      // hand-off of the fused scan + argmax: 1 = write-through + sc1 loads, 2 = release / acquire fences
   double chain_w1 = 0.25, chain_w2 = 1.0;   // relative widths of the chain's warm starts
 };
@@ -214,6 +215,12 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
       auto fn = ibs::launch_table().gcf_f64_g[P == 32 ? 0 : 1][Mg];
       if (fn) { launch = fn; M = Mg; per_wave = (size_t)(64 / P) * ibs::lds_pitch(N) * sizeof(T); }
     }
+  }
+  if constexpr (sizeof(T) == 8) {
+    // long grids, one wave per system: stream the three rows through ONE LDS row per wave (k_solve_gcf_rows) -- the
+    // 3-row staging of k_solve_gcf leaves two waves per CU at N_zeta = 2048 and five at 1024
+    auto fr = ibs::launch_table().gcf_rows_f64[M];
+    if (!gh && launch == table[M] && fr && ctx->opt.gcf_rows != 0) { launch = fr; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(T); }
   }
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
@@ -390,6 +397,7 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   if (n == "force_p") c->opt.force_p = reset ? c->opt_created.force_p : (int)value;
   else if (n == "scan_chain") c->opt.scan_chain = reset ? c->opt_created.scan_chain : (int)value;
   else if (n == "geo_lpp") c->opt.geo_lpp = reset ? c->opt_created.geo_lpp : (int)value;
+  else if (n == "gcf_rows") c->opt.gcf_rows = reset ? c->opt_created.gcf_rows : (int)value;
   else if (n == "pack_mode") c->opt.pack_mode = reset ? c->opt_created.pack_mode : (int)value;
   else if (n == "chain_w1") c->opt.chain_w1 = reset ? c->opt_created.chain_w1 : value;
   else if (n == "chain_w2") c->opt.chain_w2 = reset ? c->opt_created.chain_w2 : value;

@@ -217,8 +217,11 @@ __device__ __forceinline__ void simpson_point(const Src& src, int j, T w, T X, T
 // are added by the first and last lane.  Same per-point arithmetic as finish() (utils.py:1601-1621).  X and dX, when
 // requested, go through the wave's LDS row Xs (which may alias an LDS array of `src`: it is written after the
 // sums) to be stored coalesced.
-template <typename T, int M, class Src, bool HF>
-__device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& src, int N, T h, T* Xs, T lam,
+// PASSES > 1 (row-streamed raw systems, k_solve_gcf_rows): the Simpson sums are separable in (g, c, f), so they are
+// accumulated in PASSES sweeps over the rows, `src.begin_pass(p)` putting the p-th coefficient array into the wave's one
+// LDS row in between (the other two read as zero).
+template <typename T, int M, class Src, bool HF, int PASSES = 1>
+__device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, Src& src, int N, T h, T* Xs, T lam,
                                              const SolveInfo& inf, long sys, T* lam_out, T* gam_out,
                                              T* X_out, T* dX_out, T* dth0_out, int* info_out, const T* gh = nullptr) {
   static_assert(M >= 3, "the halo exchange takes two rows from each neighbour lane");
@@ -277,7 +280,11 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, const Src& sr
     if (do_hf) all_points(std::true_type{});
     else all_points(std::false_type{});
   } else {
-    all_points(std::false_type{});
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      if constexpr (PASSES > 1) src.begin_pass(pass);
+      all_points(std::false_type{});
+    }
   }
   IBS_PROBE_AT(14);
   y0 = wave_sum(y0); y1 = wave_sum(y1);
@@ -359,6 +366,144 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
                                    nullptr, valid ? info_out : nullptr, static_cast<const NoTangent*>(nullptr), nullptr,
                                    gh ? gh + sysc * ld : nullptr);
   }
+}
+
+// ---------------------------------------------------------------- raw (g, c, f) systems on long grids: one LDS row per wave
+// k_solve_gcf stages g, c and f of its system side by side (3 N doubles per wave: 55 KB at N_zeta = 2048 -> two waves per
+// CU, 28 KB at 1024 -> five).  Here the three rows pass through ONE row, one after the other, the way k_sturm_count moves
+// them: set-up is split into a g pass (half-grid e, diagonal scaling), an f pass and a c pass; after the solve the growth
+// rate re-stages g (scaling of the eigenvector + the g dX^2 sum), then c, then f.  LDS per wave: N doubles.
+template <typename T, int M>
+__device__ __forceinline__ void stage_row(T* row, const T* __restrict__ src, int N, int lane) {
+  // batches of up to 17 coalesced loads in flight (34 VGPRs), then their LDS writes
+  constexpr int B = 17;
+#pragma unroll
+  for (int k0 = 0; k0 <= M; k0 += B) {
+    T v[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) { const int j = lane + (k0 + k) * kWave; v[k] = (k0 + k <= M && j < N) ? src[j] : T(0); }
+#pragma unroll
+    for (int k = 0; k < B; ++k) { const int j = lane + (k0 + k) * kWave; if (k0 + k <= M && j < N) row[lpos(j)] = v[k]; }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <typename T, int M>
+struct SrcRows {
+  static constexpr bool kHasGh = false;
+  T* row; const T* gg; const T* cg; const T* fg; int N, lane, which;     // which: the array the row holds now (0 g, 1 c, 2 f)
+  __device__ __forceinline__ T g(int j) const { return row[lpos(j)]; }
+  __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const {
+    const T v = row[lpos(j)];
+    g_ = which == 0 ? v : T(0); c_ = which == 1 ? v : T(0); f_ = which == 2 ? v : T(0);
+  }
+  __device__ __forceinline__ void hold(int w) {
+    wave_lds_sync();
+    stage_row<T, M>(row, w == 0 ? gg : (w == 1 ? cg : fg), N, lane);
+    wave_lds_sync();
+    which = w;
+  }
+  __device__ __forceinline__ void begin_pass(int p) { if (which != p) hold(p); }
+};
+// set-up of WaveSolver from the three rows streamed through `s.row` (same quantities as WaveSolver::setup; the bounds are
+// formed from the scaled rows: c/f = (c s^2)/(f s^2), ...)
+template <typename T, int M>
+__device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& s, int N, T h) {
+  const int lane = s.lane;
+  ws.lane = lane;
+  const int n = N - 2;
+  const int rem = n - kWave * (M - 1);
+  ws.has_last = lane < rem;
+  const bool hl = ws.has_last;
+  int a = WaveSolver<T, M>::rows_start(lane, n);
+  const T ih2 = T(1) / (h * h);
+  T esum[M], s2[M];
+  bool bad = false;
+  s.hold(0);                                             // ---- g: half-grid e (utils.py:1574-1576), scaling e s_i s_{i+1} = 1
+  T e_first, e_last;
+  {
+    const T g0 = s.row[lpos(a)];
+    T gcur = s.row[lpos(a + 1)];
+    T e_lo = T(0.5) * (g0 + gcur) * ih2;
+    e_first = e_lo;
+    bad = !(g0 > T(0)) || !(gcur > T(0));
+    T sc = T(1);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      if ((i < M - 1) || hl) {
+        const T gnext = s.row[lpos(a + i + 2)];
+        const T e_hi = T(0.5) * (gcur + gnext) * ih2;
+        bad = bad || !(gnext > T(0)) || !(e_hi > T(0));
+        esum[i] = e_lo + e_hi; s2[i] = sc * sc;
+        sc = fast_rcp(e_hi * sc);
+        gcur = gnext; e_lo = e_hi;
+      } else { esum[i] = T(0); s2[i] = T(0); }
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    ws.kap = sc; ws.ikap = fast_rcp(sc);
+    e_last = e_lo;
+    bad = bad || !(e_first > T(0));
+  }
+  T sum_c = T(0), sum_f = T(0);
+  s.hold(2);                                             // ---- f
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    if ((i < M - 1) || hl) {
+      const T fj = s.row[lpos(a + i + 1)];
+      ws.Ph[i] = fj * s2[i];
+      sum_f += fj;
+      bad = bad || !(fj > T(0));
+    } else ws.Ph[i] = T(0);
+  }
+  s.hold(1);                                             // ---- c: d = c - (e_lo + e_hi)  (utils.py:1584-1592)
+  T vhi = -T(1e300), vlo = -T(1e300), vna = T(0);
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    if ((i < M - 1) || hl) {
+      const T cj = s.row[lpos(a + i + 1)];
+      const T d = cj - esum[i];
+      ws.D[i] = d * s2[i];
+      const T rPh = fast_rcp(ws.Ph[i]);                  // bounds only (margins added below)
+      vhi = xmax(vhi, (cj * s2[i]) * rPh);
+      vlo = xmax(vlo, ws.D[i] * rPh);
+      vna = xmax(vna, ((xabs(d) + esum[i]) * s2[i]) * rPh);
+      sum_c += cj;
+      bad = bad || !finite_of(cj);
+    } else ws.D[i] = T(0);
+  }
+  const T e0 = readlane_t(e_first, 0), en = readlane_t(e_last, kWave - 1);
+  const T sc_all = wave_sum(sum_c), sf_all = wave_sum(sum_f);
+  ws.normA = uniform(wave_max(vna));
+  ws.hi = uniform(wave_max(vhi));
+  ws.lo = uniform(xmax(wave_max(vlo), (sc_all - e0 - en) / sf_all));
+  ws.hi += T(8) * Eps<T>::v * ws.normA;
+  ws.lo -= T(8) * Eps<T>::v * ws.normA;
+  return __any(bad) != 0;
+}
+
+template <typename T, int M>
+__global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, const T* __restrict__ g,
+                                                        const T* __restrict__ c, const T* __restrict__ f, long ld,
+                                                        T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out) {
+  static_assert(M >= 3, "long grids only");
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const long sys = (long)blockIdx.x * wpb + wave;
+  const bool valid = sys < n_sys;
+  const long sysc = valid ? sys : (n_sys - 1);
+  T* row = smem + (size_t)wave * lds_pitch(N);
+  SrcRows<T, M> src{row, g + sysc * ld, c + sysc * ld, f + sysc * ld, N, lane, -1};
+  WaveSolver<T, M> ws;
+  SolveInfo inf{0, 0};
+  const bool bad = setup_rows<T, M>(ws, src, N, h);
+  T lam = T(0);
+  if (!bad) lam = ws.solve(inf);
+  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  src.hold(0);                                           // g: the eigenvector's scaling is rebuilt from it, then the g dX^2 sum
+  finish_chunk<T, M, SrcRows<T, M>, false, 3>(ws, src, N, h, row, lam, inf, sysc, valid ? lam_out : nullptr,
+                                              valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                              nullptr, valid ? info_out : nullptr);
 }
 
 // ---------------------------------------------------------------- geometry-fed theta0 scan
@@ -803,6 +948,22 @@ static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
   return hipGetLastError();
 }
 template <typename T>
+static hipError_t launch_gcf_rows(const GcfArgs<T>& a, hipStream_t st) {
+  if constexpr (IBS_M >= 3) {
+    const int wpb = a.wpb;
+    const size_t lds = (size_t)wpb * lds_pitch(a.N) * sizeof(T);
+    const long nblk = (a.n_sys + wpb - 1) / wpb;
+    auto kern = k_solve_gcf_rows<T, IBS_M>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
+                       a.lam, a.gam, a.X, a.dX, a.info);
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+template <typename T>
 static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
   const size_t lds = (size_t)(7 + wpb) * lds_pitch(a.N) * sizeof(T) + (a.pack ? 128 : 0);
@@ -861,6 +1022,12 @@ struct IBS_CAT(Registrar, IBS_M) {
   IBS_CAT(Registrar, IBS_M)() {
     LaunchTable& t = launch_table();
     t.gcf_f64[IBS_M] = &launch_gcf<double>;
+#if IBS_M >= 24
+    // long grids (N >= 1475, e.g. N_zeta = 2048): one LDS row per wave -> four waves per CU (registers: one per SIMD) where
+    // the three-row staging admits three (M = 24..28) or two (M = 29..32).  Below, the three-row kernel holds as many or
+    // more waves and is faster (N_zeta = 1024, M = 16: 198 VGPRs, two waves per SIMD, 3.7e7 against 3.0e7 solves/s)
+    t.gcf_rows_f64[IBS_M] = &launch_gcf_rows<double>;
+#endif
     t.scan_f64[IBS_M] = &launch_scan<double>;
     t.scan_chain_f64[IBS_M] = &launch_scan_chain<double>;
     t.sturm_f64[IBS_M] = &launch_sturm<double>;

@@ -880,3 +880,32 @@ def test_fused_scan_argmax_equals_two_launches(ctx, bo, ns, na, nt0, N, mode):
         idx = p.pack[:, 1].long().cpu().numpy()
         tab = p.gam.reshape(ns, -1).cpu().numpy()
         assert np.array_equal(idx, tab.argmax(axis=1))                   # first maximum (ball_scan.py:283-288)
+
+
+@pytest.mark.parametrize("N", [1475, 1537, 1985, 2049])
+def test_row_streamed_raw_kernel_matches_three_row_staging(ctx, bo, N):
+    """k_solve_gcf_rows (long grids: g, c, f streamed through ONE LDS row per wave, set-up and growth rate in passes)
+    against k_solve_gcf (three rows staged side by side) and the oracle: lam, gam, X, dX, flags; ragged batch sizes"""
+    rng = np.random.default_rng(N)
+    n = 37
+    params = np.stack([rng.uniform(0.3, 2, n), rng.uniform(0.2, 1.2, n), rng.uniform(0, 1.5, n)], 1)
+    th, g, c = salpha_batch(bo, N, params)
+    f = g * (1 + 0.3 * np.sin(th)[None] ** 2)
+    h = th[1] - th[0]
+    ctx.set_option("force_p", 64)
+    ctx.set_option("gcf_rows", 0)
+    ref = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
+    ctx.set_option("gcf_rows", 1)
+    new = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
+    assert ref["nbad"] == 0 and new["nbad"] == 0
+    normA = 4.0 / h ** 2 + 4.0                    # lam is certified to 256 ulp(||A||) = 5.7e-14 ||A||; gam is second order
+    assert np.abs(new["lam"] - ref["lam"]).max() < 2e-13 * normA and np.abs(new["gam"] - ref["gam"]).max() < 1e-10
+    assert np.abs(new["X"] - ref["X"]).max() < 1e-6 and np.abs(new["dX"] - ref["dX"]).max() < 1e-5
+    for k in (0, 17, 36):
+        go, lo, Xo, dXo = bo.solve_gcf(th, g[k], c[k], f[k])
+        assert abs(new["gam"][k] - go) < 1e-9 and abs(new["lam"][k] - lo) < 1e-9
+        assert np.abs(new["X"][k] - Xo).max() < max(1e-6, eigvec_tol(bo, th, g[k], c[k], f[k]))
+    bad = g.copy(); bad[5, 100] = -1.0; bad[9, 7] = np.nan
+    r = ctx.solve_gcf(h, bad, c, f, want_info=True)
+    flagged = np.nonzero((r["info"] >> 16) != 0)[0]
+    assert list(flagged) == [5, 9] and np.abs(np.delete(r["gam"], [5, 9]) - np.delete(new["gam"], [5, 9])).max() < 1e-12
