@@ -1,6 +1,6 @@
 set -o pipefail
 T=${1:-r02a}
 mkdir -p gpurun_out/$T
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$T/pytest.log
-tail -12 gpurun_out/$T/pytest.log
-python bench.py --steps 300 --no-cpu 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"], d[\"roofline\"][\"kernel_ms\"], d[\"stress\"][\"solves_per_s\"])"
+bash tools/run_profiles.sh ${T} > gpurun_out/$T/profiles.log 2>&1; echo "profiles rc=$?"
+python bench.py --steps 20 --warmup 5 > gpurun_out/$T/bench20.json 2> gpurun_out/$T/bench20.err; echo "bench20 rc=$?"
+python tools/bench_pipeline.py > gpurun_out/$T/pipeline.txt 2>&1; echo "pipeline rc=$?"; tail -4 gpurun_out/$T/pipeline.txt
