@@ -1,6 +1,4 @@
 set -o pipefail
 T=${1:-r02a}
 mkdir -p gpurun_out/$T
-bash tools/run_profiles.sh ${T} > gpurun_out/$T/profiles.log 2>&1; echo "profiles rc=$?"
-python bench.py --steps 20 --warmup 5 > gpurun_out/$T/bench20.json 2> gpurun_out/$T/bench20.err; echo "bench20 rc=$?"
-python tools/bench_pipeline.py > gpurun_out/$T/pipeline.txt 2>&1; echo "pipeline rc=$?"; tail -4 gpurun_out/$T/pipeline.txt
+timeout -k 10 600 python tools/bench_p32_long.py > gpurun_out/$T/p32.txt 2>&1; echo "rc=$?"; grep -v amdgpu gpurun_out/$T/p32.txt
