@@ -384,13 +384,19 @@ class C2Sharded:
         self.alphas = np.linspace(0, np.pi, self.NA)
         self.alphas_d = torch.from_numpy(self.alphas).to(device)
         self.t0_d = torch.from_numpy(np.linspace(0, np.pi / 2, self.NT0)).to(device)
+        self.th_d = torch.from_numpy(self.th).to(device)
+        self._lines = {}                                    # own surfaces -> (line_surf, line_alpha) resident in HBM
 
     def local_rows(self, own):
         import torch
         if len(own) == 0:
             return torch.empty((0, 3), dtype=torch.float64, device=self.device)
-        surf = np.repeat(np.asarray(own), self.NA); al = np.tile(self.alphas, len(own))
-        r = self.ctx.fieldline_geometry(self.tabs, surf, al, self.th, device=self.device)
+        key = tuple(own)
+        if key not in self._lines:
+            self._lines[key] = (torch.from_numpy(np.repeat(np.asarray(own), self.NA).astype(np.int32)).to(self.device),
+                                torch.from_numpy(np.tile(self.alphas, len(own))).to(self.device))
+        surf, al = self._lines[key]
+        r = self.ctx.fieldline_geometry(self.tabs, surf, al, self.th_d, device=self.device)
         sc = self.ctx.gamma_scan(self.h, *[r["geo"][k] for k in range(7)], r["dPdrho"], self.t0_d)
         idx, val = self.ctx.surface_argmax(sc["gam"].reshape(len(own), -1))
         idx = idx.long()
@@ -426,14 +432,17 @@ def c2_sharded_leg(ctx, device, rank, world, dist, fence, passes=20):
         bitwise = bool(torch.equal(per_shard, full))
         dmax = float((one_launch[:, 0] - full[:, 0]).abs().max().item())
         same_arg = bool(torch.equal(one_launch[:, 1:], full[:, 1:]))
-        assert bitwise, "gathered per-surface table differs from the same launches on one GPU"
-        assert dmax < 1e-10, "sharded vs single-launch gam_max differ by %g" % dmax
+        # (reported, not raised: a rank that dies here would leave the others waiting in the final barrier)
+        ok = bitwise and dmax < 1e-10
+        if not ok:
+            print("bench.py: ncsx_c2_sharded check FAILED (bitwise=%s, max|dgam| vs single launch=%g)" % (bitwise, dmax),
+                  file=sys.stderr, flush=True)
         n = job.NS * job.NA * job.NT0
         out = dict(workload="configs[2]: 64 surfaces x 32 alpha x 16 theta0 = %d solves, N_zeta=1024, NCSX_op wout tables; "
                             "surfaces round-robin over %d ranks, geometry -> scan -> argmax per rank, ONE all-gather of "
                             "[n_surf_local, 3]" % (n, world),
                    scaling="strong", n_gpus=world, passes=passes, ms_per_pass=dt / passes * 1e3,
-                   solves_per_s=n * passes / dt, gathered_equals_one_gpu_bitwise=bitwise,
+                   solves_per_s=n * passes / dt, checks_passed=ok, gathered_equals_one_gpu_bitwise=bitwise,
                    max_abs_dgam_vs_single_launch=dmax, same_argmax_as_single_launch=same_arg,
                    gam_max_min=float(full[:, 0].min().item()), gam_max_max=float(full[:, 0].max().item()))
     return out
@@ -557,13 +566,22 @@ def main():
     torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in un])) / per
     empty_ms = float(np.median([c.elapsed_time(d) for c, d in emp]))
+    gather_ok = None
     if use_dist:      # every rank holds every rank's maxima of the last step; its own row must be what it sent
-        assert torch.equal(gathered[rank * N_SURF:(rank + 1) * N_SURF].to(device), plan.pack), "all-gather result does not match the local maxima"
+        okt = torch.tensor([1.0 if torch.equal(gathered[rank * N_SURF:(rank + 1) * N_SURF].to(device), plan.pack) else 0.0],
+                           dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)       # (reported, not raised: no rank may leave the others in a collective)
+        gather_ok = bool(okt.item() == 1.0)
     info = plan.info.cpu().numpy()
     nbad = int(((info >> 16) != 0).sum())
     sweeps = float((info & 0xffff).mean())
 
-    c2 = c2_sharded_leg(ctx, device, rank, world, dist, fence) if (use_dist and backend == "nccl" or (use_dist and share)) else None
+    c2 = None
+    if use_dist:
+        try:
+            c2 = c2_sharded_leg(ctx, device, rank, world, dist, fence)
+        except Exception as e:          # (every rank runs the same collectives inside the leg; an error is reported, not raised)
+            c2 = dict(error="%s: %s" % (type(e).__name__, e)) if rank == 0 else None
 
     if rank == 0:
         bytes_per_solve = (7 * NPTS * 8 + 8) / N_THETA0 + 8            # geometry-fed path
@@ -584,7 +602,7 @@ def main():
                                    + (" + all-gather (%s, %d ranks) of the per-surface maxima" % (
                                        "RCCL" if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
-                       "nonconverged": nbad, "ranks_in_collective": n_ranks,
+                       "nonconverged": nbad, "ranks_in_collective": n_ranks, "allgather_roundtrip_ok": gather_ok,
                        "untimed_spinup_steps": args.warmup + n_spin},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("ibs::k_gamma_scan<double"),

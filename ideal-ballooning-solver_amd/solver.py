@@ -186,11 +186,13 @@ class Context:
         device=None: numpy in / numpy out (staged);  device=torch.device(...): results stay in HBM."""
         n_lines = len(line_surf)
         N = len(theta)
-        ls = np.ascontiguousarray(line_surf, dtype=np.int32)
-        la = np.ascontiguousarray(line_alpha, dtype=np.float64)
-        th = np.ascontiguousarray(theta, dtype=np.float64)
-        if ls.size and (ls.min() < 0 or ls.max() >= len(tables.s)):
-            raise IbsError("line_surf out of range")
+        resident = device is not None and all(_is_torch(a) for a in (line_surf, line_alpha, theta))
+        if not resident:
+            ls = np.ascontiguousarray(line_surf, dtype=np.int32)
+            la = np.ascontiguousarray(line_alpha, dtype=np.float64)
+            th = np.ascontiguousarray(theta, dtype=np.float64)
+            if ls.size and (ls.min() < 0 or ls.max() >= len(tables.s)):
+                raise IbsError("line_surf out of range")
         host = [tables.xm, tables.xn, tables.xm_nyq, tables.xn_nyq, tables.tab_mn, tables.tab_nyq, tables.scal]
         rows = [tables.rows_mn, tables.rows_nyq] if use_rows else [np.zeros((0, 2), np.int32)] * 2
         if device is None:
@@ -207,7 +209,11 @@ class Context:
         allc = self._device_tables(tables, device)
         dev = allc[:7]
         d_rows = allc[7:]
-        d_ls, d_la, d_th = (torch.from_numpy(a).to(device) for a in (ls, la, th))
+        if resident:      # index / angle / grid tensors already in HBM (int32, float64, float64): no upload, no host check
+            #               (the geometry kernel clamps the surface index itself)
+            d_ls, d_la, d_th = line_surf.to(torch.int32).contiguous(), line_alpha.to(torch.float64).contiguous(), theta.to(torch.float64).contiguous()
+        else:
+            d_ls, d_la, d_th = (torch.from_numpy(a).to(device) for a in (ls, la, th))
         geo = torch.empty((8, n_lines, N), dtype=torch.float64, device=device)
         dP = torch.empty((n_lines,), dtype=torch.float64, device=device)
         self._stream_from_torch(geo)
