@@ -359,13 +359,13 @@ def spawn_ranks(n, argv):
     return rc
 
 
-def sharded_surface_pass(local_rows, n_surf, rank, world, dist):
+def sharded_surface_pass(local_rows, n_surf, rank, world, dist, ctx=None):
     """one pass of a surface-sharded scan (ball_scan.py:172, 251-252: one process group per surface): this rank's
     surfaces -> local_rows(own) = (len(own), k) tensor -> ONE all-gather -> (n_surf, k) in surface order everywhere.
     No other collective is on the data path."""
     import ibs_amd
     own = ibs_amd.shard_surfaces(n_surf, rank, world)
-    return ibs_amd.gather_rows_tensor(local_rows(own), n_surf, rank, world, dist)
+    return ibs_amd.gather_rows_tensor(local_rows(own), n_surf, rank, world, dist, ctx)
 
 
 class C2Sharded:
@@ -403,16 +403,17 @@ class C2Sharded:
         return torch.stack([val, self.alphas_d[idx // self.NT0], self.t0_d[idx % self.NT0]], dim=1)
 
 
-def c2_sharded_leg(ctx, device, rank, world, dist, fence, passes=20):
+def c2_sharded_leg(ctx, device, rank, world, dist, fence, passes=20, native=False):
     """the north-star multi-GPU leg: strong scaling of configs[2] over the ranks.  Returns the leg's dict on rank 0."""
     import torch
     import ibs_amd
     job = C2Sharded(ctx, device)
-    full = sharded_surface_pass(job.local_rows, job.NS, rank, world, dist)        # warm-up + the table to check
+    cc = ctx if native else None
+    full = sharded_surface_pass(job.local_rows, job.NS, rank, world, dist, cc)    # warm-up + the table to check
     fence()
     t0 = time.perf_counter()
     for _ in range(passes):
-        full = sharded_surface_pass(job.local_rows, job.NS, rank, world, dist)
+        full = sharded_surface_pass(job.local_rows, job.NS, rank, world, dist, cc)
     fence()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -505,6 +506,20 @@ def main():
     # stream time on this platform (60 us per step) than the collective they hide (39 us in-stream vs 30 us without);
     # async_op=True from a ring of buffers is host-bound in torch's Work bookkeeping (56 us per step).
     gathered = torch.empty((n_ranks * N_SURF, 2), dtype=torch.float64, device=coll_dev) if use_dist else None
+    # The per-step gather is ONE ncclAllGather issued by libibs_hip.so itself on the step's stream (ibs_comm_*), not by
+    # torch.distributed: measured with a one-rank group, 30.9 us per step against 46.1 us (29.0 us without a collective) --
+    # torch's per-collective host work (~17 us) is what bounded the step.  Every rank creates its communicator or none does
+    # (then torch.distributed carries the gather); IBS_BENCH_NATIVE_COLL=0 switches it off.
+    native = False
+    if use_dist and backend == "nccl" and os.environ.get("IBS_BENCH_NATIVE_COLL", "1") != "0":
+        flag = torch.ones(1, dtype=torch.float64, device=device)
+        try:
+            ctx.comm_init(dist, rank, n_ranks)
+        except Exception as e:
+            print("bench.py: native RCCL communicator not available (%s); using torch.distributed" % e, file=sys.stderr)
+            flag.zero_()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank or none
+        native = bool(flag.item() == 1.0)
 
     def step(k=0, ev=None):
         # scan + per-surface first maximum: ONE kernel (the block that completes a surface reduces it)
@@ -513,7 +528,9 @@ def main():
         plan.scan_argmax()
         if ev is not None:
             ev[1].record()
-        if use_dist:
+        if native:
+            ctx.allgather(plan.pack, gathered)
+        elif use_dist:
             dist.all_gather_into_tensor(gathered, plan.pack if backend == "nccl" else plan.pack.cpu())
 
     def fence():
@@ -579,7 +596,7 @@ def main():
     c2 = None
     if use_dist:
         try:
-            c2 = c2_sharded_leg(ctx, device, rank, world, dist, fence)
+            c2 = c2_sharded_leg(ctx, device, rank, world, dist, fence, native=native)
         except Exception as e:          # (every rank runs the same collectives inside the leg; an error is reported, not raised)
             c2 = dict(error="%s: %s" % (type(e).__name__, e)) if rank == 0 else None
 
@@ -600,7 +617,7 @@ def main():
             "config": {"workload": "configs[1] D3D-shape: 16 surfaces x 8 alpha x 8 theta0 = 1024 solves/step/GPU, "
                                    "N_zeta=512 (513 points), geometry-fed scan with fused per-surface argmax (one launch)"
                                    + (" + all-gather (%s, %d ranks) of the per-surface maxima" % (
-                                       "RCCL" if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
+                                       ("RCCL, issued natively by the library" if native else "RCCL") if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
                        "nonconverged": nbad, "ranks_in_collective": n_ranks, "allgather_roundtrip_ok": gather_ok,
                        "untimed_spinup_steps": args.warmup + n_spin},
@@ -646,6 +663,8 @@ def main():
             out.update(ncsx_pipeline(ctx, device))
         print(json.dumps(out), flush=True)
     if use_dist:
+        if native:
+            ctx.comm_destroy()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -25,6 +25,11 @@ SYMBOLS = {
     "ibs_set_stream": (C.c_int, [_P, _P]),
     "ibs_synchronize": (C.c_int, [_P]),
     "ibs_set_option": (C.c_int, [_P, C.c_char_p, _D]),
+    "ibs_comm_load": (C.c_int, [C.c_char_p]),
+    "ibs_comm_unique_id": (C.c_int, [_P]),
+    "ibs_comm_init": (C.c_int, [_P, _P, _I32, _I32]),
+    "ibs_comm_allgather_f64": (C.c_int, [_P, _P, _P, _I64]),
+    "ibs_comm_destroy": (C.c_int, [_P]),
     "ibs_lbfgsb2_state_bytes": (C.c_int, []),
     "ibs_lbfgsb2_init": (C.c_int, [_P, _P, _P, _P, _D, _D, _I32, _I32]),
     "ibs_lbfgsb2_step": (C.c_int, [_P, _D, _P, _P]),

@@ -1,6 +1,8 @@
 // C-ABI layer of libibs_hip.so (declarations and reference citations: include/ibs.h).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,12 +60,29 @@ struct ibs_ctx {
   size_t ws_bytes = 0;
   int lds_per_block = 160 * 1024;
   int n_cu = 256;
+  // native RCCL communicator of this rank (ibs_comm_init), null = none
+  void* comm = nullptr;
+  int comm_rank = 0, comm_n = 1;
   // per-surface arrival counters of the fused scan + argmax kernel (zero between launches)
   int* surf_counter = nullptr;
   int surf_counter_n = 0;
 };
 
 namespace {
+
+// RCCL, bound at run time (the library carries no link-time dependency on it; in a PyTorch process the copy PyTorch has
+// already loaded is used).  ncclUniqueId is a 128-byte struct passed BY VALUE to ncclCommInitRank.
+struct nccl_id_t { char internal[128]; };
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(nccl_id_t*) = nullptr;
+  int (*CommInitRank)(void**, int, nccl_id_t, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi& rccl() { static RcclApi a; return a; }
+constexpr int kNcclFloat64 = 8;          // ncclDataType_t (rccl.h)
 
 // every entry point runs on the context's device and leaves the caller's current device as it found it
 struct DeviceGuard {
@@ -431,6 +450,76 @@ int ibs_lbfgsb2_result(const void* state, double* x, double* f, int32_t* counter
   if (x) { x[0] = s.x[0]; x[1] = s.x[1]; }
   if (f) *f = s.f;
   if (counters) { counters[0] = s.n_iterations; counters[1] = s.nfgv; counters[2] = s.task; counters[3] = s.n_restarts; counters[4] = s.nskip; }
+  return 0;
+}
+
+// ---- native collective: ONE ncclAllGather of the per-surface rows on the context's stream
+int ibs_comm_load(const char* librccl_path) {
+  RcclApi& a = rccl();
+  if (a.handle) return 0;
+  const char* cands[3] = {librccl_path, "librccl.so.1", "librccl.so"};
+  void* h = nullptr;
+  for (const char* c : cands) {
+    if (!c) continue;
+    h = dlopen(c, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);          // the copy this process already holds, if any
+    if (!h) h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return fail(IBS_ERR_UNSUPPORTED, "librccl not found (%s)", dlerror());
+  a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+  a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy)
+    return fail(IBS_ERR_UNSUPPORTED, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+  a.handle = h;
+  return 0;
+}
+
+static int nccl_fail(const char* what, int rc) {
+  RcclApi& a = rccl();
+  return fail(IBS_ERR_HIP, "%s -> %s", what, a.GetErrorString ? a.GetErrorString(rc) : "rccl error");
+}
+
+int ibs_comm_unique_id(void* id128) {
+  if (!id128) return fail(IBS_ERR_ARG, "null pointer");
+  if (!rccl().handle) { if (int r = ibs_comm_load(nullptr)) return r; }
+  const int rc = rccl().GetUniqueId(static_cast<nccl_id_t*>(id128));
+  return rc ? nccl_fail("ncclGetUniqueId", rc) : 0;
+}
+
+int ibs_comm_init(ibs_ctx* c, const void* id128, int32_t rank, int32_t nranks) {
+  if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(IBS_ERR_ARG, "bad arguments");
+  if (!rccl().handle) { if (int r = ibs_comm_load(nullptr)) return r; }
+  if (c->comm) return fail(IBS_ERR_ARG, "the context already holds a communicator");
+  ON_DEVICE(c);
+  nccl_id_t id;
+  memcpy(&id, id128, sizeof(id));
+  void* comm = nullptr;
+  const int rc = rccl().CommInitRank(&comm, nranks, id, rank);
+  if (rc) return nccl_fail("ncclCommInitRank", rc);
+  c->comm = comm; c->comm_rank = rank; c->comm_n = nranks;
+  return 0;
+}
+
+int ibs_comm_allgather_f64(ibs_ctx* c, const double* send, double* recv, int64_t count_per_rank) {
+  if (!c || !send || !recv || count_per_rank < 0) return fail(IBS_ERR_ARG, "bad arguments");
+  if (!c->comm) return fail(IBS_ERR_ARG, "no communicator: call ibs_comm_init first");
+  ON_DEVICE(c);
+  const int rc = rccl().AllGather(send, recv, (size_t)count_per_rank, kNcclFloat64, c->comm, c->stream);
+  return rc ? nccl_fail("ncclAllGather", rc) : 0;
+}
+
+int ibs_comm_destroy(ibs_ctx* c) {
+  if (!c) return fail(IBS_ERR_ARG, "null context");
+  if (c->comm) {
+    ON_DEVICE(c);
+    (void)hipStreamSynchronize(c->stream);
+    const int rc = rccl().CommDestroy(c->comm);
+    c->comm = nullptr;
+    if (rc) return nccl_fail("ncclCommDestroy", rc);
+  }
   return 0;
 }
 

@@ -37,8 +37,10 @@ def pick_start(gam_table, alpha_scan, theta0_scan):
     return float(alpha_scan[i]), float(theta0_scan[j]), 1.3 * abs(float(gam_table[i, j])) + 0.05, (i, j)
 
 
-def gather_rows_tensor(local, n_surf, rank, world, dist):
+def gather_rows_tensor(local, n_surf, rank, world, dist, ctx=None):
     """ONE all-gather of per-surface rows held as a torch tensor (device tensor: RCCL, in-stream; CPU tensor: gloo).
+    ctx: a Context that holds a native communicator (Context.comm_init): the collective is then issued by the library
+    itself (ibs_comm_allgather_f64) instead of torch.distributed.
     local: (n_local, k) rows of the surfaces shard_surfaces(n_surf, rank, world) lists.  Returns (n_surf, k) in surface
     order on every rank (replaces the three comm_lead.Gather of ball_scan.py:345-347)."""
     import torch
@@ -49,13 +51,16 @@ def gather_rows_tensor(local, n_surf, rank, world, dist):
     pad = torch.full((n_max, k), float("nan"), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((world * n_max, k), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad)
+    if ctx is not None and getattr(ctx, "_comm_world", 0) == world and local.is_cuda:
+        ctx.allgather(pad, out)
+    else:
+        dist.all_gather_into_tensor(out, pad)
     # row of surface j: rank j % world, slot j // world
     j = torch.arange(n_surf, device=local.device)
     return out[(j % world) * n_max + j // world]
 
 
-def gather_surfaces(local, n_surf, rank, world, dist=None, device=None):
+def gather_surfaces(local, n_surf, rank, world, dist=None, device=None, ctx=None):
     """all-gather of per-surface rows.  local: (n_local, k) rows of the surfaces shard_surfaces() lists.
     Returns (n_surf, k) on every rank (replaces ball_scan.py:345-347)."""
     local = np.asarray(local, dtype=np.float64)
@@ -65,7 +70,7 @@ def gather_surfaces(local, n_surf, rank, world, dist=None, device=None):
     t = torch.from_numpy(np.ascontiguousarray(local))
     if device is not None:
         t = t.to(device)
-    return gather_rows_tensor(t, n_surf, rank, world, dist).cpu().numpy()
+    return gather_rows_tensor(t, n_surf, rank, world, dist, ctx).cpu().numpy()
 
 
 class BallooningScan:
@@ -226,7 +231,7 @@ class BallooningScan:
             xo, fo, _ = self.refine_device(starts)
             gam = self.final_solve_device(xo)                      # ball_scan.py:322-339: one more solve at the optimum
             local = np.stack([xo[:, 1], xo[:, 0], gam], axis=1)
-            full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device)
+            full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device, self.ctx)
             return full[:, 0], full[:, 1], full[:, 2]
         for k, tab in zip(self.own, tabs):
             a0, t0, sigma0, ij = pick_start(tab, self.alpha_scan, self.theta0_scan)

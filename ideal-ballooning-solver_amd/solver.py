@@ -5,6 +5,7 @@ zero-copy, asynchronous on the torch current stream).  Mirrors the reference ope
 argument meaning; see operators.py for the exact drop-in signatures.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -85,6 +86,32 @@ class Context:
 
     def synchronize(self):
         check(self._lib.ibs_synchronize(self._h), "ibs_synchronize")
+
+    # ---- native RCCL all-gather (include/ibs.h: ibs_comm_*) -------------------------------------------------
+    def comm_init(self, dist, rank, world):
+        """create this rank's RCCL communicator inside the library; the unique id travels through `dist`
+        (any initialised torch.distributed backend).  Collective over all ranks."""
+        import torch
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        check(self._lib.ibs_comm_load(rccl.encode() if os.path.exists(rccl) else None), "ibs_comm_load")
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            check(self._lib.ibs_comm_unique_id(ident), "ibs_comm_unique_id")
+        box = [ident.raw]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        ident = C.create_string_buffer(box[0], 128)
+        check(self._lib.ibs_comm_init(self._h, ident, int(rank), int(world)), "ibs_comm_init")
+        self._comm_world = int(world)
+
+    def allgather(self, send, recv):
+        """recv (world * n,) <- every rank's send (n,): float64 CUDA tensors, asynchronous on the current torch stream"""
+        self._stream_from_torch(send)
+        check(self._lib.ibs_comm_allgather_f64(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                               send.numel()), "ibs_comm_allgather_f64")
+
+    def comm_destroy(self):
+        check(self._lib.ibs_comm_destroy(self._h), "ibs_comm_destroy")
 
     def set_option(self, name, value):
         """diagnostic override of a dispatch heuristic of this context (include/ibs.h: ibs_set_option);

@@ -66,6 +66,22 @@ int ibs_lbfgsb2_init(void* state, const double* x0, const double* lo, const doub
 int ibs_lbfgsb2_step(void* state, double f, const double* g, double* x_next);
 int ibs_lbfgsb2_result(const void* state, double* x, double* f, int32_t* counters);
 
+/* Native collective (optional): ONE all-gather of per-surface rows over RCCL on the context's stream, with no host
+ * framework in between.  Replaces: the three comm_lead.Gather([x, MPI.DOUBLE], ..., root=0) of ball_scan.py:345-347
+ * (theta0*, alpha*, gam per surface) as one all-gather of [n_surf_local][k] doubles per rank.
+ *   ibs_comm_load(path)      bind librccl at run time (NULL: the copy the process already holds, else librccl.so.1);
+ *   ibs_comm_unique_id(id)   rank 0: 128 bytes to hand to every rank by any means (MPI, a torch.distributed broadcast, a file);
+ *   ibs_comm_init(ctx, id, rank, nranks)   collective over the ranks (ncclCommInitRank on the context's device);
+ *   ibs_comm_allgather_f64(ctx, send, recv, count)   recv[nranks][count] <- every rank's send[count], device pointers,
+ *                            asynchronous on the context's stream (ordered after the kernels that produced `send`);
+ *   ibs_comm_destroy(ctx).
+ * The Python layer (BallooningScan, bench.py) uses torch.distributed by default; Context.comm_init(dist) switches it. */
+int ibs_comm_load(const char* librccl_path);
+int ibs_comm_unique_id(void* id128);
+int ibs_comm_init(ibs_ctx* ctx, const void* id128, int32_t rank, int32_t nranks);
+int ibs_comm_allgather_f64(ibs_ctx* ctx, const double* send, double* recv, int64_t count_per_rank);
+int ibs_comm_destroy(ibs_ctx* ctx);
+
 /* Diagnostic override of a dispatch heuristic of THIS context (tests, experiments; nothing upstream corresponds).
  * name: "force_p" (lanes per system 64|32|16), "scan_chain" (theta0 values chained through one wave),
  * "chain_w1" / "chain_w2" (relative widths of the chain's warm starts), "geo_lpp" (lanes per grid point of the

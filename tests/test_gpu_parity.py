@@ -909,3 +909,28 @@ def test_row_streamed_raw_kernel_matches_three_row_staging(ctx, bo, N):
     r = ctx.solve_gcf(h, bad, c, f, want_info=True)
     flagged = np.nonzero((r["info"] >> 16) != 0)[0]
     assert list(flagged) == [5, 9] and np.abs(np.delete(r["gam"], [5, 9]) - np.delete(new["gam"], [5, 9])).max() < 1e-12
+
+
+def test_native_rccl_allgather_single_rank():
+    """ibs_comm_* (ncclAllGather issued by the library on the context's stream): a one-rank communicator on this GPU --
+    the gathered buffer equals what was sent, the call is ordered after the kernel that produced it, a second init and
+    a gather without communicator are refused.  (More ranks need more GPUs: the N > 1 logic runs under gloo in the CPU suite.)"""
+    import ibs_amd
+    import torch
+    c = ibs_amd.Context(0)
+    dev = torch.device("cuda:0")
+    send = torch.zeros(48, dtype=torch.float64, device=dev)
+    recv = torch.full((48,), -1.0, dtype=torch.float64, device=dev)
+    with pytest.raises(ibs_amd.IbsError):
+        c.allgather(send, recv)
+    c.comm_init(None, 0, 1)
+    for k in range(5):
+        send.copy_(torch.arange(48, dtype=torch.float64, device=dev) + k)       # stream-ordered producer
+        c.allgather(send, recv)
+        assert torch.equal(recv.cpu(), torch.arange(48, dtype=torch.float64) + k)
+    with pytest.raises(ibs_amd.IbsError):
+        c.comm_init(None, 0, 1)
+    full = ibs_amd.gather_rows_tensor(send.reshape(16, 3), 16, 0, 1, None, c)
+    assert torch.equal(full, send.reshape(16, 3))
+    c.comm_destroy()
+    c.close()
