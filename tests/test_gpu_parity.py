@@ -934,3 +934,32 @@ def test_native_rccl_allgather_single_rank():
     assert torch.equal(full, send.reshape(16, 3))
     c.comm_destroy()
     c.close()
+
+
+def test_new_entry_points_reject_bad_arguments(ctx, bo):
+    """error behaviour of the round-2 entry points: negative return codes / IbsError, nothing launched"""
+    import ctypes as C
+    import ibs_amd
+    import torch
+    dev = torch.device("cuda:0")
+    g3 = np.load(os.path.join(G, "G3_ncsx_lines.npz"))
+    geo = g3["geo_513"][:6]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dP = -0.5 * np.mean((geo[:, 2] - geo[:, 7]) * geo[:, 0] ** 2, axis=1)
+    th = bo.theta_grid(513)
+    with pytest.raises(ibs_amd.IbsError):                     # 6 lines do not split into 4 surfaces
+        ibs_amd.ScanPlan(ctx, th[1] - th[0], [t(geo[:, k]) for k in range(7)], t(dP), t(np.linspace(0, 1, 4)), 4)
+    plan = ibs_amd.ScanPlan(ctx, th[1] - th[0], [t(geo[:, k]) for k in range(7)], t(dP), t(np.linspace(0, 1, 4)), 3)
+    lib = ctx._lib
+    args = list(plan._fused_args[0])
+    args[15] = 4                                              # n_surf = 4: n_lines % n_surf != 0
+    assert lib.ibs_gamma_scan_argmax_f64(*args) == -1 and b"n_surf" in lib.ibs_last_error()
+    args = list(plan._fused_args[0]); args[18] = C.c_void_p(None)   # pack = NULL
+    assert lib.ibs_gamma_scan_argmax_f64(*args) == -1
+    with pytest.raises(ibs_amd.IbsError):
+        ctx.set_option("no_such_option", 1)
+    assert lib.ibs_comm_allgather_f64(ctx._h, C.c_void_p(8), C.c_void_p(8), 1) < 0      # no communicator
+    assert lib.ibs_lbfgsb2_init(None, None, None, None, 1e-9, 1e-9, 10, 20) < 0
+    plan.scan_argmax()                                        # and the plan still works
+    torch.cuda.synchronize()
+    assert np.array_equal(plan.pack[:, 1].long().cpu().numpy(), plan.gam.reshape(3, -1).argmax(dim=1).cpu().numpy())

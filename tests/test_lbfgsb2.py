@@ -116,3 +116,14 @@ def test_boundaries_and_limits():
     ref = minimize(lambda x: rosen()(x), x0=(0.2, 0.3), jac=True, bounds=BOX, method="L-BFGS-B",
                    options={"ftol": 5e-11, "gtol": 2e-8, "maxiter": 3})
     assert out.nit == 3 == ref.nit and out.task == 13 and np.abs(out.x - ref.x).max() < 1e-12
+
+
+@pytest.mark.parametrize("maxiter", [0, 1, 2])
+def test_iteration_limit_like_scipy(maxiter):
+    """scipy's driver counts an iteration and tests the limit AFTER each completed iteration, so maxiter = 0 still performs
+    one (the same in ibs_refine_f64)"""
+    f = quad([[2.0, 0.0], [0.0, 2.0]], [2.0, 1.0])
+    out = ibs_amd.minimize2(f, (0.2, 0.2), BOX, ftol=5e-11, gtol=2e-8, maxiter=maxiter)
+    ref = minimize(f, x0=(0.2, 0.2), jac=True, bounds=BOX, method="L-BFGS-B", options={"ftol": 5e-11, "gtol": 2e-8, "maxiter": maxiter})
+    assert out.nit == ref.nit and out.nfev == ref.nfev and np.abs(out.x - ref.x).max() < 1e-14
+    assert out.message.split(":")[0] == ref.message.split(":")[0]

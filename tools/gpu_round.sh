@@ -1,5 +1,4 @@
 set -o pipefail
 T=${1:-r02a}
 mkdir -p gpurun_out/$T
-timeout -k 10 900 python tests/tools/parity_campaign.py > gpurun_out/$T/campaign.txt 2>&1; echo "rc=$?"; grep -v amdgpu gpurun_out/$T/campaign.txt | tail -25
-timeout -k 10 300 python tests/tools/geo_parity.py > gpurun_out/$T/geo.txt 2>&1; echo "rc=$?"; grep -v amdgpu gpurun_out/$T/geo.txt | tail -8
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "reject_bad or native_rccl or scan_plan" > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 gpurun_out/$T/pytest.log
