@@ -385,6 +385,8 @@ class C2Sharded:
         self.alphas_d = torch.from_numpy(self.alphas).to(device)
         self.t0_d = torch.from_numpy(np.linspace(0, np.pi / 2, self.NT0)).to(device)
         self.th_d = torch.from_numpy(self.th).to(device)
+        # (alpha, theta0) of every entry of a surface's row-major table: one gather turns the argmax index into the row
+        self.lut = torch.stack([self.alphas_d.repeat_interleave(self.NT0), self.t0_d.repeat(self.NA)], dim=1)
         self._lines = {}                                    # own surfaces -> (line_surf, line_alpha) resident in HBM
 
     def local_rows(self, own):
@@ -399,8 +401,7 @@ class C2Sharded:
         r = self.ctx.fieldline_geometry(self.tabs, surf, al, self.th_d, device=self.device)
         sc = self.ctx.gamma_scan(self.h, *[r["geo"][k] for k in range(7)], r["dPdrho"], self.t0_d)
         idx, val = self.ctx.surface_argmax(sc["gam"].reshape(len(own), -1))
-        idx = idx.long()
-        return torch.stack([val, self.alphas_d[idx // self.NT0], self.t0_d[idx % self.NT0]], dim=1)
+        return torch.cat([val[:, None], self.lut[idx.long()]], dim=1)
 
 
 def c2_sharded_leg(ctx, device, rank, world, dist, fence, passes=20, native=False):
