@@ -522,19 +522,35 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank or none
         native = bool(flag.item() == 1.0)
 
+    # Overlap: step k's gather runs on the communicator's own stream while step k+1 scans; pack / receive buffers alternate
+    # between two slots, and the scan of step k+2 is ordered (device side) after step k's gather, which last used its
+    # slot.  Every gather still completes inside the timed region (fence() = comm_wait + barrier + device synchronize).
+    # Measured with a one-rank group (tools/overlap_probe.py): 38.3 us per step against 29.6 us in-stream and 28.2 us
+    # without a gather -- the two event dependencies cost ~10 us of stream time per step on this platform whatever the
+    # gather takes, so the overlap pays once the gather's latency exceeds that: default from 4 ranks up
+    # (IBS_BENCH_OVERLAP=0 / 1 forces it off / on).
+    ov_env = os.environ.get("IBS_BENCH_OVERLAP", "")
+    overlap = native and (ov_env == "1" or (ov_env != "0" and n_ranks >= 4))
+    gathered2 = [gathered, torch.empty_like(gathered)] if overlap else None
+
     def step(k=0, ev=None):
         # scan + per-surface first maximum: ONE kernel (the block that completes a surface reduces it)
+        slot = (k & 1) if overlap else 0
         if ev is not None:
             ev[0].record()
-        plan.scan_argmax()
+        plan.scan_argmax(slot)
         if ev is not None:
             ev[1].record()
-        if native:
+        if overlap:
+            ctx.allgather_start(plan.packs[slot], gathered2[slot], slot, then_wait=1 - slot, same_stream=True)
+        elif native:
             ctx.allgather(plan.pack, gathered)
         elif use_dist:
             dist.all_gather_into_tensor(gathered, plan.pack if backend == "nccl" else plan.pack.cpu())
 
     def fence():
+        if overlap:
+            ctx.comm_wait(-1)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -586,8 +602,9 @@ def main():
     empty_ms = float(np.median([c.elapsed_time(d) for c, d in emp]))
     gather_ok = None
     if use_dist:      # every rank holds every rank's maxima of the last step; its own row must be what it sent
-        okt = torch.tensor([1.0 if torch.equal(gathered[rank * N_SURF:(rank + 1) * N_SURF].to(device), plan.pack) else 0.0],
-                           dtype=torch.float64, device=coll_dev)
+        last = (args.steps - 1) & 1 if overlap else 0            # slot of the last timed step
+        got = (gathered2[last] if overlap else gathered)[rank * N_SURF:(rank + 1) * N_SURF].to(device)
+        okt = torch.tensor([1.0 if torch.equal(got, plan.packs[last]) else 0.0], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)       # (reported, not raised: no rank may leave the others in a collective)
         gather_ok = bool(okt.item() == 1.0)
     info = plan.info.cpu().numpy()
@@ -618,7 +635,7 @@ def main():
             "config": {"workload": "configs[1] D3D-shape: 16 surfaces x 8 alpha x 8 theta0 = 1024 solves/step/GPU, "
                                    "N_zeta=512 (513 points), geometry-fed scan with fused per-surface argmax (one launch)"
                                    + (" + all-gather (%s, %d ranks) of the per-surface maxima" % (
-                                       ("RCCL, issued natively by the library" if native else "RCCL") if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
+                                       ("RCCL, issued natively by the library" + (", overlapped with the next scan" if overlap else "") if native else "RCCL") if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
                        "nonconverged": nbad, "ranks_in_collective": n_ranks, "allgather_roundtrip_ok": gather_ok,
                        "untimed_spinup_steps": args.warmup + n_spin},

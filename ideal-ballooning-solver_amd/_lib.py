@@ -29,6 +29,8 @@ SYMBOLS = {
     "ibs_comm_unique_id": (C.c_int, [_P]),
     "ibs_comm_init": (C.c_int, [_P, _P, _I32, _I32]),
     "ibs_comm_allgather_f64": (C.c_int, [_P, _P, _P, _I64]),
+    "ibs_comm_allgather_start_f64": (C.c_int, [_P, _P, _P, _I64, _I32, _I32]),
+    "ibs_comm_wait": (C.c_int, [_P, _I32]),
     "ibs_comm_destroy": (C.c_int, [_P]),
     "ibs_lbfgsb2_state_bytes": (C.c_int, []),
     "ibs_lbfgsb2_init": (C.c_int, [_P, _P, _P, _P, _D, _D, _I32, _I32]),

@@ -63,6 +63,13 @@ struct ibs_ctx {
   // native RCCL communicator of this rank (ibs_comm_init), null = none
   void* comm = nullptr;
   int comm_rank = 0, comm_n = 1;
+  // overlapped gathers (ibs_comm_allgather_start_f64): the communicator's own stream, "inputs written" marker of the
+  // compute stream, one completion event per slot
+  static constexpr int kCommSlots = 4;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ready = nullptr;
+  hipEvent_t comm_done[kCommSlots] = {nullptr, nullptr, nullptr, nullptr};
+  bool comm_pending[kCommSlots] = {false, false, false, false};
   // per-surface arrival counters of the fused scan + argmax kernel (zero between launches)
   int* surf_counter = nullptr;
   int surf_counter_n = 0;
@@ -396,6 +403,7 @@ int ibs_create(ibs_ctx** out, int device_id) {
 
 int ibs_destroy(ibs_ctx* c) {
   if (!c) return 0;
+  (void)ibs_comm_destroy(c);
   DeviceGuard g(c->device);
   if (c->ws) hipFree(c->ws);
   if (c->surf_counter) hipFree(c->surf_counter);
@@ -511,8 +519,56 @@ int ibs_comm_allgather_f64(ibs_ctx* c, const double* send, double* recv, int64_t
   return rc ? nccl_fail("ncclAllGather", rc) : 0;
 }
 
+// Overlapped form: the gather is ordered after everything enqueued so far on the context's stream but runs on the
+// communicator's own stream, so the next scan does not wait for the ranks to meet.
+int ibs_comm_allgather_start_f64(ibs_ctx* c, const double* send, double* recv, int64_t count_per_rank, int32_t slot,
+                                 int32_t then_wait_slot) {
+  if (!c || !send || !recv || count_per_rank < 0 || slot < 0 || slot >= ibs_ctx::kCommSlots ||
+      then_wait_slot >= ibs_ctx::kCommSlots || then_wait_slot == slot)
+    return fail(IBS_ERR_ARG, "bad arguments");
+  if (!c->comm) return fail(IBS_ERR_ARG, "no communicator: call ibs_comm_init first");
+  ON_DEVICE(c);
+  if (!c->comm_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->comm_ready, hipEventDisableTiming));
+    for (auto& e : c->comm_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(c->comm_ready, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->comm_stream, c->comm_ready, 0));
+  const int rc = rccl().AllGather(send, recv, (size_t)count_per_rank, kNcclFloat64, c->comm, c->comm_stream);
+  if (rc) return nccl_fail("ncclAllGather", rc);
+  HIPCHK(hipEventRecord(c->comm_done[slot], c->comm_stream));
+  c->comm_pending[slot] = true;
+  if (then_wait_slot >= 0 && c->comm_pending[then_wait_slot]) {      // (saves the caller a second call per step)
+    HIPCHK(hipStreamWaitEvent(c->stream, c->comm_done[then_wait_slot], 0));
+    c->comm_pending[then_wait_slot] = false;
+  }
+  return 0;
+}
+
+int ibs_comm_wait(ibs_ctx* c, int32_t slot) {
+  if (!c || slot >= ibs_ctx::kCommSlots) return fail(IBS_ERR_ARG, "bad arguments");
+  ON_DEVICE(c);
+  for (int s = 0; s < ibs_ctx::kCommSlots; ++s) {
+    if ((slot >= 0 && s != slot) || !c->comm_pending[s]) continue;
+    HIPCHK(hipStreamWaitEvent(c->stream, c->comm_done[s], 0));      // (device-side ordering; the host does not block)
+    c->comm_pending[s] = false;
+  }
+  return 0;
+}
+
 int ibs_comm_destroy(ibs_ctx* c) {
   if (!c) return fail(IBS_ERR_ARG, "null context");
+  if (c->comm_stream) {
+    ON_DEVICE(c);
+    (void)hipStreamSynchronize(c->comm_stream);
+    for (auto& e : c->comm_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (c->comm_ready) (void)hipEventDestroy(c->comm_ready);
+    c->comm_ready = nullptr;
+    (void)hipStreamDestroy(c->comm_stream);
+    c->comm_stream = nullptr;
+    for (auto& b : c->comm_pending) b = false;
+  }
   if (c->comm) {
     ON_DEVICE(c);
     (void)hipStreamSynchronize(c->stream);

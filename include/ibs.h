@@ -74,12 +74,22 @@ int ibs_lbfgsb2_result(const void* state, double* x, double* f, int32_t* counter
  *   ibs_comm_init(ctx, id, rank, nranks)   collective over the ranks (ncclCommInitRank on the context's device);
  *   ibs_comm_allgather_f64(ctx, send, recv, count)   recv[nranks][count] <- every rank's send[count], device pointers,
  *                            asynchronous on the context's stream (ordered after the kernels that produced `send`);
- *   ibs_comm_destroy(ctx).
+ *   ibs_comm_allgather_start_f64(ctx, send, recv, count, slot, then_wait_slot)   the same gather, ordered after everything enqueued so
+ *                            far on the context's stream but run on the communicator's OWN stream: the next scan does not
+ *                            wait for the ranks to meet (the reference has nothing to overlap: its Gather is blocking).
+ *                            slot in [0, 4) names the gather; then_wait_slot >= 0 (another slot) additionally does
+ *                            ibs_comm_wait(ctx, then_wait_slot) in the same call, -1 = nothing;
+ *   ibs_comm_wait(ctx, slot) orders the context's stream after the gather of `slot` (slot < 0: after every pending one)
+ *                            without blocking the host: call it before `send` / `recv` of that slot are reused or read;
+ *   ibs_comm_destroy(ctx)    (also done by ibs_destroy).
  * The Python layer (BallooningScan, bench.py) uses torch.distributed by default; Context.comm_init(dist) switches it. */
 int ibs_comm_load(const char* librccl_path);
 int ibs_comm_unique_id(void* id128);
 int ibs_comm_init(ibs_ctx* ctx, const void* id128, int32_t rank, int32_t nranks);
 int ibs_comm_allgather_f64(ibs_ctx* ctx, const double* send, double* recv, int64_t count_per_rank);
+int ibs_comm_allgather_start_f64(ibs_ctx* ctx, const double* send, double* recv, int64_t count_per_rank, int32_t slot,
+                                 int32_t then_wait_slot);
+int ibs_comm_wait(ibs_ctx* ctx, int32_t slot);
 int ibs_comm_destroy(ibs_ctx* ctx);
 
 /* Diagnostic override of a dispatch heuristic of THIS context (tests, experiments; nothing upstream corresponds).

@@ -932,6 +932,35 @@ def test_native_rccl_allgather_single_rank():
         c.comm_init(None, 0, 1)
     full = ibs_amd.gather_rows_tensor(send.reshape(16, 3), 16, 0, 1, None, c)
     assert torch.equal(full, send.reshape(16, 3))
+    # overlapped form: gathers on the communicator's own stream, two slots in flight while the compute stream goes on;
+    # comm_wait(slot) orders the compute stream after a gather before its buffers are reused / read
+    sends = [torch.zeros(48, dtype=torch.float64, device=dev) for _ in range(2)]
+    recvs = [torch.full((48,), -1.0, dtype=torch.float64, device=dev) for _ in range(2)]
+    big = torch.zeros(1 << 22, dtype=torch.float64, device=dev)
+    for k in range(12):
+        slot = k & 1
+        c.comm_wait(slot)
+        if k >= 2:
+            assert float(recvs[slot][5].item()) == 5.0 + (k - 2)                # the gather of step k-2 has landed
+        big.add_(1.0)                                                            # (keeps the compute stream busy)
+        sends[slot].copy_(torch.arange(48, dtype=torch.float64, device=dev) + k)
+        c.allgather_start(sends[slot], recvs[slot], slot)
+    c.comm_wait()
+    assert torch.equal(recvs[0].cpu(), torch.arange(48, dtype=torch.float64) + 10)
+    assert torch.equal(recvs[1].cpu(), torch.arange(48, dtype=torch.float64) + 11)
+    with pytest.raises(ibs_amd.IbsError):
+        c.allgather_start(sends[0], recvs[0], 7)                                 # slot out of range
+    with pytest.raises(ibs_amd.IbsError):
+        c.allgather_start(sends[0], recvs[0], 1, then_wait=1)                    # a gather cannot wait for itself
+    for k in range(6):                                                           # the one-call form bench.py uses
+        slot = k & 1
+        sends[slot].copy_(torch.arange(48, dtype=torch.float64, device=dev) + 100 + k)
+        c.allgather_start(sends[slot], recvs[slot], slot, then_wait=1 - slot)
+        if k >= 1:
+            assert float(recvs[1 - slot][0].item()) == 100.0 + (k - 1)
+    c.comm_wait()
+    assert float(recvs[1][0].item()) == 105.0
+    c.comm_wait(3)                                                               # nothing pending there: no-op
     c.comm_destroy()
     c.close()
 
