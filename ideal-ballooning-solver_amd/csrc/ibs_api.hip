@@ -656,6 +656,21 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   wpb = (waves_per_line + nblk - 1) / nblk;
   ibs::ScanArgs<double> a{};
   a.n_lines = n_lines; a.n_theta0 = n_theta0; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
+  // A chain shortens the blocks (a line's waves = theta0 slots / chain) while every block still stages the whole line:
+  // the LDS then limits the waves per CU.  Shorten the chain until the blocks that fit a CU hold as many waves as the
+  // registers allow (tools/batch_sweep.py, 8 theta0 per line, N = 513, 65,536 solves: chain 4 = one wave per block =
+  // 4 waves per CU: 6.5e7 solves/s; chain 2: 1.0e8).
+  auto fit_chain = [&](int chain, int slots, int rows, int cap_waves) {
+    const int occ = rows <= 4 ? 4 : (rows <= 8 ? 3 : (rows <= 16 ? 2 : 1));        // waves per SIMD the VGPRs allow
+    const long blocks_per_cu = (long)((size_t)ctx->lds_per_block / (7 * per_arr));
+    while (chain > 1) {
+      long w = (slots + chain - 1) / chain;
+      if (w > cap_waves) w = cap_waves;
+      if (blocks_per_cu * w >= 4L * occ) break;
+      chain >>= 1;
+    }
+    return chain;
+  };
   // Batches much larger than the chip (one wave per system, no caller-supplied guesses): chain consecutive theta0
   // values of a line through one wave, each solve warm-started from the previous eigenvalue (k_gamma_scan_chain).
   // 4 per wave once that still leaves two waves per SIMD, 2 from there down to two waves of chained work per SIMD
@@ -669,6 +684,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
     if (!lam_guess) {
       if (slots >= 4 && waves >= 8 * simds) chain = 4;
       else if (slots >= 2 && waves >= 4 * simds) chain = 2;
+      chain = fit_chain(chain, slots, M, cap);
       if (ctx->opt.scan_chain >= 1 && ctx->opt.scan_chain <= slots) chain = ctx->opt.scan_chain;
     }
     if (chain > 1 || lam_guess) {
@@ -693,6 +709,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
     int chain = 1;
     if (n_theta0 >= 8 && waves >= 8 * simds) chain = 4;
     else if (n_theta0 >= 4 && waves >= 4 * simds) chain = 2;      // (N = 1025: 2,048 solves 70 vs 95 us, 4,096: 111 vs 105 us)
+    chain = fit_chain(chain, n_theta0, M, cap);
     if (ctx->opt.scan_chain >= 1 && ctx->opt.scan_chain <= n_theta0) chain = ctx->opt.scan_chain;
     auto fc = ibs::launch_table().scan_chain_f64[M];
     if (chain > 1 && fc) {
