@@ -619,27 +619,30 @@ def test_F1_fieldline_geometry_kernel(ctx, bo):
 
 
 def test_F1_geometry_lanes_per_point_variants_agree(ctx, bo, monkeypatch):
-    """small batches split a grid point over 2 / 4 lanes (latency of the refinement rounds): same arrays as the
-    one-lane-per-point kernel up to the summation order"""
+    """small batches split a grid point over 2 / 4 lanes (latency of the refinement rounds), large ones put two grid
+    points on a lane and hand the points beyond a multiple of 512 (N = 1025: one per line) to the one-point-per-wave
+    kernel: same arrays as the one-lane-per-point kernel up to the summation order"""
     import ibs_amd
     import torch
     wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
     tabs = ibs_amd.SurfaceTables.from_wout(wout, [0.5, 0.8])
-    th = bo.theta_grid(969)
     surf = [0, 0, 1, 1, 1]; al = [0.0, 1.3, 0.4, 2.0, np.pi]
-    out = {}
-    for lpp in ("1", "2", "4"):
-        ctx.set_option("geo_lpp", lpp)
-        r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))
-        out[lpp] = (r["geo"].cpu().numpy(), r["dPdrho"].cpu().numpy())
-    ctx.set_option("geo_lpp", None)
-    r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))     # automatic choice (4 here)
-    auto = r["geo"].cpu().numpy()
-    scale = np.abs(out["1"][0]).max(axis=2, keepdims=True)
-    for lpp in ("2", "4"):
-        assert (np.abs(out[lpp][0] - out["1"][0]) / scale).max() < 1e-12
-        assert np.abs(out[lpp][1] - out["1"][1]).max() < 1e-12 * np.abs(out["1"][1]).max()
-    assert (np.abs(auto - out["1"][0]) / scale).max() < 1e-12
+    for N in (969, 1025, 513):
+        th = bo.theta_grid(N)
+        out = {}
+        for lpp in ("1", "2", "4", "-2"):                       # -2: two grid points per lane (+ the tail kernel)
+            ctx.set_option("geo_lpp", lpp)
+            r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))
+            out[lpp] = (r["geo"].cpu().numpy(), r["dPdrho"].cpu().numpy())
+        ctx.set_option("geo_lpp", None)
+        r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))     # automatic choice (4 here)
+        auto = r["geo"].cpu().numpy()
+        scale = np.abs(out["1"][0]).max(axis=2, keepdims=True)
+        for lpp in ("2", "4", "-2"):
+            assert np.isfinite(out[lpp][0]).all()
+            assert (np.abs(out[lpp][0] - out["1"][0]) / scale).max() < 1e-11, (N, lpp)
+            assert np.abs(out[lpp][1] - out["1"][1]).max() < 1e-11 * np.abs(out["1"][1]).max()
+        assert (np.abs(auto - out["1"][0]) / scale).max() < 1e-11
 
 
 def test_driver_with_device_geometry_reproduces_reference_scan(ctx, bo):
