@@ -7,7 +7,7 @@ import numpy as np, torch, ibs_amd
 dev = torch.device("cuda", 0)
 ctx = ibs_amd.Context(0)
 n_sys = int(os.environ.get("IBS_C5_N", "1000000"))
-for nz in (256, 512, 1024, 2048):
+for nz in [int(v) for v in os.environ.get("IBS_C5_NZ", "256,512,1024,2048").split(",")]:
     N = nz + 1
     h = 8 * np.pi / nz
     th = torch.linspace(-4 * np.pi, 4 * np.pi, N, dtype=torch.float64, device=dev)
