@@ -51,3 +51,14 @@ for rep in range(2):
 f = ibs_amd.ballooning_objective(np.full(n_eq, 0.8), val.cpu().numpy().reshape(n_eq, ns), -2e-4, 50.0)
 print('config 4 shape (%d equilibria, %d lines, %d solves): host splines %.2f s | geometry %.1f ms | scan+argmax %.1f ms | f0[:3] %s' % (
     n_eq, len(surf), n_eq * ns * na * nt0, t_spl, t_geo * 1e3, t_scan * 1e3, f[:3]))
+
+# refinement of all 365 per-surface maxima of that step in one batch (ibs_refine_f64: L-BFGS-B state machines on the device)
+scan = ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), nalpha=na, ntheta0=nt0, tables=big, device=dev)
+tab = sc['gam'].reshape(n_eq * ns, na, nt0).cpu().numpy()
+starts = np.array([ibs_amd.pick_start(t_, scan.alpha_scan, scan.theta0_scan)[:2] for t_ in tab])
+scan.refine_device(starts)
+torch.cuda.synchronize(); t = time.time()
+xo, fo, ne = scan.refine_device(starts)
+t_ref = time.time() - t
+print('config 4 shape: refinement of %d maxima in one batch %.1f ms (%d..%d evaluations per point, mean %.1f)' % (
+    len(starts), t_ref * 1e3, int(np.min(ne)), int(np.max(ne)), float(np.mean(ne))))
