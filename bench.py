@@ -276,6 +276,50 @@ def scan_large(ctx, device, geo7, dP_d, reps=3):
                               traffic=None, kernel="k_gamma_scan_g_chain<double,16,32>", bytes_per_solve=bytes_per))
 
 
+def batch_scaling(ctx, device, h, geo7, dP_d, th0_d):
+    """where the latency-bound regime of the headline step ends: the step's batch replicated 1-8x in ONE launch, and two
+    step-sized launches in flight on two streams (two contexts: stream and arrival counters are per context)."""
+    import torch
+    import ibs_amd
+
+    def timed(fn, n):
+        for _ in range(max(20, n // 10)):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    rows = []
+    for rep in (1, 2, 4, 8):
+        plan = ibs_amd.ScanPlan(ctx, h, [x.repeat(rep, 1) for x in geo7], dP_d.repeat(rep), th0_d, N_SURF * rep)
+        dt = timed(plan.scan_argmax, 600 // rep + 50)
+        n = plan.n_lines * plan.n_t0
+        rows.append(dict(solves_per_launch=n, us_per_launch=dt * 1e6, solves_per_s=n / dt))
+    ctx2 = ibs_amd.Context(ctx.device)
+    plans = [ibs_amd.ScanPlan(c, h, geo7, dP_d, th0_d, N_SURF) for c in (ctx, ctx2)]
+    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+    k = [0]
+
+    def two():
+        i = k[0] & 1
+        k[0] += 1
+        with torch.cuda.stream(streams[i]):
+            plans[i].scan_argmax()
+
+    dt = timed(two, 2000)
+    torch.cuda.synchronize()
+    ctx2.close()
+    n1 = N_SURF * N_ALPHA * N_THETA0
+    return dict(workload="scan + per-surface argmax of the step's batch replicated in one launch; two step-sized launches in "
+                         "flight on two streams", one_launch=rows,
+                two_streams=dict(solves_per_launch=n1, us_per_launch=dt * 1e6, solves_per_s=n1 / dt),
+                note="the headline step keeps one 1,024-solve launch at a time (BASELINE configs[1]); a caller with several "
+                     "independent equilibria should batch them into one launch")
+
+
 def ncsx_pipeline(ctx, device):
     """configs[2] shape on one GPU (64 surfaces x 32 alpha x 16 theta0, N_zeta=1024) from the shipped NCSX equilibrium's
     wout tables: field-line geometry kernel (row F1) -> geometry-fed scan -> per-surface argmax, and the reference's
@@ -681,6 +725,7 @@ def main():
             out["sturm_sweep"] = sturm_sweep(ctx, device, args.stress_systems)
             out["warm_rescan"] = warm_rescan(ctx, device, h, geo7, dP_d, th0_d)
             out["scan_large"] = scan_large(ctx, device, geo7, dP_d)
+            out["batch_scaling"] = batch_scaling(ctx, device, h, geo7, dP_d, th0_d)
             out.update(ncsx_pipeline(ctx, device))
         print(json.dumps(out), flush=True)
     if use_dist:
