@@ -543,7 +543,7 @@ def main():
     ctx = ibs_amd.Context(local)
 
     h, geo7, dP_d, th0_d, base, dP, theta0 = build_workload(rank, device)
-    plan = ibs_amd.ScanPlan(ctx, h, geo7, dP_d, th0_d, N_SURF)
+    plan = ibs_amd.ScanPlan(ctx, h, geo7, dP_d, th0_d, N_SURF, n_pack=3)
     n_solves = N_SURF * N_ALPHA * N_THETA0
     use_dist = dist.is_available() and dist.is_initialized()
     n_ranks = dist.get_world_size() if use_dist else 1
@@ -569,27 +569,32 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank or none
         native = bool(flag.item() == 1.0)
 
-    # Overlap: step k's gather runs on the communicator's own stream while step k+1 scans; pack / receive buffers alternate
-    # between two slots, and the scan of step k+2 is ordered (device side) after step k's gather, which last used its
-    # slot.  Every gather still completes inside the timed region (fence() = comm_wait + barrier + device synchronize).
-    # Measured with a one-rank group (tools/overlap_probe.py): 38.3 us per step against 29.6 us in-stream and 28.2 us
-    # without a gather -- the two event dependencies cost ~10 us of stream time per step on this platform whatever the
-    # gather takes, so the overlap pays once the gather's latency exceeds that: default from 4 ranks up
-    # (IBS_BENCH_OVERLAP=0 / 1 forces it off / on).
+    # Overlap: step k's gather runs on the communicator's own stream while the next steps scan.  Pack / receive buffers
+    # rotate through three slots; before step k+1 is launched the HOST makes sure the gather that last used its slot
+    # (step k-2) has finished (an event query; it blocks only if the ranks have fallen two steps behind), so the compute
+    # stream carries one event record per step and no wait.  Every gather still completes inside the timed region
+    # (fence() = comm_wait + barrier + device synchronize).
+    # Measured with a one-rank group (tools/overlap_probe.py): 33.6 us per step (39.0 with a device-side wait on the compute
+    # stream) against 29.6 us in-stream and 28.2 us without a gather: the event dependency costs ~5 us of stream time per
+    # step whatever the gather takes (bench.py itself, one-rank group: 35.1 against 30.8 us per step), so the overlap pays
+    # once the gather's own latency exceeds ~6 us -- which any gather that crosses GPUs does: default whenever there is
+    # more than one rank (IBS_BENCH_OVERLAP=0 / 1 forces it off / on).
     ov_env = os.environ.get("IBS_BENCH_OVERLAP", "")
-    overlap = native and (ov_env == "1" or (ov_env != "0" and n_ranks >= 4))
-    gathered2 = [gathered, torch.empty_like(gathered)] if overlap else None
+    overlap = native and (ov_env == "1" or (ov_env != "0" and n_ranks >= 2))
+    gathered3 = [gathered, torch.empty_like(gathered), torch.empty_like(gathered)] if overlap else None
+    n_issued = [0]                       # steps issued so far (the slot rotation must not depend on the caller's k)
 
     def step(k=0, ev=None):
         # scan + per-surface first maximum: ONE kernel (the block that completes a surface reduces it)
-        slot = (k & 1) if overlap else 0
+        slot = n_issued[0] % 3 if overlap else 0
         if ev is not None:
             ev[0].record()
         plan.scan_argmax(slot)
         if ev is not None:
             ev[1].record()
         if overlap:
-            ctx.allgather_start(plan.packs[slot], gathered2[slot], slot, then_wait=1 - slot, same_stream=True)
+            ctx.allgather_start(plan.packs[slot], gathered3[slot], slot, same_stream=True, host_wait=(n_issued[0] + 1) % 3)
+            n_issued[0] += 1
         elif native:
             ctx.allgather(plan.pack, gathered)
         elif use_dist:
@@ -649,8 +654,8 @@ def main():
     empty_ms = float(np.median([c.elapsed_time(d) for c, d in emp]))
     gather_ok = None
     if use_dist:      # every rank holds every rank's maxima of the last step; its own row must be what it sent
-        last = (args.steps - 1) & 1 if overlap else 0            # slot of the last timed step
-        got = (gathered2[last] if overlap else gathered)[rank * N_SURF:(rank + 1) * N_SURF].to(device)
+        last = (n_issued[0] - 1) % 3 if overlap else 0           # slot of the last timed step
+        got = (gathered3[last] if overlap else gathered)[rank * N_SURF:(rank + 1) * N_SURF].to(device)
         okt = torch.tensor([1.0 if torch.equal(got, plan.packs[last]) else 0.0], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)       # (reported, not raised: no rank may leave the others in a collective)
         gather_ok = bool(okt.item() == 1.0)

@@ -523,8 +523,12 @@ int ibs_comm_allgather_f64(ibs_ctx* c, const double* send, double* recv, int64_t
 // communicator's own stream, so the next scan does not wait for the ranks to meet.
 int ibs_comm_allgather_start_f64(ibs_ctx* c, const double* send, double* recv, int64_t count_per_rank, int32_t slot,
                                  int32_t then_wait_slot) {
+  // then_wait_slot: >= 0 device-side wait of the context's stream on that slot's gather; -1 nothing;
+  //                 <= -2 HOST-side wait on slot (-2 - then_wait_slot): no stream operation at all (an event query, and a
+  //                 blocking wait only if that gather has not finished) -- for callers that run several slots ahead
+  const int host_slot = then_wait_slot <= -2 ? -2 - then_wait_slot : -1;
   if (!c || !send || !recv || count_per_rank < 0 || slot < 0 || slot >= ibs_ctx::kCommSlots ||
-      then_wait_slot >= ibs_ctx::kCommSlots || then_wait_slot == slot)
+      then_wait_slot >= ibs_ctx::kCommSlots || then_wait_slot == slot || host_slot >= ibs_ctx::kCommSlots || host_slot == slot)
     return fail(IBS_ERR_ARG, "bad arguments");
   if (!c->comm) return fail(IBS_ERR_ARG, "no communicator: call ibs_comm_init first");
   ON_DEVICE(c);
@@ -542,6 +546,10 @@ int ibs_comm_allgather_start_f64(ibs_ctx* c, const double* send, double* recv, i
   if (then_wait_slot >= 0 && c->comm_pending[then_wait_slot]) {      // (saves the caller a second call per step)
     HIPCHK(hipStreamWaitEvent(c->stream, c->comm_done[then_wait_slot], 0));
     c->comm_pending[then_wait_slot] = false;
+  }
+  if (host_slot >= 0 && c->comm_pending[host_slot]) {
+    if (hipEventQuery(c->comm_done[host_slot]) != hipSuccess) HIPCHK(hipEventSynchronize(c->comm_done[host_slot]));
+    c->comm_pending[host_slot] = false;
   }
   return 0;
 }

@@ -110,11 +110,14 @@ class Context:
         check(self._lib.ibs_comm_allgather_f64(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
                                                send.numel()), "ibs_comm_allgather_f64")
 
-    def allgather_start(self, send, recv, slot=0, then_wait=-1, same_stream=False):
+    def allgather_start(self, send, recv, slot=0, then_wait=-1, same_stream=False, host_wait=None):
         """the same gather on the communicator's own stream, ordered after the work enqueued so far on the current torch
         stream: later launches do not wait for it.  comm_wait(slot) before `send` / `recv` are reused or read;
-        then_wait >= 0 does comm_wait(then_wait) in the same call.  same_stream: the context's stream is already the
-        current torch stream (the call follows a launch of this context)."""
+        then_wait >= 0 does comm_wait(then_wait) in the same call; host_wait = s instead waits for slot s on the host
+        (no stream operation; for callers that run several slots ahead).  same_stream: the context's stream is already
+        the current torch stream (the call follows a launch of this context)."""
+        if host_wait is not None:
+            then_wait = -2 - int(host_wait)
         if not same_stream:
             self._stream_from_torch(send)
         check(self._lib.ibs_comm_allgather_start_f64(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),

@@ -78,7 +78,9 @@ int ibs_lbfgsb2_result(const void* state, double* x, double* f, int32_t* counter
  *                            far on the context's stream but run on the communicator's OWN stream: the next scan does not
  *                            wait for the ranks to meet (the reference has nothing to overlap: its Gather is blocking).
  *                            slot in [0, 4) names the gather; then_wait_slot >= 0 (another slot) additionally does
- *                            ibs_comm_wait(ctx, then_wait_slot) in the same call, -1 = nothing;
+ *                            ibs_comm_wait(ctx, then_wait_slot) in the same call, -1 = nothing, -2 - s = wait for slot s
+ *                            on the HOST instead (event query; blocks only if that gather is still running) so that the
+ *                            context's stream carries no wait at all -- for callers running several slots ahead;
  *   ibs_comm_wait(ctx, slot) orders the context's stream after the gather of `slot` (slot < 0: after every pending one)
  *                            without blocking the host: call it before `send` / `recv` of that slot are reused or read;
  *   ibs_comm_destroy(ctx)    (also done by ibs_destroy).

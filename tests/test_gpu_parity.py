@@ -963,6 +963,19 @@ def test_native_rccl_allgather_single_rank():
             assert float(recvs[1 - slot][0].item()) == 100.0 + (k - 1)
     c.comm_wait()
     assert float(recvs[1][0].item()) == 105.0
+    # three slots with the HOST-side wait (no wait on the compute stream): before slot s is reused its gather has finished
+    sends.append(torch.zeros(48, dtype=torch.float64, device=dev)); recvs.append(torch.zeros(48, dtype=torch.float64, device=dev))
+    for k in range(9):
+        slot = k % 3
+        big.add_(1.0)
+        sends[slot].copy_(torch.arange(48, dtype=torch.float64, device=dev) + 200 + k)
+        c.allgather_start(sends[slot], recvs[slot], slot, host_wait=(k + 1) % 3)
+        if k >= 2:                                                               # (slot (k+1)%3 = the gather of step k-2)
+            assert float(recvs[(k + 1) % 3][0].item()) == 200.0 + (k - 2)
+    c.comm_wait()
+    assert float(recvs[2][0].item()) == 208.0
+    with pytest.raises(ibs_amd.IbsError):
+        c.allgather_start(sends[0], recvs[0], 0, host_wait=0)                    # cannot wait for itself
     c.comm_wait(3)                                                               # nothing pending there: no-op
     c.comm_destroy()
     c.close()

@@ -1,11 +1,12 @@
 set -o pipefail
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/geo_pmc
-mkdir -p $O
-cd $R
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O -o sq -- python3 tools/geo_profile_run.py > $O/sq.log 2>&1 && \
-rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY --output-format csv -d $O -o lds -- python3 tools/geo_profile_run.py > $O/lds.log 2>&1 && \
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt -- python3 tools/geo_profile_run.py > $O/kt.log 2>&1
-echo rc=$?
-ls -R $O | head -30
+T=${1:-r02a}
+mkdir -p gpurun_out/$T
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "native_rccl or new_entry" > gpurun_out/$T/pt.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/$T/pt.log
+for ov in 1 0; do
+IBS_BENCH_OVERLAP=$ov IBS_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --steps 2000 --no-cpu --no-stress > gpurun_out/$T/bench_ov$ov.json 2> gpurun_out/$T/bench_ov$ov.err; echo "rc=$?"
+tail -1 gpurun_out/$T/bench_ov$ov.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('overlap=$ov', d['value'], d['n_gpus'], d['ms_per_step'], d['config']['allgather_roundtrip_ok'], d['config']['workload'][-90:], d['ncsx_c2_sharded']['ms_per_pass'], d['ncsx_c2_sharded']['checks_passed'])
+"
+done
