@@ -93,13 +93,25 @@ class Context:
         (any initialised torch.distributed backend).  Collective over all ranks."""
         import torch
         rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        check(self._lib.ibs_comm_load(rccl.encode() if os.path.exists(rccl) else None), "ibs_comm_load")
+        # every rank takes part in the same collectives of `dist` whatever fails locally (a rank that raised before the
+        # broadcast would leave the others waiting in it): load, id, broadcast, agreement, and only then ncclCommInitRank
         ident = C.create_string_buffer(128)
-        if rank == 0:
-            check(self._lib.ibs_comm_unique_id(ident), "ibs_comm_unique_id")
-        box = [ident.raw]
+        problem = None
+        try:
+            check(self._lib.ibs_comm_load(rccl.encode() if os.path.exists(rccl) else None), "ibs_comm_load")
+            if rank == 0:
+                check(self._lib.ibs_comm_unique_id(ident), "ibs_comm_unique_id")
+        except IbsError as e:
+            problem = str(e)
+        box = [ident.raw if (rank == 0 and problem is None) else None]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
+            seen = [None] * world
+            dist.all_gather_object(seen, problem)
+        else:
+            seen = [problem]
+        if box[0] is None or any(p is not None for p in seen):
+            raise IbsError("native RCCL communicator not available on every rank: %s" % ([p for p in seen if p] or ["no id from rank 0"])[0])
         ident = C.create_string_buffer(box[0], 128)
         check(self._lib.ibs_comm_init(self._h, ident, int(rank), int(world)), "ibs_comm_init")
         self._comm_world = int(world)

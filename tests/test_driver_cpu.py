@@ -256,3 +256,55 @@ def test_bench_refuses_mismatched_world_and_spawns_before_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+class _StubLib:
+    """the four entry points Context.comm_init touches, with a failure injected on one rank"""
+    def __init__(self, fail_load):
+        self.fail_load = fail_load
+        self.inits = 0
+    def ibs_comm_load(self, path):
+        return -5 if self.fail_load else 0
+    def ibs_comm_unique_id(self, buf):
+        buf.raw = bytes(range(128))
+        return 0
+    def ibs_comm_init(self, h, ident, rank, world):
+        self.inits += 1
+        return 0
+
+
+def _worker_comm_init(rank, world, port, q, failing_rank):
+    import types
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    me = types.SimpleNamespace(_lib=_StubLib(rank == failing_rank), _h=None)
+    try:
+        ibs_amd.Context.comm_init(me, dist, rank, world)
+        out = "ok"
+    except ibs_amd.IbsError:
+        out = "refused"
+    q.put((rank, (out, me._lib.inits)))
+    dist.barrier()                      # (both ranks are still in step: nobody was left inside a collective)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing_rank", [-1, 0, 1])
+def test_two_rank_comm_init_agrees_before_the_collective_init(failing_rank):
+    """Context.comm_init: whatever fails on ONE rank before ncclCommInitRank (librccl missing, no unique id), every
+    rank takes the same collectives of the bootstrap backend and every rank refuses -- none enters the communicator's
+    collective initialisation alone.  (The library calls are stubbed: the agreement logic is what runs here.)"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_comm_init, args=(r, 2, port, q, failing_rank)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want = ("ok", 1) if failing_rank < 0 else ("refused", 0)
+    assert res[0] == want and res[1] == want
