@@ -489,8 +489,8 @@ k_fieldline_geometry_rows2(GeoArgs a) {
   int* off1 = reinterpret_cast<int*>(rn2 + nr2); int* off2 = off1 + nr1 + 1;
   {
     const int t = threadIdx.x;
-    geo_row_tables(t, nr1, a.rows_mn, a.xm, a.xn, off1, rm1, rn1);
-    geo_row_tables(t - 128, nr2, a.rows_nyq, a.xm_nyq, a.xn_nyq, off2, rm2, rn2);     // threads 128.. (t - 128 >= 0)
+    for (int q = t; q <= nr1; q += kGeoBlock2) geo_row_tables(q, nr1, a.rows_mn, a.xm, a.xn, off1, rm1, rn1);
+    for (int q = t; q <= nr2; q += kGeoBlock2) geo_row_tables(q, nr2, a.rows_nyq, a.xm_nyq, a.xn_nyq, off2, rm2, rn2);
     __syncthreads();
     const double* g_mn = a.tab_mn + (size_t)js * 6 * a.mnmax;
     const double* g_nq = a.tab_nyq + (size_t)js * 7 * a.mnmax_nyq;
