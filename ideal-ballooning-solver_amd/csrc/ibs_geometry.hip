@@ -199,6 +199,9 @@ __device__ __forceinline__ double group_sum(double v) {
   if constexpr (LPP >= 4)
     v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xF, 0xF, true),
                           __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  if constexpr (LPP >= 8)      // every lane of a quad now holds the quad's sum: the mirror image within 8 lanes is the other quad
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x141, 0xF, 0xF, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
   return v;
 }
 template <int LPP>
@@ -206,7 +209,7 @@ __device__ __forceinline__ int row_int(int v) {
   if constexpr (LPP == 1) return __builtin_amdgcn_readfirstlane(v); else return v;
 }
 
-// LPP = 1: one lane per grid point (throughput form).  LPP = 2, 4: the rows (m values) of both mode sets are
+// LPP = 1: one lane per grid point (throughput form).  LPP = 2, 4, 8: the rows (m values) of both mode sets are
 // dealt round-robin to LPP adjacent lanes and the partial sums combined by a butterfly: the per-point dependency
 // chain gets LPP times shorter, which is what bounds small batches (too few waves to hide it).
 template <int LPP>
@@ -808,8 +811,8 @@ hipError_t launch_geometry(const GeoArgs& a, hipStream_t st) {
       else n_cu = 256;
     }
     const long blocks1 = (long)((a.N + kGeoBlock - 1) / kGeoBlock) * a.n_lines;
-    int lpp = blocks1 * 4 <= n_cu ? 4 : (blocks1 * 2 <= n_cu ? 2 : 1);
-    if (a.lpp == 1 || a.lpp == 2 || a.lpp == 4) lpp = a.lpp;
+    int lpp = blocks1 * 8 <= n_cu ? 8 : (blocks1 * 4 <= n_cu ? 4 : (blocks1 * 2 <= n_cu ? 2 : 1));
+    if (a.lpp == 1 || a.lpp == 2 || a.lpp == 4 || a.lpp == 8) lpp = a.lpp;
     // Batches of at least one full block per CU: two grid points per lane (the LDS pipe no longer holds the synthesis
     // up), and the few points a line has beyond a multiple of 512 go to the one-point-per-wave kernel instead of a
     // block of their own.  tools/geo_bench.py, lines x 1,025 points, one point per lane -> this form: 2,048 lines
@@ -840,7 +843,8 @@ hipError_t launch_geometry(const GeoArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(kern, dim3((a.N * l + kGeoBlock - 1) / kGeoBlock, a.n_lines), dim3(kGeoBlock), lds, st, a);
       return hipSuccess;
     };
-    hipError_t e2 = lpp == 0 ? hipSuccess : lpp == 4 ? go(k_fieldline_geometry_rows_split<4>, 4)
+    hipError_t e2 = lpp == 0 ? hipSuccess : lpp == 8 ? go(k_fieldline_geometry_rows_split<8>, 8)
+                  : lpp == 4 ? go(k_fieldline_geometry_rows_split<4>, 4)
                   : lpp == 2 ? go(k_fieldline_geometry_rows_split<2>, 2) : go(k_fieldline_geometry_rows, 1);
     if (e2 != hipSuccess) return e2;
   } else {

@@ -57,7 +57,7 @@ struct GeoArgs {
   const int* rows_mn;      // [nrows_mn][2]
   const int* rows_nyq;     // [nrows_nyq][2]
   double dn_mn, dn_nyq;    // common n-spacing inside the rows of each set (rows with another spacing are split by the host)
-  int lpp;                 // lanes per grid point: 0 = chosen from the batch size, else 1 | 2 | 4; -2 = two grid points per lane
+  int lpp;                 // lanes per grid point: 0 = chosen from the batch size, else 1 | 2 | 4 | 8; -2 = two grid points per lane
   int j_begin, j_end;      // (set by launch_geometry) grid points [j_begin, j_end) of every line are this launch's
 };
 hipError_t launch_geometry(const GeoArgs& a, hipStream_t st);

@@ -630,7 +630,7 @@ def test_F1_geometry_lanes_per_point_variants_agree(ctx, bo, monkeypatch):
     for N in (969, 1025, 513):
         th = bo.theta_grid(N)
         out = {}
-        for lpp in ("1", "2", "4", "-2"):                       # -2: two grid points per lane (+ the tail kernel)
+        for lpp in ("1", "2", "4", "8", "-2"):                  # -2: two grid points per lane (+ the tail kernel)
             ctx.set_option("geo_lpp", lpp)
             r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))
             out[lpp] = (r["geo"].cpu().numpy(), r["dPdrho"].cpu().numpy())
@@ -638,7 +638,7 @@ def test_F1_geometry_lanes_per_point_variants_agree(ctx, bo, monkeypatch):
         r = ctx.fieldline_geometry(tabs, surf, al, th, device=torch.device("cuda:0"))     # automatic choice (4 here)
         auto = r["geo"].cpu().numpy()
         scale = np.abs(out["1"][0]).max(axis=2, keepdims=True)
-        for lpp in ("2", "4", "-2"):
+        for lpp in ("2", "4", "8", "-2"):
             assert np.isfinite(out[lpp][0]).all()
             assert (np.abs(out[lpp][0] - out["1"][0]) / scale).max() < 1e-11, (N, lpp)
             assert np.abs(out[lpp][1] - out["1"][1]).max() < 1e-11 * np.abs(out["1"][1]).max()
