@@ -811,7 +811,10 @@ hipError_t launch_geometry(const GeoArgs& a, hipStream_t st) {
       else n_cu = 256;
     }
     const long blocks1 = (long)((a.N + kGeoBlock - 1) / kGeoBlock) * a.n_lines;
-    int lpp = blocks1 * 8 <= n_cu ? 8 : (blocks1 * 4 <= n_cu ? 4 : (blocks1 * 2 <= n_cu ? 2 : 1));
+    // (8 lanes per point, geo_lpp = 8, shortens a 15-line call from 52 to 46 us, but it is not dispatched by itself: the
+    //  refinement's evaluation count reacts chaotically to the summation order -- the reference batch of bench.py went
+    //  from 10 to 29 evaluations on one surface for a 2e-15 change of its maximum -- so nothing is gained on average)
+    int lpp = blocks1 * 4 <= n_cu ? 4 : (blocks1 * 2 <= n_cu ? 2 : 1);
     if (a.lpp == 1 || a.lpp == 2 || a.lpp == 4 || a.lpp == 8) lpp = a.lpp;
     // Batches of at least one full block per CU: two grid points per lane (the LDS pipe no longer holds the synthesis
     // up), and the few points a line has beyond a multiple of 512 go to the one-point-per-wave kernel instead of a

@@ -688,7 +688,10 @@ def test_F2_batched_refinement_matches_per_surface_lbfgsb(ctx, bo):
         assert -fo[k] >= tabs_c[k].max() - 1e-9                        # never below the coarse maximum
         assert abs(-fo[k] - gam_opt) < 1e-8, (k, -fo[k], gam_opt)       # the same algorithm: same stopping point
     t0, al, gam = scan.run()
-    assert np.abs(gam + fo).max() < 1e-10
+    # (device state machines against the host-driven lockstep loop: the two batch their geometry differently -- other lanes
+    #  per grid point, i.e. another summation order -- and the end-game of L-BFGS-B reacts to rounding: a different number
+    #  of line-search evaluations, stopping points up to ~1e-9 apart in gam; bar 1e-8)
+    assert np.abs(gam + fo).max() < 2e-9
 
 
 def test_F2_device_state_machine_matches_host_driven_refinement(ctx, bo):
