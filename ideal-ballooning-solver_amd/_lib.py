@@ -52,6 +52,7 @@ SYMBOLS = {
                                              _I64, _P, _P, _I32, _P, _I32, _P, _D, _D, _I32]),
     "ibs_refine_f64": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _P, _D, _D, _I32, _P, _P,
                                  _I32, _P, _D, _I32, _D, _D, _P, _P, _P, _I32]),
+    "ibs_refine_stats": (C.c_int, [_P, _P]),
     "ibs_sturm_count_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _I64, _P, _P, _I32]),
     "ibs_surface_argmax_f64": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I32]),
     "ibs_surface_argmax_pack_f64": (C.c_int, [_P, _I32, _I32, _P, _P]),

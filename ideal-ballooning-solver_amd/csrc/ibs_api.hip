@@ -15,6 +15,9 @@
 #include "ibs_launch.hpp"
 #include "ibs_wave.hpp"
 #include "ibs_lbfgsb2.hpp"
+#include "ibs_refine.hpp"
+#include <chrono>
+#include <thread>
 
 namespace ibs {
 LaunchTable& launch_table() {
@@ -73,6 +76,10 @@ struct ibs_ctx {
   // per-surface arrival counters of the fused scan + argmax kernel (zero between launches)
   int* surf_counter = nullptr;
   int surf_counter_n = 0;
+  // ibs_refine_f64: per-round counts posted by the device (pinned host memory), statistics of the last call
+  int* refine_hist = nullptr;
+  int refine_hist_len = 0;
+  long long refine_stats[4] = {0, 0, 0, 0};      // evaluations, forward sweeps, rounds, rounds enqueued
 };
 
 namespace {
@@ -295,73 +302,29 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
 }
 
 
-// ---------------------------------------------------------------- (alpha, theta0) maximiser state machine (row F2)
-// One thread per evaluation point, each running the bounded quasi-Newton of ibs_lbfgsb2.hpp -- the L-BFGS-B that
-// scipy.optimize.minimize runs for ball_scan.py:307-314 (same bounds, ftol, gtol, maxiter, m = 10, maxls = 20) --
-// in reverse communication: a round = geometry of the requested points + fused objective/gradient + one step() per
-// point.  Every point advances on its own: no host round trip between evaluations.
-struct RefineState {
-  ibs::lbfgsb2::State q;
-  int active, nev;
-};
-struct RefineParams { double lo[2], hi[2], del_alpha, ftol, gtol; int maxiter, n_surf; };
-
-// evaluation request of one point into slot j of the batch: the three field lines of utils.py:1641-1646 and theta0
-__device__ inline void refine_emit(const RefineState& s, const RefineParams& p, int j, int surf, int* line_surf,
-                                   double* line_alpha, double* th0) {
-  const double a = s.q.x[0];
-  for (int l = 0; l < 3; ++l) { line_surf[3 * j + l] = surf; line_alpha[3 * j + l] = a + (l - 1) * 0.5 * p.del_alpha; }
-  th0[j] = s.q.x[1];
-}
+// ---------------------------------------------------------------- (alpha, theta0) maximiser (row F2): see ibs_refine.hpp
+using ibs::RefineState; using ibs::RefineParams; using ibs::RefineCtrl;
 
 __global__ void k_refine_init(int n, const int* pt_surf, const double* start, RefineState* st, RefineParams p,
-                              int* idx, int* line_surf, double* line_alpha, double* th0) {
+                              int* idx, int* line_surf, double* line_alpha, double* th0, RefineCtrl* ctrl) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) { ctrl->n_c = n; ctrl->n_lines = 3 * n; ctrl->done = 0; ctrl->round = 0; }
   if (k >= n) return;
   RefineState& s = st[k];                     // (the state lives in global memory; nothing of it is kept in registers)
   const double x0[2] = {start[2 * k], start[2 * k + 1]};
   ibs::lbfgsb2::init(s.q, x0, p.lo, p.hi, p.ftol, p.gtol, p.maxiter, 20);
-  s.active = 1; s.nev = 0;
+  s.active = 1; s.nev = 0; s.have = 0; s.sweeps = 0;
+  s.lam_prev = 0.0; s.x_prev[0] = s.x_prev[1] = 0.0; s.g_prev[0] = s.g_prev[1] = 0.0; s.err_prev = 0.0;
   idx[k] = k;
-  const int surf = min(max(pt_surf[k], 0), p.n_surf - 1);
-  refine_emit(s, p, k, surf, line_surf, line_alpha, th0);
+  ibs::refine_emit(s.q.x, p.del_alpha, k, min(max(pt_surf[k], 0), p.n_surf - 1), line_surf, line_alpha, th0);
 }
 
-// consumes the evaluations (val, jac) of the n_c batch slots (slot j holds point idx[j]) and emits the next
-// evaluation request of each into the same slot
-__global__ void k_refine_step(int n_c, const int* idx, const int* pt_surf, RefineState* st, RefineParams p,
-                              const double* val, const double* jac, int* line_surf, double* line_alpha, double* th0,
-                              int* n_active) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_c) return;
-  const int k = idx[j];
-  RefineState& s = st[k];
-  if (s.active) {
-    const double g[2] = {jac[2 * j], jac[2 * j + 1]};
-    s.nev++;
-    if (!ibs::lbfgsb2::step(s.q, val[j], g)) s.active = 0;
-  }
-  const int surf = min(max(pt_surf[k], 0), p.n_surf - 1);
-  refine_emit(s, p, j, surf, line_surf, line_alpha, th0);
-  if (s.active) atomicAdd(n_active, 1);
-}
-
-// drop the finished points from the batch: the still active ones get new slots (any order) and re-emit there
-__global__ void k_refine_compact(int n_c, const int* idx_in, int* idx_out, const int* pt_surf, const RefineState* st,
-                                 RefineParams p, int* line_surf, double* line_alpha, double* th0, int* counter) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_c) return;
-  const int k = idx_in[j];
-  if (!st[k].active) return;
-  const int pos = atomicAdd(counter, 1);
-  idx_out[pos] = k;
-  refine_emit(st[k], p, pos, min(max(pt_surf[k], 0), p.n_surf - 1), line_surf, line_alpha, th0);
-}
-
-__global__ void k_refine_out(int n, const RefineState* st, double* x_opt, double* f_opt, int* n_evals) {
+__global__ void k_refine_out(int n, const RefineState* st, double* x_opt, double* f_opt, int* n_evals, long long* stats) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   x_opt[2 * k] = st[k].q.x[0]; x_opt[2 * k + 1] = st[k].q.x[1]; f_opt[k] = st[k].q.f; n_evals[k] = st[k].nev;
+  atomicAdd(reinterpret_cast<unsigned long long*>(stats), (unsigned long long)st[k].nev);
+  atomicAdd(reinterpret_cast<unsigned long long*>(stats + 1), (unsigned long long)st[k].sweeps);
 }
 }  // namespace
 
@@ -407,6 +370,7 @@ int ibs_destroy(ibs_ctx* c) {
   DeviceGuard g(c->device);
   if (c->ws) hipFree(c->ws);
   if (c->surf_counter) hipFree(c->surf_counter);
+  if (c->refine_hist) hipHostFree(c->refine_hist);
   delete c;
   return 0;
 }
@@ -887,6 +851,11 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
   return 0;
 }
 
+// workspace for the prepared table images of the geometry row kernels (ibs_geometry.hip): the set of the form `f`
+static size_t geo_img_bytes(const ibs::GeoArgs& a, int lpp) {
+  return ibs::geo_rows_usable(a, lpp) ? pad256((size_t)a.n_surf * ibs::geo_image_doubles(a, lpp) * sizeof(double)) : 0;
+}
+
 int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm,
                                const double* xn, const double* xm_nyq, const double* xn_nyq, const double* tab_mn,
                                const double* tab_nyq, const double* scal, int32_t n_lines, const int32_t* line_surf,
@@ -904,13 +873,17 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
   ibs::GeoArgs a{};
   a.n_surf = n_surf; a.mnmax = mnmax; a.mnmax_nyq = mnmax_nyq; a.n_lines = n_lines; a.N = N; a.ld = ld;
   a.lpp = ctx->opt.geo_lpp;
+  const bool rows = nrows_mn > 0 && nrows_nyq > 0;
+  if (rows) { a.nrows_mn = nrows_mn; a.nrows_nyq = nrows_nyq; a.dn_mn = dn_mn; a.dn_nyq = dn_nyq; }
+  a.form = ibs::geo_pick_form(n_lines, N, ctx->n_cu, a.lpp);
+  const size_t img_bytes = geo_img_bytes(a, a.form.lpp);
   if (mem == IBS_MEM_HOST) {
     for (int i = 0; i < n_lines; ++i)
       if (line_surf[i] < 0 || line_surf[i] >= n_surf) return fail(IBS_ERR_ARG, "line_surf[%d]=%d out of range", i, line_surf[i]);
     const size_t n_mn = (size_t)n_surf * 6 * mnmax, n_nyq = (size_t)n_surf * 7 * mnmax_nyq, n_geo = (size_t)8 * n_lines * ld;
     size_t need = pad256(n_mn * 8) + pad256(n_nyq * 8) + 2 * pad256((size_t)mnmax * 8) + 2 * pad256((size_t)mnmax_nyq * 8) +
                   pad256((size_t)n_surf * 48) + pad256((size_t)n_lines * 4) + 2 * pad256((size_t)n_lines * 8) +
-                  pad256((size_t)N * 8) + pad256(n_geo * 8) + pad256((size_t)nrows_mn * 8) + pad256((size_t)nrows_nyq * 8) + 8192;
+                  pad256((size_t)N * 8) + pad256(n_geo * 8) + pad256((size_t)nrows_mn * 8) + pad256((size_t)nrows_nyq * 8) + img_bytes + 8192;
     if (int r = ensure_ws(ctx, need)) return r;
     Arena ar(ctx);
     auto up = [&](const void* src, size_t bytes, void* dst) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
@@ -925,12 +898,13 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
     HIPCHK(up(line_surf, (size_t)n_lines * 4, d_ls)); HIPCHK(up(line_alpha, (size_t)n_lines * 8, d_la)); HIPCHK(up(theta, (size_t)N * 8, d_th));
     a.xm = d_xm; a.xn = d_xn; a.xm_nyq = d_xmq; a.xn_nyq = d_xnq; a.tab_mn = d_mn; a.tab_nyq = d_nyq; a.scal = d_sc;
     a.line_surf = d_ls; a.line_alpha = d_la; a.theta = d_th; a.geo = d_geo; a.dPdrho = d_dP;
-    if (nrows_mn > 0 && nrows_nyq > 0) {
+    if (rows) {
       int* d_r1 = ar.take<int>((size_t)2 * nrows_mn); int* d_r2 = ar.take<int>((size_t)2 * nrows_nyq);
       HIPCHK(up(rows_mn, (size_t)nrows_mn * 8, d_r1)); HIPCHK(up(rows_nyq, (size_t)nrows_nyq * 8, d_r2));
-      a.nrows_mn = nrows_mn; a.nrows_nyq = nrows_nyq; a.rows_mn = d_r1; a.rows_nyq = d_r2; a.dn_mn = dn_mn; a.dn_nyq = dn_nyq;
+      a.rows_mn = d_r1; a.rows_nyq = d_r2;
     }
-    HIPCHK(ibs::launch_geometry(a, ctx->stream));
+    if (img_bytes) a.img[ibs::geo_lpp_index(a.form.lpp)] = ar.take<double>(img_bytes / sizeof(double));
+    HIPCHK(ibs::launch_geometry(a, ctx->stream, ctx->n_cu));
     HIPCHK(hipMemcpyAsync(geo, d_geo, n_geo * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (dPdrho) HIPCHK(hipMemcpyAsync(dPdrho, d_dP, (size_t)n_lines * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -938,8 +912,13 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
   }
   a.xm = xm; a.xn = xn; a.xm_nyq = xm_nyq; a.xn_nyq = xn_nyq; a.tab_mn = tab_mn; a.tab_nyq = tab_nyq; a.scal = scal;
   a.line_surf = line_surf; a.line_alpha = line_alpha; a.theta = theta; a.geo = geo; a.dPdrho = dPdrho;
-  if (nrows_mn > 0 && nrows_nyq > 0) { a.nrows_mn = nrows_mn; a.nrows_nyq = nrows_nyq; a.rows_mn = rows_mn; a.rows_nyq = rows_nyq; a.dn_mn = dn_mn; a.dn_nyq = dn_nyq; }
-  HIPCHK(ibs::launch_geometry(a, ctx->stream));
+  if (rows) { a.rows_mn = rows_mn; a.rows_nyq = rows_nyq; }
+  if (img_bytes) {
+    if (int r = ensure_ws(ctx, img_bytes + 4096)) return r;
+    Arena ar(ctx);
+    a.img[ibs::geo_lpp_index(a.form.lpp)] = ar.take<double>(img_bytes / sizeof(double));
+  }
+  HIPCHK(ibs::launch_geometry(a, ctx->stream, ctx->n_cu));
   return 0;
 }
 
@@ -1079,31 +1058,43 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
     for (int i = 0; i < n_pts; ++i)
       if (pt_surf[i] < 0 || pt_surf[i] >= n_surf) return fail(IBS_ERR_ARG, "pt_surf[%d]=%d out of range", i, pt_surf[i]);
   const int M = rows_per_lane(N);
-  auto grad = ibs::launch_table().grad_f64[M];
-  if (!grad) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
-  const size_t per_wave = (size_t)8 * ibs::lds_pitch(N) * sizeof(double);
-  int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
-  if (wpb > 4) wpb = 4;
-  if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
-  {
-    long per_blk = (long)n_pts / ctx->n_cu;
-    if (per_blk < 1) per_blk = 1;
-    if (per_blk < wpb) wpb = (int)per_blk;
+  auto eval = ibs::launch_table().refine_f64[M];
+  if (!eval) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
+  // LDS of the evaluation kernel: centre line (7 derived arrays) + eigenfunction + alpha-tangent (3 arrays) when they fit
+  const size_t row_b = (size_t)ibs::lds_pitch(N) * sizeof(double);
+  const size_t lds_extra = 4 * sizeof(double) + sizeof(RefineState);
+  const int lds_tangent = (11 * row_b + lds_extra <= (size_t)ctx->lds_per_block) ? 1 : 0;
+  if (8 * row_b + lds_extra > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
+  // every round = one objective/gradient evaluation of every point still in the batch.  An iteration takes at most
+  // maxls = 20 line-search evaluations, and once more after a memory restart
+  const int max_rounds = 2 + 42 * (maxiter > 0 ? maxiter : 1);
+  if (ctx->refine_hist_len < max_rounds + 2) {
+    if (ctx->refine_hist) { HIPCHK(hipHostFree(ctx->refine_hist)); ctx->refine_hist = nullptr; ctx->refine_hist_len = 0; }
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->refine_hist), (size_t)(max_rounds + 2) * sizeof(int), hipHostMallocDefault));
+    ctx->refine_hist_len = max_rounds + 2;
   }
+  volatile int* hist = ctx->refine_hist;
+  for (int r = 0; r < max_rounds + 2; ++r) hist[r] = 0;
+  hist[0] = n_pts + 1;
   const long ld = N;
   const int n_lines = 3 * n_pts;
   const size_t n_mn = (size_t)n_surf * 6 * mnmax, n_nyq = (size_t)n_surf * 7 * mnmax_nyq, n_geo = (size_t)8 * n_lines * ld;
-  size_t need = pad256(n_geo * 8) + 2 * pad256((size_t)n_lines * 4) + 2 * pad256((size_t)n_lines * 8) + 12 * pad256((size_t)n_pts * 16) +
+  ibs::GeoArgs ga{};
+  ga.n_surf = n_surf; ga.mnmax = mnmax; ga.mnmax_nyq = mnmax_nyq; ga.n_lines = n_lines; ga.N = N; ga.ld = ld;
+  ga.lpp = ctx->opt.geo_lpp;
+  if (nrows_mn > 0 && nrows_nyq > 0) { ga.nrows_mn = nrows_mn; ga.nrows_nyq = nrows_nyq; ga.dn_mn = dn_mn; ga.dn_nyq = dn_nyq; }
+  size_t need = pad256(n_geo * 8) + pad256((size_t)n_lines * 4) + pad256((size_t)n_lines * 8) + 10 * pad256((size_t)n_pts * 16) +
                 pad256((size_t)n_pts * sizeof(RefineState)) + pad256((size_t)N * 8) + 8192;
+  // the lanes-per-point forms the rounds can take as the batch shrinks (geo_pick_form is monotone in the batch size)
+  const int lpp_first = ibs::geo_pick_form(n_lines, N, ctx->n_cu, ga.lpp).lpp;
+  const int lpp_last = ibs::geo_pick_form(3, N, ctx->n_cu, ga.lpp).lpp;
+  for (int lpp = lpp_first; lpp <= lpp_last; lpp *= 2) need += geo_img_bytes(ga, lpp) + 256;
   if (host) need += pad256(n_mn * 8) + pad256(n_nyq * 8) + 2 * pad256((size_t)mnmax * 8) + 2 * pad256((size_t)mnmax_nyq * 8) +
                     pad256((size_t)n_surf * 48) + pad256((size_t)nrows_mn * 8) + pad256((size_t)nrows_nyq * 8) + 4096;
   if (int r = ensure_ws(ctx, need)) return r;
   Arena ar(ctx);
   hipStream_t st = ctx->stream;
   auto up = [&](const void* src, size_t bytes, void* dst) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st); };
-  ibs::GeoArgs ga{};
-  ga.n_surf = n_surf; ga.mnmax = mnmax; ga.mnmax_nyq = mnmax_nyq; ga.n_lines = n_lines; ga.N = N; ga.ld = ld;
-  ga.lpp = ctx->opt.geo_lpp;
   if (host) {
     double* d_xm = ar.take<double>(mnmax); double* d_xn = ar.take<double>(mnmax);
     double* d_xmq = ar.take<double>(mnmax_nyq); double* d_xnq = ar.take<double>(mnmax_nyq);
@@ -1112,78 +1103,95 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
     HIPCHK(up(xm_nyq, (size_t)mnmax_nyq * 8, d_xmq)); HIPCHK(up(xn_nyq, (size_t)mnmax_nyq * 8, d_xnq));
     HIPCHK(up(tab_mn, n_mn * 8, d_mn)); HIPCHK(up(tab_nyq, n_nyq * 8, d_nyq)); HIPCHK(up(scal, (size_t)n_surf * 48, d_sc));
     ga.xm = d_xm; ga.xn = d_xn; ga.xm_nyq = d_xmq; ga.xn_nyq = d_xnq; ga.tab_mn = d_mn; ga.tab_nyq = d_nyq; ga.scal = d_sc;
-    if (nrows_mn > 0 && nrows_nyq > 0) {
+    if (ga.nrows_mn) {
       int* d_r1 = ar.take<int>((size_t)2 * nrows_mn); int* d_r2 = ar.take<int>((size_t)2 * nrows_nyq);
       HIPCHK(up(rows_mn, (size_t)nrows_mn * 8, d_r1)); HIPCHK(up(rows_nyq, (size_t)nrows_nyq * 8, d_r2));
-      ga.nrows_mn = nrows_mn; ga.nrows_nyq = nrows_nyq; ga.rows_mn = d_r1; ga.rows_nyq = d_r2; ga.dn_mn = dn_mn; ga.dn_nyq = dn_nyq;
+      ga.rows_mn = d_r1; ga.rows_nyq = d_r2;
     }
   } else {
     ga.xm = xm; ga.xn = xn; ga.xm_nyq = xm_nyq; ga.xn_nyq = xn_nyq; ga.tab_mn = tab_mn; ga.tab_nyq = tab_nyq; ga.scal = scal;
-    if (nrows_mn > 0 && nrows_nyq > 0) { ga.nrows_mn = nrows_mn; ga.nrows_nyq = nrows_nyq; ga.rows_mn = rows_mn; ga.rows_nyq = rows_nyq; ga.dn_mn = dn_mn; ga.dn_nyq = dn_nyq; }
+    if (ga.nrows_mn) { ga.rows_mn = rows_mn; ga.rows_nyq = rows_nyq; }
   }
   double* d_th = ar.take<double>(N);
   HIPCHK(up(theta, (size_t)N * 8, d_th));
   int* d_ps = ar.take<int>(n_pts); double* d_start = ar.take<double>((size_t)2 * n_pts);
   HIPCHK(up(pt_surf, (size_t)n_pts * 4, d_ps)); HIPCHK(up(start, (size_t)n_pts * 16, d_start));
   double* d_geo = ar.take<double>(n_geo);
-  int* d_ls[2]; double* d_la[2]; double* d_t0[2]; int* d_idx[2];
-  for (int q = 0; q < 2; ++q) { d_ls[q] = ar.take<int>(n_lines); d_la[q] = ar.take<double>(n_lines); d_t0[q] = ar.take<double>(n_pts); d_idx[q] = ar.take<int>(n_pts); }
+  int* d_ls = ar.take<int>(n_lines); double* d_la = ar.take<double>(n_lines); double* d_t0 = ar.take<double>(n_pts); int* d_idx = ar.take<int>(n_pts);
   RefineState* d_st = ar.take<RefineState>(n_pts);
-  double* d_val = ar.take<double>(n_pts); double* d_jac = ar.take<double>((size_t)2 * n_pts);
   double* d_gam = ar.take<double>(n_pts); double* d_da = ar.take<double>(n_pts); double* d_dt = ar.take<double>(n_pts);
-  int* d_info = ar.take<int>(n_pts); int* d_nact = ar.take<int>(2);
+  int* d_info = ar.take<int>(n_pts);
+  RefineCtrl* d_ctrl = ar.take<RefineCtrl>(1);
+  long long* d_stats = ar.take<long long>(2);
   double* d_xo = ar.take<double>((size_t)2 * n_pts); double* d_fo = ar.take<double>(n_pts); int* d_ne = ar.take<int>(n_pts);
+  for (int lpp = lpp_first; lpp <= lpp_last; lpp *= 2)
+    if (geo_img_bytes(ga, lpp)) ga.img[ibs::geo_lpp_index(lpp)] = ar.take<double>(geo_img_bytes(ga, lpp) / sizeof(double));
   ga.theta = d_th; ga.geo = d_geo; ga.dPdrho = nullptr;
+  ga.line_surf = d_ls; ga.line_alpha = d_la;
+  ga.n_lines_dev = &d_ctrl->n_lines;
+  ga.plane = (size_t)n_lines * ld;                                        // fixed: the batch shrinks, the planes stay
 
   RefineParams prm{};
   prm.lo[0] = 0.0; prm.lo[1] = 0.0; prm.hi[0] = 3.141592653589793; prm.hi[1] = 1.5707963267948966;   // ball_scan.py:311
   prm.del_alpha = del_alpha; prm.ftol = ftol; prm.gtol = gtol; prm.maxiter = maxiter; prm.n_surf = n_surf;
-  ibs::GradArgs<double> a{};
-  a.n_pts = n_pts; a.N = N; a.h = h; a.ld = ld; a.del_alpha = del_alpha; a.wpb = wpb;
-  a.line_stride = ld;                                                   // geometry kernel output: [8][lines][ld] planes
-  a.geo = d_geo; a.val = d_val; a.jac = d_jac; a.gam = d_gam; a.dalpha = d_da; a.dth0 = d_dt; a.info = d_info;
+  ibs::RefineEvalArgs<double> ea{};
+  ea.N = N; ea.h = h; ea.geo = d_geo; ea.ld = ld; ea.plane = ga.plane;
+  ea.st = d_st; ea.prm = prm; ea.ctrl = d_ctrl; ea.idx = d_idx; ea.pt_surf = d_ps;
+  ea.line_surf = d_ls; ea.line_alpha = d_la; ea.th0 = d_t0;
+  ea.gam = d_gam; ea.dalpha = d_da; ea.dth0 = d_dt; ea.info = d_info;
+  ea.hist = ctx->refine_hist; ea.hist_len = ctx->refine_hist_len; ea.lds_tangent = lds_tangent;
 
   const dim3 grd((unsigned)((n_pts + 127) / 128)), blk(128);
-  hipLaunchKernelGGL(k_refine_init, grd, blk, 0, st, n_pts, d_ps, d_start, d_st, prm, d_idx[0], d_ls[0], d_la[0], d_t0[0]);
+  HIPCHK(hipMemsetAsync(d_stats, 0, 2 * sizeof(long long), st));
+  hipLaunchKernelGGL(k_refine_init, grd, blk, 0, st, n_pts, d_ps, d_start, d_st, prm, d_idx, d_ls, d_la, d_t0, d_ctrl);
   HIPCHK(hipGetLastError());
-  // every round = one objective/gradient evaluation of every point still in the batch.  An iteration takes at most
-  // maxls = 20 line-search evaluations, and once more after a memory restart
-  const int max_rounds = 2 + 42 * (maxiter > 0 ? maxiter : 1);
-  int rounds = 0, n_c = n_pts, cur = 0;
-  while (rounds < max_rounds && n_c > 0) {
-    const dim3 grc((unsigned)((n_c + 127) / 128));
-    ga.n_lines = 3 * n_c; ga.line_surf = d_ls[cur]; ga.line_alpha = d_la[cur];
-    a.n_pts = n_c; a.theta0 = d_t0[cur]; a.arr_stride = (long)ga.n_lines * ld;   // planes of this round's batch
-    {
-      long per_blk = (long)n_c / ctx->n_cu;
-      a.wpb = (int)(per_blk < 1 ? 1 : (per_blk < wpb ? per_blk : wpb));
+  // Rounds are enqueued kLook ahead of the last one whose count the device has posted: the grid sizes and the geometry
+  // form of round r are functions of the count after round r - 1 - kLook -- of the trajectory, not of host timing, so the
+  // arithmetic (summation order of the geometry kernel's forms) is reproducible -- and the GPU never waits for the host.
+  // Rounds enqueued after the last point has finished find an empty batch and return at once.
+  constexpr int kLook = 2;
+  int enq = 0, rounds = -1;
+  const auto t_start = std::chrono::steady_clock::now();
+  while (enq < max_rounds) {
+    const int need_r = enq > kLook ? enq - kLook : 0;
+    int spins = 0;
+    while (hist[need_r] == 0) {
+      if (++spins > 2000) {
+        std::this_thread::yield();
+        if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(120)) {
+          (void)hipStreamSynchronize(st);
+          return fail(IBS_ERR_HIP, "refinement round %d did not report within 120 s", need_r);
+        }
+      }
     }
-    const int burst = rounds < 8 ? 4 : 2;                               // rounds between two looks at the active count
-    for (int b = 0; b < burst && rounds < max_rounds; ++b, ++rounds) {
-      HIPCHK(ibs::launch_geometry(ga, st));
-      HIPCHK(grad(a, st));
-      HIPCHK(hipMemsetAsync(d_nact, 0, 2 * sizeof(int), st));
-      hipLaunchKernelGGL(k_refine_step, grc, blk, 0, st, n_c, d_idx[cur], d_ps, d_st, prm, d_val, d_jac, d_ls[cur], d_la[cur],
-                         d_t0[cur], d_nact);
-      HIPCHK(hipGetLastError());
-    }
-    int n_active = 0;
-    HIPCHK(hipMemcpyAsync(&n_active, d_nact, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (n_active < n_c && n_active > 0) {                               // finished points leave the batch
-      hipLaunchKernelGGL(k_refine_compact, grc, blk, 0, st, n_c, d_idx[cur], d_idx[cur ^ 1], d_ps, d_st, prm, d_ls[cur ^ 1],
-                         d_la[cur ^ 1], d_t0[cur ^ 1], d_nact + 1);
-      HIPCHK(hipGetLastError());
-      cur ^= 1;
-    }
-    n_c = n_active;
+    const int nc = hist[need_r] - 1;
+    if (nc <= 0) { rounds = need_r; break; }
+    ga.n_lines = 3 * nc;
+    ga.form = ibs::geo_pick_form(ga.n_lines, N, ctx->n_cu, ga.lpp);
+    HIPCHK(ibs::launch_geometry(ga, st, ctx->n_cu));
+    ea.n_c_max = nc;
+    HIPCHK(eval(ea, st));
+    ++enq;
   }
-  hipLaunchKernelGGL(k_refine_out, grd, blk, 0, st, n_pts, d_st, d_xo, d_fo, d_ne);
+  hipLaunchKernelGGL(k_refine_out, grd, blk, 0, st, n_pts, d_st, d_xo, d_fo, d_ne, d_stats);
   HIPCHK(hipGetLastError());
   HIPCHK(up(d_xo, (size_t)n_pts * 16, x_opt)); HIPCHK(up(d_fo, (size_t)n_pts * 8, f_opt));
   if (n_evals) HIPCHK(up(d_ne, (size_t)n_pts * 4, n_evals));
+  HIPCHK(up(d_stats, 2 * sizeof(long long), ctx->refine_stats));
   HIPCHK(hipStreamSynchronize(st));
+  if (rounds < 0) {                       // (the loop ended on max_rounds, or the last rounds' counts were not looked at yet)
+    rounds = enq;
+    for (int r = 0; r <= enq; ++r) if (hist[r] == 1) { rounds = r; break; }
+  }
+  ctx->refine_stats[2] = rounds; ctx->refine_stats[3] = enq;
   return rounds;
+}
+
+/* statistics of the last ibs_refine_f64 call of this context: evaluations, forward sweeps of the eigen-solves, rounds needed, rounds enqueued */
+int ibs_refine_stats(ibs_ctx* ctx, int64_t* out4) {
+  if (!ctx || !out4) return fail(IBS_ERR_ARG, "null pointer");
+  for (int i = 0; i < 4; ++i) out4[i] = ctx->refine_stats[i];
+  return 0;
 }
 
 }  // extern "C"

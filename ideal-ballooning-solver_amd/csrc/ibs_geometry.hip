@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "ibs_launch.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace ibs {
 
@@ -48,14 +49,14 @@ namespace ibs {
   const double gbdrift0 = -1.0 * BxgB_psi * 2 * shat / (B3 * sq) * sgn; \
   const double mu0 = 4 * M_PI * 1.0e-7; \
   const double cvdrift = gbdrift - 2 * Bref * L * L * sq * mu0 * dp * sgn / (etf * modB * modB); \
-  const size_t plane = (size_t)a.n_lines * a.ld, o = (size_t)line * a.ld + j; \
+  const size_t plane = a.plane, o = (size_t)line * a.ld + j; \
   a.geo[o] = bmag; a.geo[plane + o] = gradpar; a.geo[2 * plane + o] = cvdrift; a.geo[3 * plane + o] = gbdrift0; \
   a.geo[4 * plane + o] = gds2; a.geo[5 * plane + o] = gds21; a.geo[6 * plane + o] = gds22; a.geo[7 * plane + o] = gbdrift; \
 
 __global__ void __launch_bounds__(256) k_fieldline_geometry(GeoArgs a) {
   const int line = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.N) return;
+  if (j >= a.N || (a.n_lines_dev && line >= *a.n_lines_dev)) return;
   const int js = min(max(a.line_surf[line], 0), a.n_surf - 1);   // (device-resident indices are not range-checked by the C ABI)
   const double* sc = a.scal + 6 * js;
   const double s = sc[0], iota = sc[1], diota = sc[2], dp = sc[3], phiedge = sc[4], L = sc[5];
@@ -115,82 +116,212 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry(GeoArgs a) {
 }
 
 
-// (cos, sin) of the first angle of a row, m*tv - n0*phi, from running (cos, sin)(m_cur*tv) and (n0_cur*phi):
-// rows come sorted by m (VMEC order), so m advances by plane rotations; n0 takes one or two values.
-struct RowStart {
-  double tv, phi, ctv, stv;
-  double m_cur, cm, sm;       // cos/sin(m_cur * tv)
-  double n_cur, cn, sn;       // cos/sin(n_cur * phi)
-  double n_keep, cn_keep, sn_keep;   // the last non-zero first-n seen: phi is fixed per point, so this survives init(tv)
-  __device__ __forceinline__ void init_phi(double phi_) { phi = phi_; n_keep = 0.0; cn_keep = 1.0; sn_keep = 0.0; }
-  __device__ __forceinline__ void init(double tv_) {
-    tv = tv_;
-    sincos(tv, &stv, &ctv);
-    m_cur = 0.0; cm = 1.0; sm = 0.0;
-    n_cur = 0.0; cn = 1.0; sn = 0.0;
-  }
-  __device__ __forceinline__ void init(double tv_, double phi_) { init_phi(phi_); init(tv_); }
-  __device__ __forceinline__ void start(double m, double n0, double& ca, double& sa) {
-    if (m != m_cur) {
-      if (m - m_cur == 1.0) {          // VMEC order: the next row is the next m -> one plane rotation
-        const double c2 = cm * ctv - sm * stv, s2 = sm * ctv + cm * stv; cm = c2; sm = s2;
-      } else {
-        sincos(m * tv, &sm, &cm);
-      }
-      m_cur = m;
-    }
-    if (n0 != n_cur) {
-      if (n0 == 0.0) { cn = 1.0; sn = 0.0; }
-      else {
-        if (n0 != n_keep) { sincos(n0 * phi, &sn_keep, &cn_keep); n_keep = n0; }
-        cn = cn_keep; sn = sn_keep;
-      }
-      n_cur = n0;
-    }
-    ca = cm * cn + sm * sn;      // cos(m tv - n0 phi)
-    sa = sm * cn - cm * sn;      // sin(m tv - n0 phi)
-  }
-};
 
-// Same arithmetic with the mode lists walked row by row (all modes of one m): inside a row the angle
-// m theta - n phi decreases by a constant D = dn*phi per mode, so cos and sin follow the three-term recurrence
+// =====================================================================================================================
+// Row kernels (round 3).  The mode lists are walked row by row (a row = all modes of one m whose n advance by the common
+// step dn): inside a row the angle m theta - n phi changes by the constant D = dn*phi per mode, so cos and sin follow
 //   t[k+1] = 2 cos(D) t[k] - t[k-1]        (one fma each; rows hold <= ~60 modes: error growth ~k^2 eps)
-// instead of a sincos per mode.  One thread per grid point, one field line per block row.
+// instead of a sincos per mode, and cos / sin(m theta) advance from row to row by one plane rotation.
 //
-// The surface's tables are staged once per block in LDS (every lane reads the same entry: broadcast,
-// conflict-free) with each row padded by zero coefficients to a multiple of 4 modes, so that the inner loops
-// are unrolled with all LDS reads of a group issued before its arithmetic (an un-unrolled loop exposes the
-// full LDS latency per mode: measured 2x slower).  Layout, mode numbers already multiplied in:
-//   lm   [P]      lmns (root solve)
-//   amn  [P][10]  rmnc d_rmnc m*rmnc n*rmnc | d_zmns m*zmns n*zmns | d_lmns m*lmns n*lmns
-//   anq  [Q][10]  gmnc bmnc d_bmnc m*bmnc n*bmnc bsupv bsubs bsubu bsubv (pad)
-// so a mode costs five 16-byte LDS reads and one fma per accumulated quantity.
-constexpr int kGeoBlock = 512;      // 8 waves share one staged table set; 2 blocks per CU -> 4 waves per SIMD
+// Against the round-2 kernels (k_fieldline_geometry_rows / _rows2 / _split):
+//  (1) PREPARED TABLE IMAGES.  The per-surface tables a block works from -- array-of-structures, mode numbers multiplied
+//      in, rows zero-padded, two modes per 160-byte group -- are built ONCE per call (k_geo_prepare) in global memory in
+//      exactly the layout the LDS wants, so staging is a straight coalesced copy instead of a search + gather per
+//      element in every block.
+//  (2) FACTORISED ROOT SOLVE.  phi is fixed while theta_vmec is iterated (utils.py:391-416), and
+//        sum_mn l_mn sin(m tv - n phi) = sum_m [ sin(m tv) P_m - cos(m tv) Q_m ],
+//        P_m = sum_n l_mn cos(n phi),  Q_m = sum_n l_mn sin(n phi)
+//      so ONE pass over the 242 modes gives (P_m, Q_m) -- kept in registers, MAXR rows at most -- and each of the ~6
+//      secant evaluations costs a sincos and 6 flops per ROW instead of 2 per MODE.
+//  (3) PERSISTENT BLOCKS.  One 512-thread block per CU (two waves per SIMD: a lone wave gets half of its SIMD's issue
+//      rate) walks a contiguous range of wave-items and re-stages its table image only when the surface changes.
+//  (4) LANE-MAJOR FLAT GROUP LISTS.  A wave-item is 64*PPL/LPP consecutive grid points of one line: PPL = 2 points per
+//      lane for batches that fill the chip (every table entry read from LDS feeds two points: the LDS pipe, which a
+//      ds_read_b128 occupies for 4 cycles per wave whether or not its lanes broadcast, stops being the bound), or
+//      LPP = 2 / 4 / 8 lanes per point for small batches (the refinement rounds of ibs_refine_f64: a handful of lines).
+//      With LPP lanes per point every lane takes an equally long n-segment of EVERY row; the image stores each lane's
+//      groups of all rows back to back (lane stride odd in 16-byte units: the LPP addresses of a read fall on distinct
+//      banks), so the synthesis is ONE flat loop over the lane's groups with the next group's ten 16-byte reads in
+//      flight while the current one is consumed -- rows of two groups (LPP = 8) would otherwise expose the LDS latency
+//      26 + 11 times per point.
+constexpr int kGeoBlock = 512;
 constexpr int kGeoMaxRows = 128;
 
-__device__ __forceinline__ int geo_pad4(int n) { return (n + 3) & ~3; }
-__host__ __device__ inline int geo_cap(int nmodes, int nrows) { return (nmodes + 3 * nrows + 4 + 3) & ~3; }
+// phase timestamps (100 MHz wall clock) of wave 0 of the first 256 blocks: debug builds only (-DGEO_PROBE, tools/geo_probe.py)
+#ifdef GEO_PROBE
+__device__ long long geo_probe_buf[256 * 16];
+#define GEO_PROBE_AT(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) geo_probe_buf[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define GEO_PROBE_AT(k) do {} while (0)
+#endif
 
-// padded offset table of one mode set (off[r] .. off[r+1]) and the (m, first n) of each row
-__device__ __forceinline__ void geo_row_tables(int t, int nrows, const int* rows, const double* xm, const double* xn,
-                                               int* off, double* rm, double* rn) {
-  if (t >= 0 && t <= nrows) {
+struct GeoImgLayout {      // offsets (in doubles) inside one surface's image: a function of the table sizes and LPP only
+  int T1c, T2c;            // capacities (groups per lane) of the two lists, even
+  int o_ri1, o_ri2;        // row info [nr][4]: m, first n, n advance per lane, groups per lane
+  int o_int;               // ints: goff1[nr1 + 1], goff2[nr2 + 1], code1[nr1], code2[nr2]
+  int o_lm, o_amn, o_anq;  // lane-major lists
+  int s_lm, s_amn, s_anq;  // lane strides
+  int total;
+};
+__host__ __device__ inline GeoImgLayout geo_layout(int mnmax, int nr1, int mnmax_nyq, int nr2, int lpp) {
+  GeoImgLayout L;
+  // a row of c modes gives every lane ceil(c / (2 lpp)) groups of two modes; + 1 keeps the total even
+  L.T1c = (mnmax / (2 * lpp) + nr1 + 2) & ~1;
+  L.T2c = (mnmax_nyq / (2 * lpp) + nr2 + 2) & ~1;
+  L.o_ri1 = 16;            // header: s iota d_iota_d_s phiedge Aminor_p + the per-surface factors of the metric algebra
+  L.o_ri2 = L.o_ri1 + 4 * nr1;
+  L.o_int = L.o_ri2 + 4 * nr2;
+  const int n_int = (nr1 + 1) + (nr2 + 1) + nr1 + nr2;
+  L.o_lm = (L.o_int + ((n_int + 1) >> 1) + 1) & ~1;
+  L.s_lm = 2 * (L.T1c + 1);
+  L.o_amn = L.o_lm + lpp * L.s_lm;
+  L.s_amn = 2 * (10 * L.T1c + 1);
+  L.o_anq = L.o_amn + lpp * L.s_amn;
+  L.s_anq = 2 * (10 * L.T2c + 1);
+  L.total = L.o_anq + lpp * L.s_anq;
+  return L;
+}
+int geo_lpp_index(int lpp) { return lpp == 1 ? 0 : (lpp == 2 ? 1 : (lpp == 4 ? 2 : 3)); }
+size_t geo_image_doubles(const GeoArgs& a, int lpp) {
+  return (size_t)geo_layout(a.mnmax, a.nrows_mn, a.mnmax_nyq, a.nrows_nyq, lpp).total;
+}
+
+// One block per surface.  Group = two modes x 10 coefficients (mode numbers multiplied in):
+//   mn  : rmnc d_rmnc m*rmnc n*rmnc | d_zmns m*zmns n*zmns | d_lmns m*lmns n*lmns
+//   nyq : gmnc bmnc d_bmnc m*bmnc n*bmnc bsupv bsubs bsubu bsubv (pad)
+// so a mode costs five 16-byte LDS reads and one fma per accumulated quantity; lm holds the lmns pairs of the same groups
+// (P / Q pass of the root solve).  Row codes (uniform over the block, so the kernels branch on scalars):
+//   bits 0-1: 0 = same m as the row before (or m = 0 in the first row), 1 = m advanced by one (plane rotation), 2 = any
+//             other m (sincos);   bits 2-3: 0 = first n is 0 (one lane per point), 1 = the same first n as the last row that
+//             computed cos / sin(n phi), 2 = compute them.
+__global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double* img) {
+  __shared__ int goff1[kGeoMaxRows + 1], goff2[kGeoMaxRows + 1], cnt1[kGeoMaxRows], cnt2[kGeoMaxRows];
+  const int js = blockIdx.x, t = threadIdx.x;
+  const int nr1 = a.nrows_mn, nr2 = a.nrows_nyq;
+  const GeoImgLayout L = geo_layout(a.mnmax, nr1, a.mnmax_nyq, nr2, lpp);
+  double* I = img + (size_t)js * L.total;
+  for (int r = t; r < nr1; r += blockDim.x) cnt1[r] = a.rows_mn[2 * r + 1];
+  for (int r = t; r < nr2; r += blockDim.x) cnt2[r] = a.rows_nyq[2 * r + 1];
+  __syncthreads();
+  int* ints = reinterpret_cast<int*>(I + L.o_int);
+  int* igoff1 = ints; int* igoff2 = igoff1 + nr1 + 1; int* code1 = igoff2 + nr2 + 1; int* code2 = code1 + nr1;
+  if (t < 2) {                                     // groups per lane and row, running offsets (totals made even), row codes
+    int* goff = t ? goff2 : goff1; const int* cnt = t ? cnt2 : cnt1; const int nr = t ? nr2 : nr1;
+    const int* rows = t ? a.rows_nyq : a.rows_mn; const double* xm = t ? a.xm_nyq : a.xm; const double* xn = t ? a.xn_nyq : a.xn;
+    const double dn = t ? a.dn_nyq : a.dn_mn;
+    int* code = t ? code2 : code1; int* igoff = t ? igoff2 : igoff1; double* ri = I + (t ? L.o_ri2 : L.o_ri1);
     int o = 0;
-    for (int q = 0; q < t; ++q) o += geo_pad4(rows[2 * q + 1]);
-    off[t] = o;
-    if (t < nrows) { const int k0 = rows[2 * t]; rm[t] = xm[k0]; rn[t] = xn[k0]; }
+    for (int r = 0; r < nr; ++r) { goff[r] = o; o += (cnt[r] + 2 * lpp - 1) / (2 * lpp); }
+    if (o & 1) ++o;                                // (the last row gets one group of zeros more)
+    goff[nr] = o;
+    double m_prev = 0.0, keep_n = 0.0, keep_adv = 0.0;
+    bool keep = false;
+    for (int r = 0; r < nr; ++r) {
+      const int k0 = rows[2 * r], gs = goff[r + 1] - goff[r];
+      const double m = xm[k0], n0 = xn[k0], adv = 2.0 * gs * dn;
+      ri[4 * r] = m; ri[4 * r + 1] = n0; ri[4 * r + 2] = adv; ri[4 * r + 3] = gs;
+      const int mc = (m == m_prev) ? 0 : ((m - m_prev == 1.0) ? 1 : 2);
+      int nc;
+      if (lpp == 1 && n0 == 0.0) nc = 0;
+      else if (keep && n0 == keep_n && adv == keep_adv) nc = 1;
+      else { nc = 2; keep = true; keep_n = n0; keep_adv = adv; }
+      code[r] = mc | (nc << 2);
+      igoff[r] = goff[r];
+      m_prev = m;
+    }
+    igoff[nr] = goff[nr];
+  }
+  __syncthreads();
+  const int T1 = goff1[nr1], T2 = goff2[nr2];
+  if (t == 0) {
+    // header: scalars of the surface and the factors of the metric algebra that do not depend on the grid point
+    // (utils.py:474, 654-720: Psi' = -phiedge / 2 pi, Bref = 2 |Psi'| / L^2, shat = -2 s iota' / iota, ...)
+    const double* sc = a.scal + 6 * js;
+    const double s_ = sc[0], iota = sc[1], diota = sc[2], dp = sc[3], phiedge = sc[4], Lm = sc[5];
+    const double etf = -phiedge / (2 * M_PI);
+    const double Bref = 2 * fabs(etf) / (Lm * Lm);
+    const double sgn = etf > 0 ? 1.0 : (etf < 0 ? -1.0 : 0.0);
+    const double sq = sqrt(s_);
+    const double shat = (-2 * s_ / iota) * diota;
+    const double mu0 = 4 * M_PI * 1.0e-7;
+    I[0] = s_; I[1] = iota; I[2] = diota; I[3] = etf; I[4] = Lm; I[5] = 1.0 / Bref;
+    I[6] = Lm * Lm * s_;                                  // gds2  = |grad alpha|^2 L^2 s
+    I[7] = shat / Bref;                                   // gds21 = (grad alpha . grad psi) shat / Bref
+    I[8] = shat * shat / (Lm * Lm * Bref * Bref * s_);     // gds22 = |grad psi|^2 shat^2 / (L^2 Bref^2 s)
+    I[9] = -1.0 * 2 * Bref * Lm * Lm * sq * sgn;          // gbdrift  = I9 BxgB_alpha / B^3
+    I[10] = -1.0 * 2 * shat / sq * sgn;                   // gbdrift0 = I10 BxgB_psi / B^3
+    I[11] = 2 * Bref * Lm * Lm * sq * mu0 * dp * sgn / etf;   // cvdrift = gbdrift - I11 / B^2
+    I[12] = Lm * iota;                                    // gradpar = I12 B^phi / B
+    I[13] = (double)T1; I[14] = (double)T2; I[15] = 0.0;
+  }
+  auto row_of = [](int g, int nr, const int* goff) { int r = 0; while (r + 1 < nr && goff[r + 1] <= g) ++r; return r; };
+  // source mode of slot u (0 | 1) of group g of lane sub, or -1 (padding)
+  auto src_mode = [&](int sub, int g, int u, int nr, const int* goff, const int* cnt, const int* rows) {
+    const int r = row_of(g, nr, goff);
+    const int gs = goff[r + 1] - goff[r];
+    const int i = (sub * gs + (g - goff[r])) * 2 + u;
+    return i < cnt[r] ? rows[2 * r] + i : -1;
+  };
+  const double* g_mn = a.tab_mn + (size_t)js * 6 * a.mnmax;
+  const double* g_nq = a.tab_nyq + (size_t)js * 7 * a.mnmax_nyq;
+  const int n1 = a.mnmax, n2 = a.mnmax_nyq;
+  for (int e = t; e < lpp * T1 * 2; e += blockDim.x) {
+    const int sub = e / (T1 * 2), rem = e - sub * T1 * 2, g = rem >> 1, u = rem & 1;
+    const int k = src_mode(sub, g, u, nr1, goff1, cnt1, a.rows_mn);
+    double* q = I + L.o_amn + (size_t)sub * L.s_amn + 20 * g + 10 * u;
+    double* lq = I + L.o_lm + (size_t)sub * L.s_lm + 2 * g + u;
+    if (k >= 0) {
+      const double m = a.xm[k], n = a.xn[k];
+      const double rm = g_mn[k], zm = g_mn[n1 + k], l_ = g_mn[2 * n1 + k];
+      *lq = l_;
+      q[0] = rm; q[1] = g_mn[3 * n1 + k]; q[2] = m * rm; q[3] = n * rm;
+      q[4] = g_mn[4 * n1 + k]; q[5] = m * zm; q[6] = n * zm;
+      q[7] = g_mn[5 * n1 + k]; q[8] = m * l_; q[9] = n * l_;
+    } else {
+      *lq = 0.0;
+      for (int c = 0; c < 10; ++c) q[c] = 0.0;
+    }
+  }
+  for (int e = t; e < lpp * T2 * 2; e += blockDim.x) {
+    const int sub = e / (T2 * 2), rem = e - sub * T2 * 2, g = rem >> 1, u = rem & 1;
+    const int k = src_mode(sub, g, u, nr2, goff2, cnt2, a.rows_nyq);
+    double* q = I + L.o_anq + (size_t)sub * L.s_anq + 20 * g + 10 * u;
+    if (k >= 0) {
+      const double m = a.xm_nyq[k], n = a.xn_nyq[k];
+      const double bm = g_nq[n2 + k];
+      q[0] = g_nq[k]; q[1] = bm; q[2] = g_nq[2 * n2 + k]; q[3] = m * bm; q[4] = n * bm;
+      q[5] = g_nq[3 * n2 + k]; q[6] = g_nq[4 * n2 + k]; q[7] = g_nq[5 * n2 + k]; q[8] = g_nq[6 * n2 + k]; q[9] = 0.0;
+    } else {
+      for (int c = 0; c < 10; ++c) q[c] = 0.0;
+    }
   }
 }
-// padded position -> source mode (or -1 for padding)
-__device__ __forceinline__ int geo_src_mode(int idx, int nrows, const int* off, const int* rows) {
-  int r = 0;
-  while (r < nrows && off[r + 1] <= idx) ++r;
-  if (r >= nrows) return -1;
-  const int i = idx - off[r];
-  return i < rows[2 * r + 1] ? rows[2 * r] + i : -1;
+
+// sin and cos for |x| < ~1e5 (the angles here stay below ~2e3): Cody-Waite reduction by pi/2 in three 33-bit pieces (k * piece
+// exact for |k| < 2^20, the scheme of fdlibm's medium range) and the fdlibm kernels on [-pi/4, pi/4]; ~1 ulp.  A third of the
+// instructions of the general-range library sincos, which is what the root solve's evaluations mostly consisted of.
+__device__ __forceinline__ void geo_sincos(double x, double* sn, double* cs) {
+  const double k = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632673412561417e+00, x);
+  r = fma(-k, 6.07710050650619224932e-11, r);
+  r = fma(-k, 2.02226624879595063154e-21, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06); ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03); ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double s = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07); pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03); pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = (int)k;
+  const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
-// sum over the LPP adjacent lanes that share one grid point (in-register butterfly, quad_perm DPP)
+// sum over the LPP adjacent lanes that share one grid point (in-register butterfly, quad_perm / row_half_mirror DPP);
+// every lane of the group ends up with the same bits
 template <int LPP>
 __device__ __forceinline__ double group_sum(double v) {
   if constexpr (LPP >= 2)
@@ -204,261 +335,57 @@ __device__ __forceinline__ double group_sum(double v) {
                           __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
   return v;
 }
-template <int LPP>
-__device__ __forceinline__ int row_int(int v) {
-  if constexpr (LPP == 1) return __builtin_amdgcn_readfirstlane(v); else return v;
-}
 
-// LPP = 1: one lane per grid point (throughput form).  LPP = 2, 4, 8: the rows (m values) of both mode sets are
-// dealt round-robin to LPP adjacent lanes and the partial sums combined by a butterfly: the per-point dependency
-// chain gets LPP times shorter, which is what bounds small batches (too few waves to hide it).
-template <int LPP>
-__device__ __forceinline__ void geo_rows_body(const GeoArgs& a) {
-  extern __shared__ __align__(16) unsigned char geo_smem[];
-  const int line = blockIdx.y;
-  const int js = min(max(a.line_surf[line], 0), a.n_surf - 1);   // (device-resident indices are not range-checked by the C ABI)
-  const int nr1 = a.nrows_mn, nr2 = a.nrows_nyq;
-  const int P = geo_cap(a.mnmax, nr1), Q = geo_cap(a.mnmax_nyq, nr2);
-  double* lm_s = reinterpret_cast<double*>(geo_smem);
-  double* amn = lm_s + P;
-  double* anq = amn + 10 * P;
-  double* rm1 = anq + 10 * Q; double* rn1 = rm1 + nr1;
-  double* rm2 = rn1 + nr1; double* rn2 = rm2 + nr2;
-  int* off1 = reinterpret_cast<int*>(rn2 + nr2); int* off2 = off1 + nr1 + 1;
-  {
-    const int t = threadIdx.x;
-    geo_row_tables(t, nr1, a.rows_mn, a.xm, a.xn, off1, rm1, rn1);
-    geo_row_tables(t - 256, nr2, a.rows_nyq, a.xm_nyq, a.xn_nyq, off2, rm2, rn2);     // threads 256.. (t - 256 >= 0)
-    __syncthreads();
-    const double* g_mn = a.tab_mn + (size_t)js * 6 * a.mnmax;
-    const double* g_nq = a.tab_nyq + (size_t)js * 7 * a.mnmax_nyq;
-    const int n1 = a.mnmax, n2 = a.mnmax_nyq;
-    for (int idx = t; idx < P; idx += kGeoBlock) {
-      const int k = geo_src_mode(idx, nr1, off1, a.rows_mn);
-      double* q = amn + 10 * idx;
-      if (k >= 0) {
-        const double m = a.xm[k], n = a.xn[k];
-        const double rm = g_mn[k], zm = g_mn[n1 + k], lm = g_mn[2 * n1 + k];
-        lm_s[idx] = lm;
-        q[0] = rm; q[1] = g_mn[3 * n1 + k]; q[2] = m * rm; q[3] = n * rm;
-        q[4] = g_mn[4 * n1 + k]; q[5] = m * zm; q[6] = n * zm;
-        q[7] = g_mn[5 * n1 + k]; q[8] = m * lm; q[9] = n * lm;
-      } else {
-        lm_s[idx] = 0.0;
-        for (int c = 0; c < 10; ++c) q[c] = 0.0;
+// (cos, sin) of a row's first angle for PPL points of a lane.  cos / sin(m tv) advance with the rows (rows come sorted by
+// m: one plane rotation per row), cos / sin(n phi) of the lane's first n of a row are kept from the last row that computed
+// them (phi is fixed per point, and all rows but the m = 0 one start at the same n).  The row codes of the image say which
+// case a row is, uniformly for the block.
+template <int PPL>
+struct RowTrig {
+  double phi[PPL], ctv[PPL], stv[PPL], tv[PPL];
+  double cm[PPL], sm[PPL];              // cos / sin(m_cur tv)
+  double ck[PPL], sk[PPL];              // cos / sin(n phi) of the last row with code 2
+  __device__ __forceinline__ void init_phi(const double (&phi_)[PPL]) {
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) { phi[p] = phi_[p]; ck[p] = 1.0; sk[p] = 0.0; }
+  }
+  __device__ __forceinline__ void set_tv(const double (&tv_)[PPL]) {
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) { tv[p] = tv_[p]; geo_sincos(tv[p], &stv[p], &ctv[p]); }
+  }
+  __device__ __forceinline__ void rewind() {         // back to m = 0 for the next pass over the rows (same tv)
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) { cm[p] = 1.0; sm[p] = 0.0; }
+  }
+  __device__ __forceinline__ void advance_m(int mcode, double m) {
+    if (mcode == 1) {                  // VMEC order: the next row is the next m -> one plane rotation
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) {
+        const double c2 = cm[p] * ctv[p] - sm[p] * stv[p], s2 = sm[p] * ctv[p] + cm[p] * stv[p];
+        cm[p] = c2; sm[p] = s2;
       }
-    }
-    for (int idx = t; idx < Q; idx += kGeoBlock) {
-      const int k = geo_src_mode(idx, nr2, off2, a.rows_nyq);
-      double* q = anq + 10 * idx;
-      if (k >= 0) {
-        const double m = a.xm_nyq[k], n = a.xn_nyq[k];
-        const double bm = g_nq[n2 + k];
-        q[0] = g_nq[k]; q[1] = bm; q[2] = g_nq[2 * n2 + k]; q[3] = m * bm; q[4] = n * bm;
-        q[5] = g_nq[3 * n2 + k]; q[6] = g_nq[4 * n2 + k]; q[7] = g_nq[5 * n2 + k]; q[8] = g_nq[6 * n2 + k]; q[9] = 0.0;
-      } else {
-        for (int c = 0; c < 10; ++c) q[c] = 0.0;
-      }
+    } else if (mcode == 2) {
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) geo_sincos(m * tv[p], &sm[p], &cm[p]);
     }
   }
-  __syncthreads();
-  const int sub = threadIdx.x % LPP;
-  const int j_raw = (blockIdx.x * kGeoBlock + threadIdx.x) / LPP;
-  if ((int)(blockIdx.x * kGeoBlock + (threadIdx.x & ~63u)) / LPP >= a.N) return;   // whole wave past the end of the line (no barrier follows)
-  const bool live = j_raw < a.N;
-  const int j = live ? j_raw : a.N - 1;
-  const double* sc = a.scal + 6 * js;
-  const double s = sc[0], iota = sc[1], diota = sc[2], dp = sc[3], phiedge = sc[4], L = sc[5];
-  const double alpha = a.line_alpha[line];
-  const double tp = a.theta[j];
-  const double phi = (tp - alpha) / iota;
-  double sD, cD;
-  sincos(a.dn_mn * phi, &sD, &cD);
-  double two_cD = 2.0 * cD;
-  RowStart rs;
-  rs.init_phi(phi);
-  auto resid = [&](double tv) {
-    double acc0 = 0.0, acc1 = 0.0;
-    rs.init(tv);
-    int o_nx = off1[sub < nr1 ? sub : 0], e_nx = off1[sub < nr1 ? sub + 1 : 0];
-    double m_nx = rm1[sub < nr1 ? sub : 0], n_nx = rn1[sub < nr1 ? sub : 0];
-    for (int r = sub; r < nr1; r += LPP) {
-      // this row's table entries were fetched one row ahead (the LDS latency hides behind the previous row)
-      const int o = row_int<LPP>(o_nx);
-      const int ng = (row_int<LPP>(e_nx) - o) >> 2;
-      const double m_r = m_nx, n_r = n_nx;
-      { const int rn = r + LPP < nr1 ? r + LPP : r; o_nx = off1[rn]; e_nx = off1[rn + 1]; m_nx = rm1[rn]; n_nx = rn1[rn]; }
-      double s0, c0;
-      rs.start(m_r, n_r, c0, s0);
-      double sm1 = s0 * cD + c0 * sD;              // sin of the (virtual) previous mode: angle + D
-      const double2* Lp = reinterpret_cast<const double2*>(lm_s + o);
-      for (int g = 0; g < ng; ++g) {
-        const double2 u = Lp[2 * g], v = Lp[2 * g + 1];
-        const double s1 = fma(two_cD, s0, -sm1);
-        const double s2 = fma(two_cD, s1, -s0);
-        const double s3 = fma(two_cD, s2, -s1);
-        acc0 = fma(u.x, s0, acc0); acc1 = fma(u.y, s1, acc1);
-        acc0 = fma(v.x, s2, acc0); acc1 = fma(v.y, s3, acc1);
-        sm1 = s3; s0 = fma(two_cD, s3, -s2);
-      }
-    }
-    return tp - (tv + group_sum<LPP>(acc0 + acc1));
-  };
-  // secant iteration (superlinear, e_{n+1} ~ C e_n e_{n-1}): it stops, like the reference's scipy secant
-  // (tol 1.48e-8, utils.py:391-416), on the step size; a step below 1e-9 means the point it leaves was 1e-9 from
-  // the root, so the point it lands on is at ~1e-13 or better and is not evaluated again (one residual
-  // evaluation = 242 modes saved per point).
-  // Second point: one fixed-point step theta_p + resid(theta_p) instead of the reference's theta_p + 0.1
-  // (same root, about two evaluations fewer).
-  double p0 = tp;
-  double q0 = resid(p0);
-  double p1 = tp + q0;
-  double q1 = resid(p1);
-  for (int it = 0; it < 40; ++it) {
-    const double den = q1 - q0;
-    if (den == 0.0) break;
-    const double step = q1 * (p1 - p0) / den;
-    p0 = p1; q0 = q1;
-    p1 = p1 - step;
-    if (fabs(step) <= 1e-9 * fmax(1.0, fabs(p1))) break;
-    q1 = resid(p1);
-  }
-  const double tv = p1;
-  double R = 0, R_s = 0, R_t = 0, R_p = 0, Z_s = 0, Z_t = 0, Z_p = 0, l_s = 0, l_t = 0, l_p = 0;
-  rs.init(tv);
-  int o_nx = off1[sub < nr1 ? sub : 0], e_nx = off1[sub < nr1 ? sub + 1 : 0];
-  double m_nx = rm1[sub < nr1 ? sub : 0], n_nx = rn1[sub < nr1 ? sub : 0];
-  for (int r = sub; r < nr1; r += LPP) {
-    const int o = row_int<LPP>(o_nx);
-    const int ng = (row_int<LPP>(e_nx) - o) >> 1;
-    const double m_r = m_nx, n_r = n_nx;
-    { const int rn = r + LPP < nr1 ? r + LPP : r; o_nx = off1[rn]; e_nx = off1[rn + 1]; m_nx = rm1[rn]; n_nx = rn1[rn]; }
-    double sa, ca;
-    rs.start(m_r, n_r, ca, sa);
-    double sm1 = sa * cD + ca * sD, cm1 = ca * cD - sa * sD;
-    const double2* q = reinterpret_cast<const double2*>(amn + 10 * o);
-    for (int g = 0; g < ng; ++g, q += 10) {
-      const double2 q0_ = q[0], q1_ = q[1], q2_ = q[2], q3_ = q[3], q4_ = q[4];
-      const double2 q5_ = q[5], q6_ = q[6], q7_ = q[7], q8_ = q[8], q9_ = q[9];
-      const double sb = fma(two_cD, sa, -sm1), cb = fma(two_cD, ca, -cm1);
-      R = fma(q0_.x, ca, R); R_s = fma(q0_.y, ca, R_s); R_t = fma(-q1_.x, sa, R_t); R_p = fma(q1_.y, sa, R_p);
-      Z_s = fma(q2_.x, sa, Z_s); Z_t = fma(q2_.y, ca, Z_t); Z_p = fma(-q3_.x, ca, Z_p);
-      l_s = fma(q3_.y, sa, l_s); l_t = fma(q4_.x, ca, l_t); l_p = fma(-q4_.y, ca, l_p);
-      R = fma(q5_.x, cb, R); R_s = fma(q5_.y, cb, R_s); R_t = fma(-q6_.x, sb, R_t); R_p = fma(q6_.y, sb, R_p);
-      Z_s = fma(q7_.x, sb, Z_s); Z_t = fma(q7_.y, cb, Z_t); Z_p = fma(-q8_.x, cb, Z_p);
-      l_s = fma(q8_.y, sb, l_s); l_t = fma(q9_.x, cb, l_t); l_p = fma(-q9_.y, cb, l_p);
-      sm1 = sb; cm1 = cb;
-      sa = fma(two_cD, sb, -sa); ca = fma(two_cD, cb, -ca);
-    }
-  }
-  if (a.dn_nyq != a.dn_mn) {
-    sincos(a.dn_nyq * phi, &sD, &cD);
-    two_cD = 2.0 * cD;
-  }
-  if constexpr (LPP > 1) {
-    R = group_sum<LPP>(R); R_s = group_sum<LPP>(R_s); R_t = group_sum<LPP>(R_t); R_p = group_sum<LPP>(R_p);
-    Z_s = group_sum<LPP>(Z_s); Z_t = group_sum<LPP>(Z_t); Z_p = group_sum<LPP>(Z_p);
-    l_s = group_sum<LPP>(l_s); l_t = group_sum<LPP>(l_t); l_p = group_sum<LPP>(l_p);
-  }
-  double sqg = 0, modB = 0, B_s = 0, B_t = 0, B_p = 0, Bsup_phi = 0, Bsub_s = 0, Bsub_t = 0, Bsub_p = 0;
-  rs.init(tv);
-  o_nx = off2[sub < nr2 ? sub : 0]; e_nx = off2[sub < nr2 ? sub + 1 : 0];
-  m_nx = rm2[sub < nr2 ? sub : 0]; n_nx = rn2[sub < nr2 ? sub : 0];
-  for (int r = sub; r < nr2; r += LPP) {
-    const int o = row_int<LPP>(o_nx);
-    const int ng = (row_int<LPP>(e_nx) - o) >> 1;
-    const double m_r = m_nx, n_r = n_nx;
-    { const int rn = r + LPP < nr2 ? r + LPP : r; o_nx = off2[rn]; e_nx = off2[rn + 1]; m_nx = rm2[rn]; n_nx = rn2[rn]; }
-    double sa, ca;
-    rs.start(m_r, n_r, ca, sa);
-    double sm1 = sa * cD + ca * sD, cm1 = ca * cD - sa * sD;
-    const double2* q = reinterpret_cast<const double2*>(anq + 10 * o);
-    for (int g = 0; g < ng; ++g, q += 10) {
-      const double2 q0_ = q[0], q1_ = q[1], q2_ = q[2], q3_ = q[3], q4_ = q[4];
-      const double2 q5_ = q[5], q6_ = q[6], q7_ = q[7], q8_ = q[8], q9_ = q[9];
-      const double sb = fma(two_cD, sa, -sm1), cb = fma(two_cD, ca, -cm1);
-      sqg = fma(q0_.x, ca, sqg); modB = fma(q0_.y, ca, modB); B_s = fma(q1_.x, ca, B_s);
-      B_t = fma(-q1_.y, sa, B_t); B_p = fma(q2_.x, sa, B_p);
-      Bsup_phi = fma(q2_.y, ca, Bsup_phi); Bsub_s = fma(q3_.x, sa, Bsub_s); Bsub_t = fma(q3_.y, ca, Bsub_t);
-      Bsub_p = fma(q4_.x, ca, Bsub_p);
-      sqg = fma(q5_.x, cb, sqg); modB = fma(q5_.y, cb, modB); B_s = fma(q6_.x, cb, B_s);
-      B_t = fma(-q6_.y, sb, B_t); B_p = fma(q7_.x, sb, B_p);
-      Bsup_phi = fma(q7_.y, cb, Bsup_phi); Bsub_s = fma(q8_.x, sb, Bsub_s); Bsub_t = fma(q8_.y, cb, Bsub_t);
-      Bsub_p = fma(q9_.x, cb, Bsub_p);
-      sm1 = sb; cm1 = cb;
-      sa = fma(two_cD, sb, -sa); ca = fma(two_cD, cb, -ca);
-    }
-  }
-  if constexpr (LPP > 1) {
-    sqg = group_sum<LPP>(sqg); modB = group_sum<LPP>(modB); B_s = group_sum<LPP>(B_s); B_t = group_sum<LPP>(B_t);
-    B_p = group_sum<LPP>(B_p); Bsup_phi = group_sum<LPP>(Bsup_phi); Bsub_s = group_sum<LPP>(Bsub_s);
-    Bsub_t = group_sum<LPP>(Bsub_t); Bsub_p = group_sum<LPP>(Bsub_p);
-  }
-  if (!live || sub != 0) return;
-  GEO_TAIL
-}
-
-// ---- two grid points per lane (round 2) -------------------------------------------------------------------------
-// The one-point form is bound by the LDS pipe, not by the VALU: every lane of a wave reads the same table entry, and a
-// ds_read_b128 occupies the LDS array for 4 cycles per wave whether or not its lanes broadcast, so a group of two modes
-// costs 10 reads = 40 LDS cycles per wave, 160 per CU (four SIMDs share one array), against 24 FMAs = 96 VALU cycles
-// per SIMD.  With two points per lane every table entry read feeds twice the arithmetic: 160 LDS cycles against 192
-// VALU cycles per group -- the VALU binds, as it should.  256-thread blocks x 2 points keep the block's 512 points
-// and its staged tables; the registers (two sets of accumulators) allow two waves per SIMD, which is what two
-// blocks per CU provide.
-constexpr int kGeoBlock2 = 256;
-
-struct RowStart2 {
-  double tv[2], phi[2], ctv[2], stv[2];
-  double cm[2], sm[2], cn[2], sn[2], cn_keep[2], sn_keep[2];
-  double m_cur, n_cur, n_keep;        // (the same for every point: the row sequence is)
-  __device__ __forceinline__ void init_phi(double p0, double p1) {
-    phi[0] = p0; phi[1] = p1; n_keep = 0.0;
+  // cos / sin(n phi) of this lane's first n of a row
+  __device__ __forceinline__ void n_part(int ncode, double n0, double (&cn)[PPL], double (&sn)[PPL]) {
+    if (ncode == 2) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) { cn_keep[p] = 1.0; sn_keep[p] = 0.0; }
-  }
-  __device__ __forceinline__ void init(const double (&tv_)[2]) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      tv[p] = tv_[p];
-      sincos(tv[p], &stv[p], &ctv[p]);
-      cm[p] = 1.0; sm[p] = 0.0; cn[p] = 1.0; sn[p] = 0.0;
-    }
-    m_cur = 0.0; n_cur = 0.0;
-  }
-  __device__ __forceinline__ void start(double m, double n0, double (&ca)[2], double (&sa)[2]) {
-    if (m != m_cur) {
-      if (m - m_cur == 1.0) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const double c2 = cm[p] * ctv[p] - sm[p] * stv[p], s2 = sm[p] * ctv[p] + cm[p] * stv[p];
-          cm[p] = c2; sm[p] = s2;
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) sincos(m * tv[p], &sm[p], &cm[p]);
-      }
-      m_cur = m;
-    }
-    if (n0 != n_cur) {
-      if (n0 == 0.0) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) { cn[p] = 1.0; sn[p] = 0.0; }
-      } else {
-        if (n0 != n_keep) {
-#pragma unroll
-          for (int p = 0; p < 2; ++p) sincos(n0 * phi[p], &sn_keep[p], &cn_keep[p]);
-          n_keep = n0;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) { cn[p] = cn_keep[p]; sn[p] = sn_keep[p]; }
-      }
-      n_cur = n0;
+      for (int p = 0; p < PPL; ++p) geo_sincos(n0 * phi[p], &sk[p], &ck[p]);
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      ca[p] = cm[p] * cn[p] + sm[p] * sn[p];
-      sa[p] = sm[p] * cn[p] - cm[p] * sn[p];
+    for (int p = 0; p < PPL; ++p) { cn[p] = ncode == 0 ? 1.0 : ck[p]; sn[p] = ncode == 0 ? 0.0 : sk[p]; }
+  }
+  __device__ __forceinline__ void start(int code, double m, double n0, double (&ca)[PPL], double (&sa)[PPL]) {
+    advance_m(code & 3, m);
+    double cn[PPL], sn[PPL];
+    n_part(code >> 2, n0, cn, sn);
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      ca[p] = cm[p] * cn[p] + sm[p] * sn[p];      // cos(m tv - n0 phi)
+      sa[p] = sm[p] * cn[p] - cm[p] * sn[p];      // sin(m tv - n0 phi)
     }
   }
 };
@@ -476,222 +403,329 @@ __device__ __forceinline__ void geo_tail(const GeoArgs& a, int line, int j, doub
   const double Bsub_s = q.Bsub_s, Bsub_t = q.Bsub_t, Bsub_p = q.Bsub_p;
   GEO_TAIL
 }
+// The same algebra (utils.py:474-720) with the factors that depend on the surface alone taken from the image header H
+// (k_geo_prepare): two divisions per grid point (1 / sqrt(g), 1 / |B|) instead of nine and no square root.
+__device__ __forceinline__ void geo_tail_h(const GeoArgs& a, const double* H, int line, int j, double phi, double sp, double cp,
+                                           const GeoSums& q) {
+  const double iota = H[1], diota = H[2], etf = H[3];
+  const double X_t = q.R_t * cp, X_p = q.R_p * cp - q.R * sp, X_s = q.R_s * cp;
+  const double Y_t = q.R_t * sp, Y_p = q.R_p * sp + q.R * cp, Y_s = q.R_s * sp;
+  const double Z_t = q.Z_t, Z_p = q.Z_p, Z_s = q.Z_s;
+  const double isg = 1.0 / q.sqg;
+  const double gsx = (Y_t * Z_p - Z_t * Y_p) * isg, gsy = (Z_t * X_p - X_t * Z_p) * isg, gsz = (X_t * Y_p - Y_t * X_p) * isg;     // grad s   (utils.py:480-508)
+  const double gtx = (Y_p * Z_s - Z_p * Y_s) * isg, gty = (Z_p * X_s - X_p * Z_s) * isg, gtz = (X_p * Y_s - Y_p * X_s) * isg;     // grad theta
+  const double gpx = (Y_s * Z_t - Z_s * Y_t) * isg, gpy = (Z_s * X_t - X_s * Z_t) * isg, gpz = (X_s * Y_t - Y_s * X_t) * isg;     // grad phi
+  const double ls = q.l_s - phi * diota;
+  const double c1 = 1 + q.l_t, c2 = -iota + q.l_p;
+  const double gax = ls * gsx + c1 * gtx + c2 * gpx, gay = ls * gsy + c1 * gty + c2 * gpy, gaz = ls * gsz + c1 * gtz + c2 * gpz;  // grad alpha (utils.py:515-538)
+  const double psx = gsx * etf, psy = gsy * etf, psz = gsz * etf;                                                                 // grad psi
+  const double BxgB_alpha = (q.Bsub_s * q.B_t * c2 + q.Bsub_t * q.B_p * ls + q.Bsub_p * q.B_s * c1
+                             - q.Bsub_p * q.B_t * ls - q.Bsub_t * q.B_s * c2 - q.Bsub_s * q.B_p * c1) * isg;                      // utils.py:603-618
+  const double BxgB_psi = (q.Bsub_t * q.B_p - q.Bsub_p * q.B_t) * isg * etf;                                                      // utils.py:646-650
+  const double iB = 1.0 / q.modB, iB2 = iB * iB, iB3 = iB2 * iB;
+  const double bmag = q.modB * H[5];
+  const double gradpar = H[12] * q.Bsup_phi * iB;
+  const double gds2 = (gax * gax + gay * gay + gaz * gaz) * H[6];
+  const double gds21 = (gax * psx + gay * psy + gaz * psz) * H[7];
+  const double gds22 = (psx * psx + psy * psy + psz * psz) * H[8];
+  const double gbdrift = H[9] * BxgB_alpha * iB3;
+  const double gbdrift0 = H[10] * BxgB_psi * iB3;
+  const double cvdrift = gbdrift - H[11] * iB2;
+  const size_t plane = a.plane, o = (size_t)line * a.ld + j;
+  a.geo[o] = bmag; a.geo[plane + o] = gradpar; a.geo[2 * plane + o] = cvdrift; a.geo[3 * plane + o] = gbdrift0;
+  a.geo[4 * plane + o] = gds2; a.geo[5 * plane + o] = gds21; a.geo[6 * plane + o] = gds22; a.geo[7 * plane + o] = gbdrift;
+}
 
-__global__ void __launch_bounds__(kGeoBlock2) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_fieldline_geometry_rows2(GeoArgs a) {
-  extern __shared__ __align__(16) unsigned char geo_smem[];
-  const int line = blockIdx.y;
-  const int js = min(max(a.line_surf[line], 0), a.n_surf - 1);
+// one group (two modes) of the non-Nyquist / Nyquist synthesis for one point; advances the angle recurrence by two modes
+__device__ __forceinline__ void geo_group_mn(GeoSums& A, const double2 (&q)[10], double two_cD, double& sa, double& ca,
+                                             double& sm1, double& cm1) {
+  const double sa_ = sa, ca_ = ca;
+  const double sb = fma(two_cD, sa_, -sm1), cb = fma(two_cD, ca_, -cm1);
+  A.R = fma(q[0].x, ca_, A.R); A.R_s = fma(q[0].y, ca_, A.R_s); A.R_t = fma(-q[1].x, sa_, A.R_t); A.R_p = fma(q[1].y, sa_, A.R_p);
+  A.Z_s = fma(q[2].x, sa_, A.Z_s); A.Z_t = fma(q[2].y, ca_, A.Z_t); A.Z_p = fma(-q[3].x, ca_, A.Z_p);
+  A.l_s = fma(q[3].y, sa_, A.l_s); A.l_t = fma(q[4].x, ca_, A.l_t); A.l_p = fma(-q[4].y, ca_, A.l_p);
+  A.R = fma(q[5].x, cb, A.R); A.R_s = fma(q[5].y, cb, A.R_s); A.R_t = fma(-q[6].x, sb, A.R_t); A.R_p = fma(q[6].y, sb, A.R_p);
+  A.Z_s = fma(q[7].x, sb, A.Z_s); A.Z_t = fma(q[7].y, cb, A.Z_t); A.Z_p = fma(-q[8].x, cb, A.Z_p);
+  A.l_s = fma(q[8].y, sb, A.l_s); A.l_t = fma(q[9].x, cb, A.l_t); A.l_p = fma(-q[9].y, cb, A.l_p);
+  sm1 = sb; cm1 = cb;
+  sa = fma(two_cD, sb, -sa_); ca = fma(two_cD, cb, -ca_);
+}
+__device__ __forceinline__ void geo_group_nyq(GeoSums& A, const double2 (&q)[10], double two_cD, double& sa, double& ca,
+                                              double& sm1, double& cm1) {
+  const double sa_ = sa, ca_ = ca;
+  const double sb = fma(two_cD, sa_, -sm1), cb = fma(two_cD, ca_, -cm1);
+  A.sqg = fma(q[0].x, ca_, A.sqg); A.modB = fma(q[0].y, ca_, A.modB); A.B_s = fma(q[1].x, ca_, A.B_s);
+  A.B_t = fma(-q[1].y, sa_, A.B_t); A.B_p = fma(q[2].x, sa_, A.B_p);
+  A.Bsup_phi = fma(q[2].y, ca_, A.Bsup_phi); A.Bsub_s = fma(q[3].x, sa_, A.Bsub_s); A.Bsub_t = fma(q[3].y, ca_, A.Bsub_t);
+  A.Bsub_p = fma(q[4].x, ca_, A.Bsub_p);
+  A.sqg = fma(q[5].x, cb, A.sqg); A.modB = fma(q[5].y, cb, A.modB); A.B_s = fma(q[6].x, cb, A.B_s);
+  A.B_t = fma(-q[6].y, sb, A.B_t); A.B_p = fma(q[7].x, sb, A.B_p);
+  A.Bsup_phi = fma(q[7].y, cb, A.Bsup_phi); A.Bsub_s = fma(q[8].x, sb, A.Bsub_s); A.Bsub_t = fma(q[8].y, cb, A.Bsub_t);
+  A.Bsub_p = fma(q[9].x, cb, A.Bsub_p);
+  sm1 = sb; cm1 = cb;
+  sa = fma(two_cD, sb, -sa_); ca = fma(two_cD, cb, -ca_);
+}
+
+// reciprocal for well-scaled operands (hardware seed + two Newton steps): steers the secant step only
+__device__ __forceinline__ double geo_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+
+// One wave-item: grid points [jfirst, jfirst + 64 PPL / LPP) of `line`, tables of its surface staged in LDS at I.
+template <int PPL, int LPP, int MAXR>
+__device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, const GeoImgLayout& L, int line, int jfirst) {
+  static_assert(PPL == 1 || LPP == 1, "either several points per lane or several lanes per point");
+  const int lane = threadIdx.x & 63;
+  const int sub = LPP > 1 ? lane % LPP : 0;
   const int nr1 = a.nrows_mn, nr2 = a.nrows_nyq;
-  const int P = geo_cap(a.mnmax, nr1), Q = geo_cap(a.mnmax_nyq, nr2);
-  double* lm_s = reinterpret_cast<double*>(geo_smem);
-  double* amn = lm_s + P;
-  double* anq = amn + 10 * P;
-  double* rm1 = anq + 10 * Q; double* rn1 = rm1 + nr1;
-  double* rm2 = rn1 + nr1; double* rn2 = rm2 + nr2;
-  int* off1 = reinterpret_cast<int*>(rn2 + nr2); int* off2 = off1 + nr1 + 1;
-  {
-    const int t = threadIdx.x;
-    for (int q = t; q <= nr1; q += kGeoBlock2) geo_row_tables(q, nr1, a.rows_mn, a.xm, a.xn, off1, rm1, rn1);
-    for (int q = t; q <= nr2; q += kGeoBlock2) geo_row_tables(q, nr2, a.rows_nyq, a.xm_nyq, a.xn_nyq, off2, rm2, rn2);
-    __syncthreads();
-    const double* g_mn = a.tab_mn + (size_t)js * 6 * a.mnmax;
-    const double* g_nq = a.tab_nyq + (size_t)js * 7 * a.mnmax_nyq;
-    const int n1 = a.mnmax, n2 = a.mnmax_nyq;
-    for (int idx = t; idx < P; idx += kGeoBlock2) {
-      const int k = geo_src_mode(idx, nr1, off1, a.rows_mn);
-      double* q = amn + 10 * idx;
-      if (k >= 0) {
-        const double m = a.xm[k], n = a.xn[k];
-        const double rm = g_mn[k], zm = g_mn[n1 + k], lm = g_mn[2 * n1 + k];
-        lm_s[idx] = lm;
-        q[0] = rm; q[1] = g_mn[3 * n1 + k]; q[2] = m * rm; q[3] = n * rm;
-        q[4] = g_mn[4 * n1 + k]; q[5] = m * zm; q[6] = n * zm;
-        q[7] = g_mn[5 * n1 + k]; q[8] = m * lm; q[9] = n * lm;
-      } else {
-        lm_s[idx] = 0.0;
-        for (int c = 0; c < 10; ++c) q[c] = 0.0;
-      }
-    }
-    for (int idx = t; idx < Q; idx += kGeoBlock2) {
-      const int k = geo_src_mode(idx, nr2, off2, a.rows_nyq);
-      double* q = anq + 10 * idx;
-      if (k >= 0) {
-        const double m = a.xm_nyq[k], n = a.xn_nyq[k];
-        const double bm = g_nq[n2 + k];
-        q[0] = g_nq[k]; q[1] = bm; q[2] = g_nq[2 * n2 + k]; q[3] = m * bm; q[4] = n * bm;
-        q[5] = g_nq[3 * n2 + k]; q[6] = g_nq[4 * n2 + k]; q[7] = g_nq[5 * n2 + k]; q[8] = g_nq[6 * n2 + k]; q[9] = 0.0;
-      } else {
-        for (int c = 0; c < 10; ++c) q[c] = 0.0;
-      }
-    }
-  }
-  __syncthreads();
-  // points of this lane: j0 = base + t, j1 = base + 256 + t (coalesced stores per point set)
-  const int base = blockIdx.x * (2 * kGeoBlock2);
-  if (base + (int)(threadIdx.x & ~63u) >= a.j_end) return;      // whole wave past the end of the range (no barrier follows)
-  int j[2]; bool live[2];
+  const double* ri1 = I + L.o_ri1; const double* ri2 = I + L.o_ri2;
+  const int* goff1 = reinterpret_cast<const int*>(I + L.o_int); const int* goff2 = goff1 + nr1 + 1;
+  const int* code1 = goff2 + nr2 + 1; const int* code2 = code1 + nr1;
+  const double iota = I[1];
+  int j[PPL]; bool live[PPL];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int jr = base + p * kGeoBlock2 + (int)threadIdx.x;
+  for (int p = 0; p < PPL; ++p) {
+    const int jr = LPP > 1 ? jfirst + lane / LPP : jfirst + p * 64 + lane;
     live[p] = jr < a.j_end;
     j[p] = live[p] ? jr : a.j_end - 1;
   }
-  const double* sc = a.scal + 6 * js;
-  const double s = sc[0], iota = sc[1], diota = sc[2], dp = sc[3], phiedge = sc[4], L = sc[5];
   const double alpha = a.line_alpha[line];
-  double tp[2], phi[2], sD[2], cD[2], two_cD[2];
+  double tp[PPL], phi[PPL], sD[PPL], cD[PPL], two_cD[PPL];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < PPL; ++p) {
     tp[p] = a.theta[j[p]];
-    phi[p] = (tp[p] - alpha) / iota;
-    sincos(a.dn_mn * phi[p], &sD[p], &cD[p]);
+    phi[p] = (tp[p] - alpha) / iota;                                          // utils.py:373 (phi_center = 0)
+    geo_sincos(a.dn_mn * phi[p], &sD[p], &cD[p]);
     two_cD[p] = 2.0 * cD[p];
   }
-  RowStart2 rs;
-  rs.init_phi(phi[0], phi[1]);
-  auto resid = [&](const double (&tv)[2], double (&out)[2]) {
-    double acc0[2] = {0.0, 0.0}, acc1[2] = {0.0, 0.0};
-    rs.init(tv);
-    int o_nx = off1[0], e_nx = off1[nr1 > 0 ? 1 : 0];
-    double m_nx = rm1[0], n_nx = rn1[0];
-    for (int r = 0; r < nr1; ++r) {
-      const int o = __builtin_amdgcn_readfirstlane(o_nx);
-      const int ng = (__builtin_amdgcn_readfirstlane(e_nx) - o) >> 2;
-      const double m_r = m_nx, n_r = n_nx;
-      { const int rn = r + 1 < nr1 ? r + 1 : r; o_nx = off1[rn]; e_nx = off1[rn + 1]; m_nx = rm1[rn]; n_nx = rn1[rn]; }
-      double s0[2], c0[2], sm1[2];
-      rs.start(m_r, n_r, c0, s0);
+  RowTrig<PPL> rs;
+  rs.init_phi(phi);
+  GEO_PROBE_AT(2);
+  // ---- (P_m, Q_m) of the root solve: one pass over lmns with the n-recurrence alone
+  double Pm[PPL][MAXR], Qm[PPL][MAXR];
+  {
+    const double2* Lp = reinterpret_cast<const double2*>(I + L.o_lm + (size_t)sub * L.s_lm);
 #pragma unroll
-      for (int p = 0; p < 2; ++p) sm1[p] = s0[p] * cD[p] + c0[p] * sD[p];
-      const double2* Lp = reinterpret_cast<const double2*>(lm_s + o);
-      for (int g = 0; g < ng; ++g) {
-        const double2 u = Lp[2 * g], v = Lp[2 * g + 1];
+    for (int r = 0; r < MAXR; ++r) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const double s1 = fma(two_cD[p], s0[p], -sm1[p]);
-          const double s2 = fma(two_cD[p], s1, -s0[p]);
-          const double s3 = fma(two_cD[p], s2, -s1);
-          acc0[p] = fma(u.x, s0[p], acc0[p]); acc1[p] = fma(u.y, s1, acc1[p]);
-          acc0[p] = fma(v.x, s2, acc0[p]); acc1[p] = fma(v.y, s3, acc1[p]);
-          sm1[p] = s3; s0[p] = fma(two_cD[p], s3, -s2);
+      for (int p = 0; p < PPL; ++p) { Pm[p][r] = 0.0; Qm[p][r] = 0.0; }
+      if (r < nr1) {                                                          // (block-uniform)
+        const int g0 = __builtin_amdgcn_readfirstlane(goff1[r]), g1 = __builtin_amdgcn_readfirstlane(goff1[r + 1]);
+        const int code = __builtin_amdgcn_readfirstlane(code1[r]);
+        const double n0 = ri1[4 * r + 1] + (LPP > 1 ? (double)sub * ri1[4 * r + 2] : 0.0);
+        double c0[PPL], s0[PPL], cm1[PPL], sm1[PPL], aP[PPL], aQ[PPL], bP[PPL], bQ[PPL];
+        rs.n_part(code >> 2, n0, c0, s0);
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+          cm1[p] = c0[p] * cD[p] + s0[p] * sD[p]; sm1[p] = s0[p] * cD[p] - c0[p] * sD[p];     // the (virtual) previous n: angle - D
+          aP[p] = aQ[p] = bP[p] = bQ[p] = 0.0;
         }
+        for (int g = g0; g < g1; ++g) {
+          const double2 u = Lp[g];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            const double c1 = fma(two_cD[p], c0[p], -cm1[p]), s1 = fma(two_cD[p], s0[p], -sm1[p]);
+            aP[p] = fma(u.x, c0[p], aP[p]); aQ[p] = fma(u.x, s0[p], aQ[p]);
+            bP[p] = fma(u.y, c1, bP[p]); bQ[p] = fma(u.y, s1, bQ[p]);
+            cm1[p] = c1; sm1[p] = s1;
+            c0[p] = fma(two_cD[p], c1, -c0[p]); s0[p] = fma(two_cD[p], s1, -s0[p]);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) { Pm[p][r] = group_sum<LPP>(aP[p] + bP[p]); Qm[p][r] = group_sum<LPP>(aQ[p] + bQ[p]); }
+      }
+    }
+  }
+  GEO_PROBE_AT(3);
+  // ---- theta_vmec: tv + sum_m [sin(m tv) P_m - cos(m tv) Q_m] = theta_pest                 utils.py:391-416
+  int mcode[MAXR];                                                            // (scalar registers)
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) mcode[r] = r < nr1 ? (__builtin_amdgcn_readfirstlane(code1[r]) & 3) : 0;
+  auto resid = [&](const double (&tv)[PPL], double (&out)[PPL]) {
+    double acc[PPL], cmv[PPL], smv[PPL], ct[PPL], st[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) { geo_sincos(tv[p], &st[p], &ct[p]); cmv[p] = 1.0; smv[p] = 0.0; acc[p] = 0.0; }
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      if (r < nr1) {
+        if (mcode[r] == 1) {
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            const double c2 = cmv[p] * ct[p] - smv[p] * st[p], s2 = smv[p] * ct[p] + cmv[p] * st[p];
+            cmv[p] = c2; smv[p] = s2;
+          }
+        } else if (mcode[r] == 2) {
+          const double m = ri1[4 * r];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) geo_sincos(m * tv[p], &smv[p], &cmv[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) acc[p] = fma(smv[p], Pm[p][r], fma(-cmv[p], Qm[p][r], acc[p]));
       }
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) out[p] = tp[p] - (tv[p] + (acc0[p] + acc1[p]));
+    for (int p = 0; p < PPL; ++p) out[p] = tp[p] - (tv[p] + acc[p]);
   };
-  // the secant iteration of the one-point form, both points in step: a point that has converged keeps its value
-  double p0[2] = {tp[0], tp[1]}, q0[2], p1[2], q1[2];
+  // Secant iteration (superlinear, e_{n+1} ~ C e_n e_{n-1}): it stops, like the reference's scipy secant (tol 1.48e-8,
+  // utils.py:391-416), on the step size; a step below 1e-9 means the point it leaves was 1e-9 from the root, so the point
+  // it lands on is at ~1e-13 or better and is not evaluated again.  Second point: one fixed-point step
+  // theta_p + resid(theta_p) instead of the reference's theta_p + 0.1 (same root, about two evaluations fewer).
+  // All points of a wave iterate in step: a point that has converged keeps its value.
+  double p0[PPL], q0[PPL], p1[PPL], q1[PPL];
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) p0[p] = tp[p];
   resid(p0, q0);
 #pragma unroll
-  for (int p = 0; p < 2; ++p) p1[p] = tp[p] + q0[p];
+  for (int p = 0; p < PPL; ++p) p1[p] = tp[p] + q0[p];
   resid(p1, q1);
-  bool fin[2] = {false, false};
-  for (int it = 0; it < 40; ++it) {
+  bool fin[PPL];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < PPL; ++p) fin[p] = false;
+  for (int it = 0; it < 40; ++it) {
+    bool all = true;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
       const double den = q1[p] - q0[p];
       if (!fin[p]) {
         if (den == 0.0) fin[p] = true;
         else {
-          const double step = q1[p] * (p1[p] - p0[p]) / den;
+          const double step = q1[p] * (p1[p] - p0[p]) * geo_rcp(den);
           p0[p] = p1[p]; q0[p] = q1[p];
           p1[p] = p1[p] - step;
           if (fabs(step) <= 1e-9 * fmax(1.0, fabs(p1[p]))) fin[p] = true;
         }
       }
+      all = all && fin[p];
     }
-    if (__builtin_amdgcn_ballot_w64(!(fin[0] && fin[1])) == 0ull) break;      // every point of the wave is done
-    double qn[2];
+    if (__builtin_amdgcn_ballot_w64(!all) == 0ull) break;      // every point of the wave is done
+    double qn[PPL];
     resid(p1, qn);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) if (!fin[p]) q1[p] = qn[p];
+    for (int p = 0; p < PPL; ++p) if (!fin[p]) q1[p] = qn[p];
   }
-  double tv[2] = {p1[0], p1[1]};
-  GeoSums S[2];
+  GEO_PROBE_AT(4);
+  // ---- Fourier synthesis: non-Nyquist set (utils.py:420-444), then Nyquist set (utils.py:447-468)
+  GeoSums S[PPL];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < PPL; ++p) {
     S[p].R = S[p].R_s = S[p].R_t = S[p].R_p = S[p].Z_s = S[p].Z_t = S[p].Z_p = S[p].l_s = S[p].l_t = S[p].l_p = 0.0;
     S[p].sqg = S[p].modB = S[p].B_s = S[p].B_t = S[p].B_p = S[p].Bsup_phi = S[p].Bsub_s = S[p].Bsub_t = S[p].Bsub_p = 0.0;
   }
-  rs.init(tv);
-  {
-    int o_nx = off1[0], e_nx = off1[nr1 > 0 ? 1 : 0];
-    double m_nx = rm1[0], n_nx = rn1[0];
-    for (int r = 0; r < nr1; ++r) {
-      const int o = __builtin_amdgcn_readfirstlane(o_nx);
-      const int ng = (__builtin_amdgcn_readfirstlane(e_nx) - o) >> 1;
-      const double m_r = m_nx, n_r = n_nx;
-      { const int rn = r + 1 < nr1 ? r + 1 : r; o_nx = off1[rn]; e_nx = off1[rn + 1]; m_nx = rm1[rn]; n_nx = rn1[rn]; }
-      double sa[2], ca[2], sm1[2], cm1[2];
-      rs.start(m_r, n_r, ca, sa);
+  rs.set_tv(p1);
+  auto run_set = [&](auto is_nyq, const double* list, const int* goff, const int* code, const double* ri, int nr) {
+    constexpr bool NYQ = decltype(is_nyq)::value;
+    const double2* base = reinterpret_cast<const double2*>(list);
+    rs.rewind();
+    // this row's table entries are fetched one row ahead (the LDS latency hides behind the previous row)
+    int g_nx = goff[0], e_nx = goff[nr > 0 ? 1 : 0], c_nx = code[0];
+    double m_nx = ri[0], n_nx = ri[1], a_nx = ri[2];
+    for (int r = 0; r < nr; ++r) {
+      const int g0 = __builtin_amdgcn_readfirstlane(g_nx), g1 = __builtin_amdgcn_readfirstlane(e_nx);
+      const int cd = __builtin_amdgcn_readfirstlane(c_nx);
+      const double m_r = m_nx, n_r = n_nx + (LPP > 1 ? (double)sub * a_nx : 0.0);
+      { const int rn = r + 1 < nr ? r + 1 : r; g_nx = goff[rn]; e_nx = goff[rn + 1]; c_nx = code[rn]; m_nx = ri[4 * rn]; n_nx = ri[4 * rn + 1]; a_nx = ri[4 * rn + 2]; }
+      double sa[PPL], ca[PPL], sm1[PPL], cm1[PPL];
+      rs.start(cd, m_r, n_r, ca, sa);
 #pragma unroll
-      for (int p = 0; p < 2; ++p) { sm1[p] = sa[p] * cD[p] + ca[p] * sD[p]; cm1[p] = ca[p] * cD[p] - sa[p] * sD[p]; }
-      const double2* q = reinterpret_cast<const double2*>(amn + 10 * o);
-      for (int g = 0; g < ng; ++g, q += 10) {
-        const double2 q0_ = q[0], q1_ = q[1], q2_ = q[2], q3_ = q[3], q4_ = q[4];
-        const double2 q5_ = q[5], q6_ = q[6], q7_ = q[7], q8_ = q[8], q9_ = q[9];
+      for (int p = 0; p < PPL; ++p) { sm1[p] = sa[p] * cD[p] + ca[p] * sD[p]; cm1[p] = ca[p] * cD[p] - sa[p] * sD[p]; }   // angle + D
+      const double2* q = base + 10 * g0;
+      for (int g = g0; g < g1; ++g, q += 10) {
+        double2 v[10];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          GeoSums& A = S[p];
-          const double sa_ = sa[p], ca_ = ca[p];
-          const double sb = fma(two_cD[p], sa_, -sm1[p]), cb = fma(two_cD[p], ca_, -cm1[p]);
-          A.R = fma(q0_.x, ca_, A.R); A.R_s = fma(q0_.y, ca_, A.R_s); A.R_t = fma(-q1_.x, sa_, A.R_t); A.R_p = fma(q1_.y, sa_, A.R_p);
-          A.Z_s = fma(q2_.x, sa_, A.Z_s); A.Z_t = fma(q2_.y, ca_, A.Z_t); A.Z_p = fma(-q3_.x, ca_, A.Z_p);
-          A.l_s = fma(q3_.y, sa_, A.l_s); A.l_t = fma(q4_.x, ca_, A.l_t); A.l_p = fma(-q4_.y, ca_, A.l_p);
-          A.R = fma(q5_.x, cb, A.R); A.R_s = fma(q5_.y, cb, A.R_s); A.R_t = fma(-q6_.x, sb, A.R_t); A.R_p = fma(q6_.y, sb, A.R_p);
-          A.Z_s = fma(q7_.x, sb, A.Z_s); A.Z_t = fma(q7_.y, cb, A.Z_t); A.Z_p = fma(-q8_.x, cb, A.Z_p);
-          A.l_s = fma(q8_.y, sb, A.l_s); A.l_t = fma(q9_.x, cb, A.l_t); A.l_p = fma(-q9_.y, cb, A.l_p);
-          sm1[p] = sb; cm1[p] = cb;
-          sa[p] = fma(two_cD[p], sb, -sa_); ca[p] = fma(two_cD[p], cb, -ca_);
+        for (int i = 0; i < 10; ++i) v[i] = q[i];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+          if constexpr (NYQ) geo_group_nyq(S[p], v, two_cD[p], sa[p], ca[p], sm1[p], cm1[p]);
+          else geo_group_mn(S[p], v, two_cD[p], sa[p], ca[p], sm1[p], cm1[p]);
         }
       }
     }
-  }
+  };
+  run_set(std::false_type{}, I + L.o_amn + (size_t)sub * L.s_amn, goff1, code1, ri1, nr1);
+  GEO_PROBE_AT(5);
   if (a.dn_nyq != a.dn_mn) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) { sincos(a.dn_nyq * phi[p], &sD[p], &cD[p]); two_cD[p] = 2.0 * cD[p]; }
+    for (int p = 0; p < PPL; ++p) { geo_sincos(a.dn_nyq * phi[p], &sD[p], &cD[p]); two_cD[p] = 2.0 * cD[p]; }
   }
-  rs.init(tv);
-  {
-    int o_nx = off2[0], e_nx = off2[nr2 > 0 ? 1 : 0];
-    double m_nx = rm2[0], n_nx = rn2[0];
-    for (int r = 0; r < nr2; ++r) {
-      const int o = __builtin_amdgcn_readfirstlane(o_nx);
-      const int ng = (__builtin_amdgcn_readfirstlane(e_nx) - o) >> 1;
-      const double m_r = m_nx, n_r = n_nx;
-      { const int rn = r + 1 < nr2 ? r + 1 : r; o_nx = off2[rn]; e_nx = off2[rn + 1]; m_nx = rm2[rn]; n_nx = rn2[rn]; }
-      double sa[2], ca[2], sm1[2], cm1[2];
-      rs.start(m_r, n_r, ca, sa);
+  run_set(std::true_type{}, I + L.o_anq + (size_t)sub * L.s_anq, goff2, code2, ri2, nr2);
+  GEO_PROBE_AT(6);
+  if constexpr (LPP > 1) {
+    GeoSums& A = S[0];
+    A.R = group_sum<LPP>(A.R); A.R_s = group_sum<LPP>(A.R_s); A.R_t = group_sum<LPP>(A.R_t); A.R_p = group_sum<LPP>(A.R_p);
+    A.Z_s = group_sum<LPP>(A.Z_s); A.Z_t = group_sum<LPP>(A.Z_t); A.Z_p = group_sum<LPP>(A.Z_p);
+    A.l_s = group_sum<LPP>(A.l_s); A.l_t = group_sum<LPP>(A.l_t); A.l_p = group_sum<LPP>(A.l_p);
+    A.sqg = group_sum<LPP>(A.sqg); A.modB = group_sum<LPP>(A.modB); A.B_s = group_sum<LPP>(A.B_s); A.B_t = group_sum<LPP>(A.B_t);
+    A.B_p = group_sum<LPP>(A.B_p); A.Bsup_phi = group_sum<LPP>(A.Bsup_phi); A.Bsub_s = group_sum<LPP>(A.Bsub_s);
+    A.Bsub_t = group_sum<LPP>(A.Bsub_t); A.Bsub_p = group_sum<LPP>(A.Bsub_p);
+  }
 #pragma unroll
-      for (int p = 0; p < 2; ++p) { sm1[p] = sa[p] * cD[p] + ca[p] * sD[p]; cm1[p] = ca[p] * cD[p] - sa[p] * sD[p]; }
-      const double2* q = reinterpret_cast<const double2*>(anq + 10 * o);
-      for (int g = 0; g < ng; ++g, q += 10) {
-        const double2 q0_ = q[0], q1_ = q[1], q2_ = q[2], q3_ = q[3], q4_ = q[4];
-        const double2 q5_ = q[5], q6_ = q[6], q7_ = q[7], q8_ = q[8], q9_ = q[9];
+  for (int p = 0; p < PPL; ++p) {
+    if (live[p] && sub == 0) {
+      double sp, cp;
+      geo_sincos(phi[p], &sp, &cp);
+      geo_tail_h(a, I, line, j[p], phi[p], sp, cp, S[p]);
+    }
+  }
+  GEO_PROBE_AT(7);
+}
+
+// Persistent blocks: block b owns the wave-items [b W / B, (b + 1) W / B), W = n_lines * items_per_line (line-major), and
+// takes them eight at a time, one per wave.  The table image of a surface is copied into LDS when an item needs a surface
+// other than the staged one (lines usually come sorted by surface: once per surface and block).
+template <int PPL, int LPP, int MAXR>
+__global__ void __launch_bounds__(kGeoBlock) k_geo_rows(GeoArgs a, const double* __restrict__ img) {
+  extern __shared__ __align__(16) unsigned char geo_smem[];
+  __shared__ int s_req;
+  double* I = reinterpret_cast<double*>(geo_smem);
+  const GeoImgLayout L = geo_layout(a.mnmax, a.nrows_mn, a.mnmax_nyq, a.nrows_nyq, LPP);
+  const int n_lines = a.n_lines_dev ? min(*a.n_lines_dev, a.n_lines) : a.n_lines;
+  constexpr int PTS = 64 * PPL / LPP;
+  const int ipl = (a.j_end + PTS - 1) / PTS;
+  const long W = (long)n_lines * ipl;
+  const long w_begin = W * blockIdx.x / gridDim.x, w_end = W * (blockIdx.x + 1) / gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int WPB = kGeoBlock / 64;
+  int cur = -1;
+  GEO_PROBE_AT(0);
+  for (long base = w_begin; base < w_end; base += WPB) {
+    const long item = base + wave;
+    const bool has = item < w_end;
+    const int line = has ? (int)(item / ipl) : 0;
+    const int chunk = has ? (int)(item - (long)line * ipl) : 0;
+    const int js = has ? min(max(a.line_surf[line], 0), a.n_surf - 1) : -1;   // (device-resident indices are not range-checked by the C ABI)
+    bool pending = has;
+    while (true) {
+      __syncthreads();                                   // the staged image and s_req of the last pass are no longer in use
+      if (threadIdx.x == 0) s_req = -1;
+      __syncthreads();
+      if (pending && lane == 0) atomicMax(&s_req, js);
+      __syncthreads();
+      const int req = s_req;
+      if (req < 0) break;                                // (block-uniform)
+      if (req != cur) {
+        // straight copy of the prepared image, four 16-byte loads in flight per thread
+        const double2* src = reinterpret_cast<const double2*>(img + (size_t)req * L.total);
+        double2* dst = reinterpret_cast<double2*>(I);
+        const int n2 = L.total >> 1;                     // (L.total is even)
+        for (int k = threadIdx.x; k < n2; k += 4 * kGeoBlock) {
+          double2 v[4];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          GeoSums& A = S[p];
-          const double sa_ = sa[p], ca_ = ca[p];
-          const double sb = fma(two_cD[p], sa_, -sm1[p]), cb = fma(two_cD[p], ca_, -cm1[p]);
-          A.sqg = fma(q0_.x, ca_, A.sqg); A.modB = fma(q0_.y, ca_, A.modB); A.B_s = fma(q1_.x, ca_, A.B_s);
-          A.B_t = fma(-q1_.y, sa_, A.B_t); A.B_p = fma(q2_.x, sa_, A.B_p);
-          A.Bsup_phi = fma(q2_.y, ca_, A.Bsup_phi); A.Bsub_s = fma(q3_.x, sa_, A.Bsub_s); A.Bsub_t = fma(q3_.y, ca_, A.Bsub_t);
-          A.Bsub_p = fma(q4_.x, ca_, A.Bsub_p);
-          A.sqg = fma(q5_.x, cb, A.sqg); A.modB = fma(q5_.y, cb, A.modB); A.B_s = fma(q6_.x, cb, A.B_s);
-          A.B_t = fma(-q6_.y, sb, A.B_t); A.B_p = fma(q7_.x, sb, A.B_p);
-          A.Bsup_phi = fma(q7_.y, cb, A.Bsup_phi); A.Bsub_s = fma(q8_.x, sb, A.Bsub_s); A.Bsub_t = fma(q8_.y, cb, A.Bsub_t);
-          A.Bsub_p = fma(q9_.x, cb, A.Bsub_p);
-          sm1[p] = sb; cm1[p] = cb;
-          sa[p] = fma(two_cD[p], sb, -sa_); ca[p] = fma(two_cD[p], cb, -ca_);
+          for (int u = 0; u < 4; ++u) { const int kk = k + u * kGeoBlock; v[u] = kk < n2 ? src[kk] : double2{0.0, 0.0}; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int kk = k + u * kGeoBlock; if (kk < n2) dst[kk] = v[u]; }
         }
+        cur = req;
+        __syncthreads();
+      }
+      if (pending && js == cur) {
+        GEO_PROBE_AT(1);
+        geo_item<PPL, LPP, MAXR>(a, I, L, line, chunk * PTS);
+        pending = false;
       }
     }
   }
-#pragma unroll
-  for (int p = 0; p < 2; ++p)
-    if (live[p]) geo_tail(a, line, j[p], phi[p], s, iota, diota, dp, phiedge, L, S[p]);
 }
 
 // ---- one grid point per WAVE: the few points a line has beyond a multiple of the block's 512 ---------------------
@@ -708,7 +742,7 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_tail(GeoArgs a) {
   const int lane = threadIdx.x & 63;
   const int r = a.j_end - a.j_begin;
   const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= (long)a.n_lines * r) return;
+  if (w >= (long)(a.n_lines_dev ? min(*a.n_lines_dev, a.n_lines) : a.n_lines) * r) return;
   const int line = (int)(w / r);
   const int j = a.j_begin + (int)(w % r);
   const int js = min(max(a.line_surf[line], 0), a.n_surf - 1);
@@ -770,18 +804,11 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_tail(GeoArgs a) {
   if (lane == 0) geo_tail(a, line, j, phi, s, iota, diota, dp, phiedge, L, S);
 }
 
-// register budget: the throughput form is held to 128 VGPRs (4 waves per SIMD hide the LDS latency); the
-// latency forms run with few waves anyway and take what they need
-__global__ void __launch_bounds__(kGeoBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_fieldline_geometry_rows(GeoArgs a) { geo_rows_body<1>(a); }
-template <int LPP>
-__global__ void __launch_bounds__(kGeoBlock) k_fieldline_geometry_rows_split(GeoArgs a) { geo_rows_body<LPP>(a); }
-
 // dPdrho of each line: -0.5 mean((cvdrift - gbdrift) bmag^2)   (ball_scan.py:262)
-__global__ void __launch_bounds__(256) k_line_dPdrho(int n_lines, int N, long ld, const double* geo, double* dPdrho) {
+__global__ void __launch_bounds__(256) k_line_dPdrho(int n_lines, int N, long ld, size_t plane, const double* geo, double* dPdrho) {
   __shared__ double part[4];
   const int line = blockIdx.x;
-  const size_t plane = (size_t)n_lines * ld, o = (size_t)line * ld;
+  const size_t o = (size_t)line * ld;
   double s = 0.0;
   for (int j = threadIdx.x; j < N; j += blockDim.x) {
     const double B = geo[o + j];
@@ -793,73 +820,86 @@ __global__ void __launch_bounds__(256) k_line_dPdrho(int n_lines, int N, long ld
   if (threadIdx.x == 0) dPdrho[line] = -0.5 * (part[0] + part[1] + part[2] + part[3]) / N;
 }
 
-hipError_t launch_geometry(const GeoArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)(11 * geo_cap(a.mnmax, a.nrows_mn) + 10 * geo_cap(a.mnmax_nyq, a.nrows_nyq) + 2 * (a.nrows_mn + a.nrows_nyq)) * sizeof(double)
-                     + (size_t)(a.nrows_mn + a.nrows_nyq + 2) * sizeof(int);
-  if (a.nrows_mn > 0 && a.nrows_nyq > 0 && a.nrows_mn <= kGeoMaxRows && a.nrows_nyq <= kGeoMaxRows && lds <= 150 * 1024) {
-    // lanes per point: 1.  The split forms (IBS_GEO_LPP = 2, 4: rows dealt to adjacent lanes) were measured
-    // slower at every shape tried (128 x 513: 120 / 144 / 135 us; 2048 x 1025: 1.74 / 2.17 / 2.71 ms): each
-    // block stages its own 68 KB of tables and only two blocks fit a CU, so more, smaller blocks do not shorten
-    // the critical path.  Kept as an experiment switch only.
-    // ... except for batches that leave most of the chip idle (the refinement rounds of ibs_refine_f64: 3 lines per
-    // point): there the launch is the latency of one thread's ~630 modes, and splitting a point over 4 (2) lanes
-    // shortens it (5 surfaces, N = 969: 3.3 -> 2.2 ms for the whole refinement).  IBS_GEO_LPP=1|2|4 overrides.
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0, v = 0;
-      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
-      else n_cu = 256;
+// Which form serves a batch of n_lines x N grid points on a chip of n_cu CUs: the persistent kernel has 8 n_cu wave
+// slots (two waves per SIMD), and the form is the cheapest per point that still fills them.
+//   lpp_opt: 0 = by batch size, 1 | 2 | 4 | 8 = lanes per point, -2 = two points per lane.
+GeoForm geo_pick_form(long n_lines, int N, int n_cu, int lpp_opt) {
+  if (lpp_opt == -2) return GeoForm{2, 1};
+  if (lpp_opt == 1 || lpp_opt == 2 || lpp_opt == 4 || lpp_opt == 8) return GeoForm{1, lpp_opt};
+  const long pts = n_lines * (long)N, slots = 8L * n_cu;
+  if (pts >= slots * 128) return GeoForm{2, 1};
+  if (pts >= slots * 64) return GeoForm{1, 1};
+  if (pts >= slots * 32) return GeoForm{1, 2};
+  if (pts >= slots * 16) return GeoForm{1, 4};
+  return GeoForm{1, 8};
+}
+bool geo_rows_usable(const GeoArgs& a, int lpp) {
+  if (a.nrows_mn <= 0 || a.nrows_nyq <= 0 || a.nrows_mn > kGeoMaxRows || a.nrows_nyq > kGeoMaxRows) return false;
+  if (a.nrows_mn > 24 || (a.nrows_mn > 12 && lpp != 1)) return false;      // (P_m, Q_m) live in registers: MAXR instantiations below
+  return geo_image_doubles(a, lpp) * sizeof(double) <= 150 * 1024;
+}
+
+// a.form (set by the caller through geo_pick_form, or {0, 0} = pick here), a.img[geo_lpp_index(lpp)] = room for
+// n_surf * geo_image_doubles(a, lpp) doubles, a.img_ready = bit per image already built from these tables (updated).
+hipError_t launch_geometry(GeoArgs& a, hipStream_t st, int n_cu) {
+  GeoForm f = a.form;
+  if (f.ppl == 0) f = geo_pick_form(a.n_lines, a.N, n_cu, a.lpp);
+  const size_t plane = a.plane ? a.plane : (size_t)a.n_lines * a.ld;
+  a.plane = plane;
+  const int li = geo_lpp_index(f.lpp);
+  if (geo_rows_usable(a, f.lpp) && a.img[li]) {
+    if (!(a.img_ready & (1u << li))) {
+      hipLaunchKernelGGL(k_geo_prepare, dim3(a.n_surf), dim3(256), 0, st, a, f.lpp, a.img[li]);
+      a.img_ready |= 1u << li;
     }
-    const long blocks1 = (long)((a.N + kGeoBlock - 1) / kGeoBlock) * a.n_lines;
-    // (8 lanes per point, geo_lpp = 8, shortens a 15-line call from 52 to 46 us, but it is not dispatched by itself: the
-    //  refinement's evaluation count reacts chaotically to the summation order -- the reference batch of bench.py went
-    //  from 10 to 29 evaluations on one surface for a 2e-15 change of its maximum -- so nothing is gained on average)
-    int lpp = blocks1 * 4 <= n_cu ? 4 : (blocks1 * 2 <= n_cu ? 2 : 1);
-    if (a.lpp == 1 || a.lpp == 2 || a.lpp == 4 || a.lpp == 8) lpp = a.lpp;
-    // Batches of at least one full block per CU: two grid points per lane (the LDS pipe no longer holds the synthesis
-    // up), and the few points a line has beyond a multiple of 512 go to the one-point-per-wave kernel instead of a
-    // block of their own.  tools/geo_bench.py, lines x 1,025 points, one point per lane -> this form: 2,048 lines
-    // 1.45 -> 1.05 ms, 1,024: 0.75 -> 0.55, 256: 0.23 -> 0.17, 128: 0.158 -> 0.134; 8,760 x 969: 4.95 -> 4.35 ms; smaller
-    // batches are one block's latency, which two points per lane double (128 x 513: 0.10 -> 0.13 ms).
-    // geo_lpp = -2 forces this form, 1 | 2 | 4 the others.
-    const long n_points = (long)a.n_lines * a.N;
-    if (a.lpp == -2 || (a.lpp == 0 && n_points >= (long)n_cu * kGeoBlock)) {
-      GeoArgs b = a;
-      const int per = 2 * kGeoBlock2;
-      const int rem = a.N % per;
-      b.j_begin = 0;
-      b.j_end = (rem > 0 && rem <= 16 && a.N > per) ? a.N - rem : a.N;
-      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fieldline_geometry_rows2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e1 != hipSuccess) return e1;
-      hipLaunchKernelGGL(k_fieldline_geometry_rows2, dim3((b.j_end + per - 1) / per, a.n_lines), dim3(kGeoBlock2), lds, st, b);
-      if (b.j_end < a.N) {
-        GeoArgs c = a;
-        c.j_begin = b.j_end; c.j_end = a.N;
-        const long waves = (long)a.n_lines * (c.j_end - c.j_begin);
-        hipLaunchKernelGGL(k_fieldline_geometry_tail, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, c);
-      }
-      lpp = 0;
-    }
-    auto go = [&](auto kern, int l) {
+    const size_t lds = geo_image_doubles(a, f.lpp) * sizeof(double);
+    const int pts = 64 * f.ppl / f.lpp;
+    GeoArgs b = a;
+    const int rem = a.N % pts;
+    // the few points a line has beyond a multiple of the wave-item (N = 2^k + 1: one) go to the one-point-per-wave
+    // kernel instead of a wave-item of their own
+    b.j_begin = 0;
+    b.j_end = (f.lpp == 1 && rem > 0 && rem <= 16 && a.N > pts) ? a.N - rem : a.N;
+    const long items = (long)a.n_lines * ((b.j_end + pts - 1) / pts);
+    long nblk = (items + 7) / 8;
+    if (nblk > n_cu) nblk = n_cu;
+    if (nblk < 1) nblk = 1;
+    auto go = [&](auto kern) {
       hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e1 != hipSuccess) return e1;
-      hipLaunchKernelGGL(kern, dim3((a.N * l + kGeoBlock - 1) / kGeoBlock, a.n_lines), dim3(kGeoBlock), lds, st, a);
+      hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kGeoBlock), lds, st, b, (const double*)a.img[li]);
       return hipSuccess;
     };
-    hipError_t e2 = lpp == 0 ? hipSuccess : lpp == 8 ? go(k_fieldline_geometry_rows_split<8>, 8)
-                  : lpp == 4 ? go(k_fieldline_geometry_rows_split<4>, 4)
-                  : lpp == 2 ? go(k_fieldline_geometry_rows_split<2>, 2) : go(k_fieldline_geometry_rows, 1);
+    hipError_t e2;
+    if (a.nrows_mn > 12) e2 = go(k_geo_rows<1, 1, 24>);
+    else if (f.ppl == 2) e2 = go(k_geo_rows<2, 1, 12>);
+    else if (f.lpp == 1) e2 = go(k_geo_rows<1, 1, 12>);
+    else if (f.lpp == 2) e2 = go(k_geo_rows<1, 2, 12>);
+    else if (f.lpp == 4) e2 = go(k_geo_rows<1, 4, 12>);
+    else e2 = go(k_geo_rows<1, 8, 12>);
     if (e2 != hipSuccess) return e2;
+    if (b.j_end < a.N) {
+      GeoArgs c = a;
+      c.j_begin = b.j_end; c.j_end = a.N;
+      const long waves = (long)a.n_lines * (c.j_end - c.j_begin);
+      hipLaunchKernelGGL(k_fieldline_geometry_tail, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, c);
+    }
   } else {
     hipLaunchKernelGGL(k_fieldline_geometry, dim3((a.N + 255) / 256, a.n_lines), dim3(256), 0, st, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.dPdrho) {
-    hipLaunchKernelGGL(k_line_dPdrho, dim3(a.n_lines), dim3(256), 0, st, a.n_lines, a.N, a.ld, a.geo, a.dPdrho);
+    hipLaunchKernelGGL(k_line_dPdrho, dim3(a.n_lines), dim3(256), 0, st, a.n_lines, a.N, a.ld, plane, a.geo, a.dPdrho);
     e = hipGetLastError();
   }
   return e;
 }
 
 }  // namespace ibs
+
+#ifdef GEO_PROBE
+extern "C" int ibs_geo_probe_read(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ibs::geo_probe_buf), sizeof(long long) * 256 * 16);
+}
+#endif

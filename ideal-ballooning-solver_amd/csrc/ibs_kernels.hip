@@ -8,6 +8,7 @@
 //  k_sturm_count : inertia of T - lam F at given shifts (pins the s-alpha stability test)
 #include "ibs_wave.hpp"
 #include "ibs_launch.hpp"
+#include "ibs_refine.hpp"
 #include <type_traits>
 
 #ifndef IBS_M
@@ -786,6 +787,135 @@ __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const
   }
 }
 
+// ---------------------------------------------------------------- one round of the device-resident maximiser (row F2)
+// alpha-tangent of (g, c, f) staged in LDS by the whole block (same values as AlphaTangent::at)
+template <typename T>
+struct AlphaTangentLds {
+  const T* Tg; const T* Tc; const T* Tf;
+  __device__ __forceinline__ void at(int j, T& ga, T& ca, T& fa) const { const int q = lpos(j); ga = Tg[q]; ca = Tc[q]; fa = Tf[q]; }
+};
+
+// One block (4 waves) per point of the batch; see ibs_refine.hpp.  The objective is utils.py:1632-1728 (as k_obj_w_grad),
+// the optimizer step ibs_lbfgsb2.hpp (= scipy's L-BFGS-B for ball_scan.py:307-314) on the point's state, and the block
+// that finishes last re-packs the batch (finished points leave it) for the next round.
+template <typename T, int M>
+__global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
+  static_assert(sizeof(T) == 8, "the refinement is an FP64 path");
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int n_c = a.ctrl->n_c;
+  const int slot = blockIdx.x;
+  if (slot >= n_c) return;                                 // (block-uniform: the grid was sized for an earlier, larger batch)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int N = a.N;
+  const int P = lds_pitch(N);
+  T* A1 = smem; T* A3 = A1 + P; T* C0 = A3 + P; T* C1 = C0 + P; T* G0 = C1 + P; T* G1 = G0 + P; T* G2 = G1 + P; T* Xs = G2 + P;
+  T* Tg = Xs + P; T* Tc = Tg + P; T* Tf = Tc + P;
+  T* s_dP = smem + (size_t)(a.lds_tangent ? 11 : 8) * P;
+  double* s_state = s_dP + 4;
+  constexpr int kStateWords = (int)(sizeof(RefineState) / 8);
+  const int k = a.idx[slot];
+  const T th0 = a.th0[slot];
+  const long ld = a.ld, as = (long)a.plane;                // line pitch / distance between the 8 arrays of a line
+  const T* pl = a.geo + (long)(3 * slot) * ld; const T* pc = pl + ld; const T* pr = pc + ld;
+  if (wave < 3) {                                          // dPdrho of the three lines, one wave each (utils.py:1657 / 1691 / 1703)
+    const T d = line_dPdrho(wave == 0 ? pl : (wave == 1 ? pc : pr), as, N, lane);
+    if (lane == 0) s_dP[wave] = d;
+  } else {                                                 // meanwhile the optimizer state of the point comes into LDS
+    const double* src = reinterpret_cast<const double*>(a.st + k);
+    for (int i = lane; i < kStateWords; i += kWave) s_state[i] = src[i];
+  }
+  __syncthreads();
+  const T dP_l = s_dP[0], dP_c = s_dP[1], dP_r = s_dP[2];
+  const AlphaTangent<T> tang{pl, pr, as, -dP_l, -dP_r, th0, T(2) * th0, th0 * th0, T(1) / a.prm.del_alpha};
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    const T B = pc[j], gp = xabs(pc[as + j]);
+    const T inv = T(1) / (gp * B);
+    const int q = lpos(j);
+    A1[q] = gp / B; A3[q] = inv / (B * B);
+    C0[q] = -dP_c * pc[2 * as + j] * inv; C1[q] = -dP_c * pc[3 * as + j] * inv;
+    G0[q] = pc[4 * as + j]; G1[q] = pc[5 * as + j]; G2[q] = pc[6 * as + j];
+    if (a.lds_tangent) {
+      T ga, ca, fa;
+      tang.at(j, ga, ca, fa);
+      Tg[q] = ga; Tc[q] = ca; Tf[q] = fa;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;                                   // (no block barrier below)
+  RefineState& S = *reinterpret_cast<RefineState*>(s_state);
+  SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
+  WaveSolver<T, M> ws;
+  SolveInfo inf{0, 0};
+  const bool bad = ws.setup(src, N, a.h);
+  // warm start: lam of the point's previous evaluation moved along the Hellmann-Feynman gradient found there; the bracket
+  // still moves on counts only, so a poor guess costs sweeps, never correctness
+  const T xe0 = S.q.x[0], xe1 = S.q.x[1];
+  T lam = T(0), guess = T(0);
+  const bool warm = !bad && S.have != 0;
+  if (warm) {
+    const T lin = -(S.g_prev[0] * (xe0 - S.x_prev[0]) + S.g_prev[1] * (xe1 - S.x_prev[1]));
+    guess = S.lam_prev + lin;
+    const T floor_w = T(4096) * T(64) * Eps<T>::v * ws.normA;
+    const T width = xmax(xmax(T(0.5) * xabs(lin), T(4) * S.err_prev), floor_w);
+    lam = ws.solve(inf, true, guess, width);
+  } else if (!bad) {
+    lam = ws.solve(inf);
+  } else {
+    inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi);
+  }
+  if (a.lds_tangent) {
+    const AlphaTangentLds<T> tl{Tg, Tc, Tf};
+    finish<T, M, SrcGeo<T>, true, AlphaTangentLds<T>>(ws, src, N, a.h, Xs, lam, inf, slot, nullptr, a.gam, nullptr, nullptr,
+                                                      a.dth0, a.info, &tl, a.dalpha);
+  } else {
+    finish<T, M, SrcGeo<T>, true, AlphaTangent<T>>(ws, src, N, a.h, Xs, lam, inf, slot, nullptr, a.gam, nullptr, nullptr,
+                                                   a.dth0, a.info, &tang, a.dalpha);
+  }
+  if (lane == 0) {                                         // lane 0 wrote the three scratch values itself
+    const double val = -a.gam[slot];                                 // utils.py:1728
+    const double g[2] = {-a.dalpha[slot], -a.dth0[slot]};
+    S.err_prev = warm ? xabs(lam - guess) : T(0);
+    S.lam_prev = lam; S.x_prev[0] = xe0; S.x_prev[1] = xe1; S.g_prev[0] = g[0]; S.g_prev[1] = g[1];
+    S.have = bad ? 0 : 1;
+    S.sweeps += inf.iters;
+    S.nev++;
+    S.active = lbfgsb2::step(S.q, val, g) ? 1 : 0;
+  }
+  wave_lds_sync();
+  {
+    double* dst = reinterpret_cast<double*>(a.st + k);
+    for (int i = lane; i < kStateWords; i += kWave) dst[i] = s_state[i];
+  }
+  // ---- last block done: compact the batch for the next round (ibs_refine.hpp)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  int last = 0;
+  if (lane == 0) last = (__hip_atomic_fetch_add(&a.ctrl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_c - 1) ? 1 : 0;
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  int count = 0;
+  for (int base = 0; base < n_c; base += kWave) {
+    const int j = base + lane;
+    const int kk = j < n_c ? a.idx[j] : -1;
+    const bool act = kk >= 0 && a.st[kk].active != 0;
+    const unsigned long long mask = __ballot(act);
+    const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (act) {
+      const double x[2] = {a.st[kk].q.x[0], a.st[kk].q.x[1]};
+      a.idx[pos] = kk;
+      refine_emit(x, a.prm.del_alpha, pos, min(max(a.pt_surf[kk], 0), a.prm.n_surf - 1), a.line_surf, a.line_alpha, a.th0);
+    }
+    count += __popcll(mask);
+  }
+  if (lane == 0) {
+    const int r = a.ctrl->round + 1;
+    a.ctrl->round = r; a.ctrl->n_c = count; a.ctrl->n_lines = 3 * count;
+    __hip_atomic_store(&a.ctrl->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r < a.hist_len) __hip_atomic_store(&a.hist[r], count + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---------------------------------------------------------------- Sturm count at given shifts
 // The bandwidth kernel of the path ("batched Sturm/tridiag sweep"): one forward sweep per system, no
 // scaling set-up, no divisions.  Works on the un-normalised three-term recurrence
@@ -1016,6 +1146,16 @@ static hipError_t launch_grad(const GradArgs<T>& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <typename T>
+static hipError_t launch_refine_eval(const RefineEvalArgs<T>& a, hipStream_t st) {
+  const size_t lds = (size_t)(a.lds_tangent ? 11 : 8) * lds_pitch(a.N) * sizeof(T) + 4 * sizeof(T) + sizeof(RefineState);
+  auto kern = k_refine_eval<T, IBS_M>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(a.n_c_max), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 #define IBS_CAT2(a, b) a##b
 #define IBS_CAT(a, b) IBS_CAT2(a, b)
 struct IBS_CAT(Registrar, IBS_M) {
@@ -1032,6 +1172,7 @@ struct IBS_CAT(Registrar, IBS_M) {
     t.scan_chain_f64[IBS_M] = &launch_scan_chain<double>;
     t.sturm_f64[IBS_M] = &launch_sturm<double>;
     t.grad_f64[IBS_M] = &launch_grad<double>;
+    t.refine_f64[IBS_M] = &launch_refine_eval<double>;
 #ifdef IBS_WITH_F32
     t.gcf_f32[IBS_M] = &launch_gcf<float>;
 #endif

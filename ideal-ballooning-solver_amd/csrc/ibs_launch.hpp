@@ -40,6 +40,7 @@ struct GradArgs {
 };
 
 // field-line geometry kernel (ibs_geometry.hip)
+struct GeoForm { int ppl, lpp; };   // grid points per lane, lanes per grid point (one of them is 1)
 struct GeoArgs {
   int n_surf, mnmax, mnmax_nyq, n_lines, N;
   const double *xm, *xn, *xm_nyq, *xn_nyq;
@@ -59,9 +60,22 @@ struct GeoArgs {
   double dn_mn, dn_nyq;    // common n-spacing inside the rows of each set (rows with another spacing are split by the host)
   int lpp;                 // lanes per grid point: 0 = chosen from the batch size, else 1 | 2 | 4 | 8; -2 = two grid points per lane
   int j_begin, j_end;      // (set by launch_geometry) grid points [j_begin, j_end) of every line are this launch's
+  // round 3: the row kernels work from per-surface table images prepared once per call (k_geo_prepare), one image set
+  // per lanes-per-point value (index geo_lpp_index: 1, 2, 4, 8); img_ready = bit per set already built from these tables
+  GeoForm form;            // {0, 0} = picked by launch_geometry from the batch size
+  double* img[4];
+  unsigned img_ready;
+  const int* n_lines_dev;  // optional: the number of lines actually requested, read on the device (<= n_lines, which then
+                           // only sizes the grid): the refinement rounds of ibs_refine_f64 shrink without a host round trip
+  size_t plane;            // distance between the 8 output planes in elements; 0 = n_lines * ld
 };
-hipError_t launch_geometry(const GeoArgs& a, hipStream_t st);
+GeoForm geo_pick_form(long n_lines, int N, int n_cu, int lpp_opt);
+int geo_lpp_index(int lpp);
+size_t geo_image_doubles(const GeoArgs& a, int lpp);      // per surface
+bool geo_rows_usable(const GeoArgs& a, int lpp);
+hipError_t launch_geometry(GeoArgs& a, hipStream_t st, int n_cu);
 
+template <typename T> struct RefineEvalArgs;
 struct LaunchTable {
   hipError_t (*gcf_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
   hipError_t (*gcf_rows_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);   // row-streamed form (k_solve_gcf_rows)
@@ -70,6 +84,7 @@ struct LaunchTable {
   hipError_t (*scan_chain_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
   hipError_t (*sturm_f64[kMaxM + 1])(const SturmArgs<double>&, hipStream_t);
   hipError_t (*grad_f64[kMaxM + 1])(const GradArgs<double>&, hipStream_t);
+  hipError_t (*refine_f64[kMaxM + 1])(const RefineEvalArgs<double>&, hipStream_t);   // one round of ibs_refine_f64 (ibs_refine.hpp)
   // sub-wave variants (ibs_group.hpp): index 0 -> 32 lanes per system, 1 -> 16 lanes per system
   hipError_t (*gcf_f64_g[2][kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
   hipError_t (*scan_f64_g[2][kMaxM + 1])(const ScanArgs<double>&, hipStream_t);

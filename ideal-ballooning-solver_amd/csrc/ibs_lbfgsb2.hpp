@@ -22,7 +22,7 @@
 #pragma once
 #include <cmath>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define IBS_HD __host__ __device__ inline
 #else
 #define IBS_HD inline

@@ -330,6 +330,12 @@ class Context:
                                                 p(d_th), *tail, p(xo), p(fo), p(ne), MEM_DEVICE), "ibs_refine_f64")
         return xo.cpu().numpy(), fo.cpu().numpy(), ne.cpu().numpy(), rounds
 
+    def refine_stats(self):
+        """(evaluations, forward sweeps, rounds needed, rounds enqueued) of the last refine() call of this context"""
+        out = np.zeros(4, dtype=np.int64)
+        check(self._lib.ibs_refine_stats(self._h, C.c_void_p(out.ctypes.data)), "ibs_refine_stats")
+        return tuple(int(v) for v in out)
+
     def hf_grad(self, X, dX, f, g_p, c_p, f_p, gam):
         """Hellmann-Feynman d(gam)/dp for caller-built tangents (utils.py:1676-1680, 1721-1725).
         X, dX, f, g_p, c_p, f_p: (n_sys, N); gam: (n_sys,) -> jac (n_sys,)"""

@@ -200,11 +200,14 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
 
 /* Refinement of the per-surface maximum: maximise gam over (alpha, theta0) in
  * [0, pi] x [0, pi/2] from n_pts start points at once, entirely on the device.
- * Replaces: ball_scan.py:305-314 (scipy.optimize.minimize(obj_w_grad, x0, jac=True, bounds, ftol, gtol, maxiter);
- * L-BFGS-B there, a projected BFGS with Armijo backtracking here) together with the evaluations it drives
- * (utils.py:1632-1728 on the three field lines of utils.py:1641-1646, produced by the geometry kernel).
- * Every round is one launch each of the geometry kernel (3 n_pts lines), the fused objective/gradient kernel and a
- * one-thread-per-point state machine; the host only looks at the count of unfinished points every few rounds.
+ * Replaces: ball_scan.py:305-314 (scipy.optimize.minimize(obj_w_grad, x0, jac=True, bounds, ftol, gtol, maxiter), i.e.
+ * scipy's L-BFGS-B: restated for the two unknowns in csrc/ibs_lbfgsb2.hpp, one state machine per point) together with
+ * the evaluations it drives (utils.py:1632-1728 on the three field lines of utils.py:1641-1646, produced by the
+ * geometry kernel).  A round = the geometry kernel (3 lines per point still running) + one fused kernel per point
+ * (objective, Hellmann-Feynman gradient, optimizer step; the eigen-solve is warm-started from the point's previous
+ * evaluation; the block that finishes last re-packs the batch).  Nothing returns to the host between rounds: the device
+ * posts the count of unfinished points per round into pinned memory, and the host enqueues rounds two ahead of the last
+ * count it has seen (csrc/ibs_refine.hpp).
  *   surface tables, mode tables, row tables: as for ibs_fieldline_geometry_f64;  pt_surf[n_pts] surface of each point;
  *   start[n_pts][2] = (alpha, theta0);  theta[N] uniform theta_PEST grid;  del_alpha (utils.py:1639: 0.004);
  *   maxiter, ftol, gtol: ball_scan.py:312-313 (30, 5e-11, 2e-8).
@@ -216,6 +219,10 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
                    const int32_t* rows_nyq, double dn_mn, double dn_nyq, int32_t n_pts, const int32_t* pt_surf,
                    const double* start, int32_t N, const double* theta, double del_alpha, int32_t maxiter,
                    double ftol, double gtol, double* x_opt, double* f_opt, int32_t* n_evals, int32_t mem);
+
+/* Statistics of the last ibs_refine_f64 call of this context (diagnostic; no reference counterpart):
+ * out4 = {objective evaluations, forward sweeps of their eigen-solves, rounds needed, rounds enqueued}. */
+int ibs_refine_stats(ibs_ctx* ctx, int64_t* out4);
 
 /* Number of eigenvalues of (T, F) strictly above shift[i] for each system (Sturm sequence).
  * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0). */
