@@ -80,6 +80,7 @@ struct ibs_ctx {
   int* refine_hist = nullptr;
   int refine_hist_len = 0;
   long long refine_stats[4] = {0, 0, 0, 0};      // evaluations, forward sweeps, rounds, rounds enqueued
+  bool refine_pending = false;                   // the last call's output kernel may still be running (device-pointer call)
 };
 
 namespace {
@@ -306,9 +307,17 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
 using ibs::RefineState; using ibs::RefineParams; using ibs::RefineCtrl;
 
 __global__ void k_refine_init(int n, const int* pt_surf, const double* start, RefineState* st, RefineParams p,
-                              int* idx, int* line_surf, double* line_alpha, double* th0, RefineCtrl* ctrl) {
+                              int* idx, int* line_surf, double* line_alpha, double* th0, RefineCtrl* ctrl,
+                              int N, const double* theta, int* status) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k == 0) { ctrl->n_c = n; ctrl->n_lines = 3 * n; ctrl->done = 0; ctrl->round = 0; }
+  // the theta grid must be uniform (the batched kernels take h): checked here, on the device copy; the host sees *status
+  const double h = (theta[N - 1] - theta[0]) / (N - 1);
+  if (k == 0) {
+    ctrl->n_c = n; ctrl->n_lines = 3 * n; ctrl->done = 0; ctrl->round = 0; ctrl->h = h;
+    if (!(h > 0)) *status = 2;
+  }
+  for (int j = 1 + k; j < N; j += gridDim.x * blockDim.x)
+    if (fabs((theta[j] - theta[j - 1]) - h) > 1e-9 * fabs(h)) *status = 1;
   if (k >= n) return;
   RefineState& s = st[k];                     // (the state lives in global memory; nothing of it is kept in registers)
   const double x0[2] = {start[2 * k], start[2 * k + 1]};
@@ -322,9 +331,10 @@ __global__ void k_refine_init(int n, const int* pt_surf, const double* start, Re
 __global__ void k_refine_out(int n, const RefineState* st, double* x_opt, double* f_opt, int* n_evals, long long* stats) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  x_opt[2 * k] = st[k].q.x[0]; x_opt[2 * k + 1] = st[k].q.x[1]; f_opt[k] = st[k].q.f; n_evals[k] = st[k].nev;
-  atomicAdd(reinterpret_cast<unsigned long long*>(stats), (unsigned long long)st[k].nev);
-  atomicAdd(reinterpret_cast<unsigned long long*>(stats + 1), (unsigned long long)st[k].sweeps);
+  x_opt[2 * k] = st[k].q.x[0]; x_opt[2 * k + 1] = st[k].q.x[1]; f_opt[k] = st[k].q.f;
+  if (n_evals) n_evals[k] = st[k].nev;
+  atomicAdd_system(reinterpret_cast<unsigned long long*>(stats), (unsigned long long)st[k].nev);         // (pinned host memory)
+  atomicAdd_system(reinterpret_cast<unsigned long long*>(stats + 1), (unsigned long long)st[k].sweeps);
 }
 }  // namespace
 
@@ -1045,18 +1055,16 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   if (n_pts == 0) return 0;
   ON_DEVICE(ctx);
   const bool host = (mem == IBS_MEM_HOST);
-  // theta must be uniform; h from its ends (checked on the host copy)
-  std::vector<double> th_h(N > 0 ? N : 0);
   if (N < 2) return fail(IBS_ERR_ARG, "N=%d", N);
-  HIPCHK(hipMemcpyAsync(th_h.data(), theta, (size_t)N * 8, hipMemcpyDefault, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  const double h = (th_h[N - 1] - th_h[0]) / (N - 1);
-  if (int r = check_grid(N, h)) return r;
-  for (int j = 1; j < N; ++j)
-    if (fabs((th_h[j] - th_h[j - 1]) - h) > 1e-9 * fabs(h)) return fail(IBS_ERR_UNSUPPORTED, "theta grid is not uniform");
-  if (host)
+  if (int r = check_grid(N, 1.0)) return r;
+  if (host) {                                 // (device-resident grids are checked by k_refine_init)
+    const double h = (theta[N - 1] - theta[0]) / (N - 1);
+    if (!(h > 0)) return fail(IBS_ERR_ARG, "h must be > 0");
+    for (int j = 1; j < N; ++j)
+      if (fabs((theta[j] - theta[j - 1]) - h) > 1e-9 * fabs(h)) return fail(IBS_ERR_UNSUPPORTED, "theta grid is not uniform");
     for (int i = 0; i < n_pts; ++i)
       if (pt_surf[i] < 0 || pt_surf[i] >= n_surf) return fail(IBS_ERR_ARG, "pt_surf[%d]=%d out of range", i, pt_surf[i]);
+  }
   const int M = rows_per_lane(N);
   auto eval = ibs::launch_table().refine_f64[M];
   if (!eval) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
@@ -1068,14 +1076,21 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   // every round = one objective/gradient evaluation of every point still in the batch.  An iteration takes at most
   // maxls = 20 line-search evaluations, and once more after a memory restart
   const int max_rounds = 2 + 42 * (maxiter > 0 ? maxiter : 1);
-  if (ctx->refine_hist_len < max_rounds + 2) {
-    if (ctx->refine_hist) { HIPCHK(hipHostFree(ctx->refine_hist)); ctx->refine_hist = nullptr; ctx->refine_hist_len = 0; }
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->refine_hist), (size_t)(max_rounds + 2) * sizeof(int), hipHostMallocDefault));
-    ctx->refine_hist_len = max_rounds + 2;
+  const int hist_len = (max_rounds + 2 + 1) & ~1;      // then: two 64-bit statistics words, one status word
+  if (ctx->refine_hist_len < hist_len) {
+    if (ctx->refine_hist) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipHostFree(ctx->refine_hist)); ctx->refine_hist = nullptr; ctx->refine_hist_len = 0; }
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->refine_hist), (size_t)(hist_len + 8) * sizeof(int), hipHostMallocDefault));
+    ctx->refine_hist_len = hist_len;
+  } else if (ctx->refine_pending) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));           // (the output kernel of the previous call posts its statistics here)
   }
+  ctx->refine_pending = false;
   volatile int* hist = ctx->refine_hist;
+  long long* h_stats = reinterpret_cast<long long*>(ctx->refine_hist + ctx->refine_hist_len);
+  volatile int* h_status = ctx->refine_hist + ctx->refine_hist_len + 4;
   for (int r = 0; r < max_rounds + 2; ++r) hist[r] = 0;
   hist[0] = n_pts + 1;
+  h_stats[0] = 0; h_stats[1] = 0; *h_status = 0;
   const long ld = N;
   const int n_lines = 3 * n_pts;
   const size_t n_mn = (size_t)n_surf * 6 * mnmax, n_nyq = (size_t)n_surf * 7 * mnmax_nyq, n_geo = (size_t)8 * n_lines * ld;
@@ -1112,18 +1127,20 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
     ga.xm = xm; ga.xn = xn; ga.xm_nyq = xm_nyq; ga.xn_nyq = xn_nyq; ga.tab_mn = tab_mn; ga.tab_nyq = tab_nyq; ga.scal = scal;
     if (ga.nrows_mn) { ga.rows_mn = rows_mn; ga.rows_nyq = rows_nyq; }
   }
-  double* d_th = ar.take<double>(N);
-  HIPCHK(up(theta, (size_t)N * 8, d_th));
-  int* d_ps = ar.take<int>(n_pts); double* d_start = ar.take<double>((size_t)2 * n_pts);
-  HIPCHK(up(pt_surf, (size_t)n_pts * 4, d_ps)); HIPCHK(up(start, (size_t)n_pts * 16, d_start));
+  const double* d_th = theta; const int* d_ps = pt_surf; const double* d_start = start;   // (device pointers are used in place)
+  if (host) {
+    double* t_ = ar.take<double>(N); int* p_ = ar.take<int>(n_pts); double* s_ = ar.take<double>((size_t)2 * n_pts);
+    HIPCHK(up(theta, (size_t)N * 8, t_)); HIPCHK(up(pt_surf, (size_t)n_pts * 4, p_)); HIPCHK(up(start, (size_t)n_pts * 16, s_));
+    d_th = t_; d_ps = p_; d_start = s_;
+  }
   double* d_geo = ar.take<double>(n_geo);
   int* d_ls = ar.take<int>(n_lines); double* d_la = ar.take<double>(n_lines); double* d_t0 = ar.take<double>(n_pts); int* d_idx = ar.take<int>(n_pts);
   RefineState* d_st = ar.take<RefineState>(n_pts);
   double* d_gam = ar.take<double>(n_pts); double* d_da = ar.take<double>(n_pts); double* d_dt = ar.take<double>(n_pts);
   int* d_info = ar.take<int>(n_pts);
   RefineCtrl* d_ctrl = ar.take<RefineCtrl>(1);
-  long long* d_stats = ar.take<long long>(2);
-  double* d_xo = ar.take<double>((size_t)2 * n_pts); double* d_fo = ar.take<double>(n_pts); int* d_ne = ar.take<int>(n_pts);
+  double* d_xo = x_opt; double* d_fo = f_opt; int* d_ne = n_evals;                          // (device pointers: written in place)
+  if (host) { d_xo = ar.take<double>((size_t)2 * n_pts); d_fo = ar.take<double>(n_pts); d_ne = ar.take<int>(n_pts); }
   for (int lpp = lpp_first; lpp <= lpp_last; lpp *= 2)
     if (geo_img_bytes(ga, lpp)) ga.img[ibs::geo_lpp_index(lpp)] = ar.take<double>(geo_img_bytes(ga, lpp) / sizeof(double));
   ga.theta = d_th; ga.geo = d_geo; ga.dPdrho = nullptr;
@@ -1135,15 +1152,16 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   prm.lo[0] = 0.0; prm.lo[1] = 0.0; prm.hi[0] = 3.141592653589793; prm.hi[1] = 1.5707963267948966;   // ball_scan.py:311
   prm.del_alpha = del_alpha; prm.ftol = ftol; prm.gtol = gtol; prm.maxiter = maxiter; prm.n_surf = n_surf;
   ibs::RefineEvalArgs<double> ea{};
-  ea.N = N; ea.h = h; ea.geo = d_geo; ea.ld = ld; ea.plane = ga.plane;
+  ea.N = N; ea.geo = d_geo; ea.ld = ld; ea.plane = ga.plane;
   ea.st = d_st; ea.prm = prm; ea.ctrl = d_ctrl; ea.idx = d_idx; ea.pt_surf = d_ps;
   ea.line_surf = d_ls; ea.line_alpha = d_la; ea.th0 = d_t0;
   ea.gam = d_gam; ea.dalpha = d_da; ea.dth0 = d_dt; ea.info = d_info;
-  ea.hist = ctx->refine_hist; ea.hist_len = ctx->refine_hist_len; ea.lds_tangent = lds_tangent;
+  ea.hist = ctx->refine_hist; ea.hist_len = max_rounds + 2; ea.lds_tangent = lds_tangent;
 
   const dim3 grd((unsigned)((n_pts + 127) / 128)), blk(128);
-  HIPCHK(hipMemsetAsync(d_stats, 0, 2 * sizeof(long long), st));
-  hipLaunchKernelGGL(k_refine_init, grd, blk, 0, st, n_pts, d_ps, d_start, d_st, prm, d_idx, d_ls, d_la, d_t0, d_ctrl);
+  const dim3 gri((unsigned)((n_pts > N ? n_pts : N) + 127) / 128);
+  hipLaunchKernelGGL(k_refine_init, gri, blk, 0, st, n_pts, d_ps, d_start, d_st, prm, d_idx, d_ls, d_la, d_t0, d_ctrl, N, d_th,
+                     ctx->refine_hist + ctx->refine_hist_len + 4);
   HIPCHK(hipGetLastError());
   // Rounds are enqueued kLook ahead of the last one whose count the device has posted: the grid sizes and the geometry
   // form of round r are functions of the count after round r - 1 - kLook -- of the trajectory, not of host timing, so the
@@ -1173,12 +1191,20 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
     HIPCHK(eval(ea, st));
     ++enq;
   }
-  hipLaunchKernelGGL(k_refine_out, grd, blk, 0, st, n_pts, d_st, d_xo, d_fo, d_ne, d_stats);
+  hipLaunchKernelGGL(k_refine_out, grd, blk, 0, st, n_pts, d_st, d_xo, d_fo, d_ne, h_stats);
   HIPCHK(hipGetLastError());
-  HIPCHK(up(d_xo, (size_t)n_pts * 16, x_opt)); HIPCHK(up(d_fo, (size_t)n_pts * 8, f_opt));
-  if (n_evals) HIPCHK(up(d_ne, (size_t)n_pts * 4, n_evals));
-  HIPCHK(up(d_stats, 2 * sizeof(long long), ctx->refine_stats));
-  HIPCHK(hipStreamSynchronize(st));
+  ctx->refine_pending = true;
+  if (host) {
+    HIPCHK(up(d_xo, (size_t)n_pts * 16, x_opt)); HIPCHK(up(d_fo, (size_t)n_pts * 8, f_opt));
+    if (n_evals) HIPCHK(up(d_ne, (size_t)n_pts * 4, n_evals));
+  }
+  // device pointers: the results are complete once the stream reaches this point (the rounds themselves are known to be
+  // over -- their counts were read above -- unless the loop ended on the round limit)
+  if (host || rounds < 0) { HIPCHK(hipStreamSynchronize(st)); ctx->refine_pending = false; }
+  if (*h_status != 0) {
+    HIPCHK(hipStreamSynchronize(st)); ctx->refine_pending = false;
+    return *h_status == 1 ? fail(IBS_ERR_UNSUPPORTED, "theta grid is not uniform") : fail(IBS_ERR_ARG, "h must be > 0");
+  }
   if (rounds < 0) {                       // (the loop ended on max_rounds, or the last rounds' counts were not looked at yet)
     rounds = enq;
     for (int r = 0; r <= enq; ++r) if (hist[r] == 1) { rounds = r; break; }
@@ -1190,6 +1216,11 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
 /* statistics of the last ibs_refine_f64 call of this context: evaluations, forward sweeps of the eigen-solves, rounds needed, rounds enqueued */
 int ibs_refine_stats(ibs_ctx* ctx, int64_t* out4) {
   if (!ctx || !out4) return fail(IBS_ERR_ARG, "null pointer");
+  if (ctx->refine_pending) { ON_DEVICE(ctx); HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->refine_pending = false; }
+  if (ctx->refine_hist) {
+    const long long* h_stats = reinterpret_cast<const long long*>(ctx->refine_hist + ctx->refine_hist_len);
+    ctx->refine_stats[0] = h_stats[0]; ctx->refine_stats[1] = h_stats[1];
+  }
   for (int i = 0; i < 4; ++i) out4[i] = ctx->refine_stats[i];
   return 0;
 }

@@ -671,59 +671,51 @@ __device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, cons
   GEO_PROBE_AT(7);
 }
 
-// Persistent blocks: block b owns the wave-items [b W / B, (b + 1) W / B), W = n_lines * items_per_line (line-major), and
-// takes them eight at a time, one per wave.  The table image of a surface is copied into LDS when an item needs a surface
-// other than the staged one (lines usually come sorted by surface: once per surface and block).
+// Persistent blocks.  A UNIT is eight consecutive wave-items of ONE line (one per wave of the block), so a unit never
+// straddles two surfaces; block b owns the units [b U / B, (b + 1) U / B), U = n_lines * units_per_line (line-major).  The
+// table image of a surface is copied into LDS when a unit needs a surface other than the staged one (lines usually come
+// sorted by surface: once per surface and block) -- the only block barriers of the kernel: between re-stagings the waves
+// run through their items independently, so a SIMD always has both of its waves to pick instructions from (with a
+// barrier per unit the older wave of each SIMD, which the issue arbiter favours, finished its item ~30 % earlier and
+// left the younger one alone at half the issue rate).
 template <int PPL, int LPP, int MAXR>
 __global__ void __launch_bounds__(kGeoBlock) k_geo_rows(GeoArgs a, const double* __restrict__ img) {
   extern __shared__ __align__(16) unsigned char geo_smem[];
-  __shared__ int s_req;
   double* I = reinterpret_cast<double*>(geo_smem);
   const GeoImgLayout L = geo_layout(a.mnmax, a.nrows_mn, a.mnmax_nyq, a.nrows_nyq, LPP);
   const int n_lines = a.n_lines_dev ? min(*a.n_lines_dev, a.n_lines) : a.n_lines;
   constexpr int PTS = 64 * PPL / LPP;
-  const int ipl = (a.j_end + PTS - 1) / PTS;
-  const long W = (long)n_lines * ipl;
-  const long w_begin = W * blockIdx.x / gridDim.x, w_end = W * (blockIdx.x + 1) / gridDim.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int WPB = kGeoBlock / 64;
+  const int ipl = (a.j_end + PTS - 1) / PTS;             // wave-items per line
+  const int upl = (ipl + WPB - 1) / WPB;                 // units per line
+  const long U = (long)n_lines * upl;
+  const long u_begin = U * blockIdx.x / gridDim.x, u_end = U * (blockIdx.x + 1) / gridDim.x;
+  const int wave = threadIdx.x >> 6;
   int cur = -1;
   GEO_PROBE_AT(0);
-  for (long base = w_begin; base < w_end; base += WPB) {
-    const long item = base + wave;
-    const bool has = item < w_end;
-    const int line = has ? (int)(item / ipl) : 0;
-    const int chunk = has ? (int)(item - (long)line * ipl) : 0;
-    const int js = has ? min(max(a.line_surf[line], 0), a.n_surf - 1) : -1;   // (device-resident indices are not range-checked by the C ABI)
-    bool pending = has;
-    while (true) {
-      __syncthreads();                                   // the staged image and s_req of the last pass are no longer in use
-      if (threadIdx.x == 0) s_req = -1;
-      __syncthreads();
-      if (pending && lane == 0) atomicMax(&s_req, js);
-      __syncthreads();
-      const int req = s_req;
-      if (req < 0) break;                                // (block-uniform)
-      if (req != cur) {
-        // straight copy of the prepared image, four 16-byte loads in flight per thread
-        const double2* src = reinterpret_cast<const double2*>(img + (size_t)req * L.total);
-        double2* dst = reinterpret_cast<double2*>(I);
-        const int n2 = L.total >> 1;                     // (L.total is even)
-        for (int k = threadIdx.x; k < n2; k += 4 * kGeoBlock) {
-          double2 v[4];
+  for (long u = u_begin; u < u_end; ++u) {
+    const int line = (int)(u / upl);
+    const int item = (int)(u - (long)line * upl) * WPB + wave;
+    const int js = min(max(__builtin_amdgcn_readfirstlane(a.line_surf[line]), 0), a.n_surf - 1);   // (device-resident indices are not range-checked by the C ABI)
+    if (js != cur) {                                     // (block-uniform)
+      __syncthreads();                                   // every wave is done with the staged image
+      // straight copy of the prepared image, four 16-byte loads in flight per thread
+      const double2* src = reinterpret_cast<const double2*>(img + (size_t)js * L.total);
+      double2* dst = reinterpret_cast<double2*>(I);
+      const int n2 = L.total >> 1;                       // (L.total is even)
+      for (int k = threadIdx.x; k < n2; k += 4 * kGeoBlock) {
+        double2 v[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int kk = k + u * kGeoBlock; v[u] = kk < n2 ? src[kk] : double2{0.0, 0.0}; }
+        for (int q = 0; q < 4; ++q) { const int kk = k + q * kGeoBlock; v[q] = kk < n2 ? src[kk] : double2{0.0, 0.0}; }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int kk = k + u * kGeoBlock; if (kk < n2) dst[kk] = v[u]; }
-        }
-        cur = req;
-        __syncthreads();
+        for (int q = 0; q < 4; ++q) { const int kk = k + q * kGeoBlock; if (kk < n2) dst[kk] = v[q]; }
       }
-      if (pending && js == cur) {
-        GEO_PROBE_AT(1);
-        geo_item<PPL, LPP, MAXR>(a, I, L, line, chunk * PTS);
-        pending = false;
-      }
+      cur = js;
+      __syncthreads();
+    }
+    if (item < ipl) {
+      GEO_PROBE_AT(1);
+      geo_item<PPL, LPP, MAXR>(a, I, L, line, item * PTS);
     }
   }
 }
@@ -860,8 +852,8 @@ hipError_t launch_geometry(GeoArgs& a, hipStream_t st, int n_cu) {
     // kernel instead of a wave-item of their own
     b.j_begin = 0;
     b.j_end = (f.lpp == 1 && rem > 0 && rem <= 16 && a.N > pts) ? a.N - rem : a.N;
-    const long items = (long)a.n_lines * ((b.j_end + pts - 1) / pts);
-    long nblk = (items + 7) / 8;
+    const long units = (long)a.n_lines * (((b.j_end + pts - 1) / pts + 7) / 8);     // eight wave-items of one line each
+    long nblk = units;
     if (nblk > n_cu) nblk = n_cu;
     if (nblk < 1) nblk = 1;
     auto go = [&](auto kern) {
@@ -899,6 +891,10 @@ hipError_t launch_geometry(GeoArgs& a, hipStream_t st, int n_cu) {
 }  // namespace ibs
 
 #ifdef GEO_PROBE
+extern "C" int ibs_geo_probe_clear() {
+  static long long zeros[256 * 16];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(ibs::geo_probe_buf), zeros, sizeof(zeros));
+}
 extern "C" int ibs_geo_probe_read(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ibs::geo_probe_buf), sizeof(long long) * 256 * 16);
 }

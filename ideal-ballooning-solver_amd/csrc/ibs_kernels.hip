@@ -806,6 +806,7 @@ __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
   const int n_c = a.ctrl->n_c;
   const int slot = blockIdx.x;
   if (slot >= n_c) return;                                 // (block-uniform: the grid was sized for an earlier, larger batch)
+  const T h = a.ctrl->h;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int N = a.N;
   const int P = lds_pitch(N);
@@ -847,7 +848,7 @@ __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
   SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
-  const bool bad = ws.setup(src, N, a.h);
+  const bool bad = ws.setup(src, N, h);
   // warm start: lam of the point's previous evaluation moved along the Hellmann-Feynman gradient found there; the bracket
   // still moves on counts only, so a poor guess costs sweeps, never correctness
   const T xe0 = S.q.x[0], xe1 = S.q.x[1];
@@ -866,10 +867,10 @@ __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
   }
   if (a.lds_tangent) {
     const AlphaTangentLds<T> tl{Tg, Tc, Tf};
-    finish<T, M, SrcGeo<T>, true, AlphaTangentLds<T>>(ws, src, N, a.h, Xs, lam, inf, slot, nullptr, a.gam, nullptr, nullptr,
+    finish<T, M, SrcGeo<T>, true, AlphaTangentLds<T>>(ws, src, N, h, Xs, lam, inf, slot, nullptr, a.gam, nullptr, nullptr,
                                                       a.dth0, a.info, &tl, a.dalpha);
   } else {
-    finish<T, M, SrcGeo<T>, true, AlphaTangent<T>>(ws, src, N, a.h, Xs, lam, inf, slot, nullptr, a.gam, nullptr, nullptr,
+    finish<T, M, SrcGeo<T>, true, AlphaTangent<T>>(ws, src, N, h, Xs, lam, inf, slot, nullptr, a.gam, nullptr, nullptr,
                                                    a.dth0, a.info, &tang, a.dalpha);
   }
   if (lane == 0) {                                         // lane 0 wrote the three scratch values itself

@@ -31,11 +31,12 @@ struct RefineCtrl {
   int n_lines;    // = 3 n_c: what the geometry kernel reads
   int done;       // blocks of the current round that have finished (reset by the last one)
   int round;      // rounds completed
+  double h;       // grid spacing of the (uniform) theta grid, formed on the device by k_refine_init
 };
 
 template <typename T>
 struct RefineEvalArgs {
-  int n_c_max, N; T h;
+  int n_c_max, N;
   const T* geo; long ld; size_t plane;     // [8][lines][ld] planes of the geometry kernel, `plane` elements apart
   RefineState* st; RefineParams prm; RefineCtrl* ctrl;
   int* idx; const int* pt_surf;            // slot -> point, point -> surface

@@ -319,16 +319,25 @@ class Context:
             return xo, fo, ne, rounds
         import torch
         dev = self._device_tables(tables, device)
-        d_ps, d_st, d_th = (torch.from_numpy(a).to(device) for a in (ps, st, th))
-        xo = torch.empty((n, 2), dtype=torch.float64, device=device)
-        fo = torch.empty((n,), dtype=torch.float64, device=device)
-        ne = torch.zeros((n,), dtype=torch.int32, device=device)
-        self._stream_from_torch(xo)
+        # the grid and the point -> surface map rarely change between calls: their device copies are kept on the tables
+        # object, keyed by content; the start points go up in one copy, the results come back in one
+        cache = tables.__dict__.setdefault("_refine_inputs", {})
+        key = (str(device), th.tobytes(), ps.tobytes())
+        if key not in cache:
+            cache.clear()
+            cache[key] = (torch.from_numpy(ps).to(device), torch.from_numpy(th).to(device))
+        d_ps, d_th = cache[key]
+        d_st = torch.from_numpy(st).to(device)
+        out = torch.empty((4 * n,), dtype=torch.float64, device=device)     # x_opt (2n) | f_opt (n) | n_evals (n int32 in n/2.. words)
+        xo, fo = out[:2 * n].view(n, 2), out[2 * n:3 * n]
+        ne = out[3 * n:].view(torch.int32)[:n]
+        self._stream_from_torch(out)
         p = lambda t: C.c_void_p(t.data_ptr())
         rounds = check(self._lib.ibs_refine_f64(*head, *[p(t) for t in dev[:7]], nr[0], p(dev[7]), nr[1], p(dev[8]),
                                                 float(tables.dn_mn), float(tables.dn_nyq), n, p(d_ps), p(d_st), len(th),
                                                 p(d_th), *tail, p(xo), p(fo), p(ne), MEM_DEVICE), "ibs_refine_f64")
-        return xo.cpu().numpy(), fo.cpu().numpy(), ne.cpu().numpy(), rounds
+        h = out.cpu()
+        return (h[:2 * n].view(n, 2).numpy(), h[2 * n:3 * n].numpy(), h[3 * n:].view(torch.int32)[:n].numpy().copy(), rounds)
 
     def refine_stats(self):
         """(evaluations, forward sweeps, rounds needed, rounds enqueued) of the last refine() call of this context"""

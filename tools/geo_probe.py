@@ -20,9 +20,16 @@ for ns, na, N, lpp in ((5, 3, 969, 8), (5, 3, 969, 4), (73, 3, 969, 1), (64, 32,
         r = ctx.fieldline_geometry(tabs, surf, al, th, device=dev)
     torch.cuda.synchronize()
     buf = np.zeros((256, 16), dtype=np.int64)
+    _lib.lib().ibs_geo_probe_clear()
+    r = ctx.fieldline_geometry(tabs, surf, al, th, device=dev); torch.cuda.synchronize()
     rc = _lib.lib().ibs_geo_probe_read(C.c_void_p(buf.ctypes.data))
     d = np.diff(buf[:64, :8], axis=1) * 10.0 / 1e3        # us (100 MHz clock); last item of wave 0 of each block
     print("%d lines x %d, geo_lpp=%d: per-phase us (median over blocks | max):" % (ns * na, N, lpp))
     for k, nm in enumerate(names):
         print("   %-16s %7.2f | %7.2f" % (nm, np.median(d[:, k]), d[:, k].max()))
+    nb = min(256, (ns * na * ((N + (8 if lpp == 8 else 64)) - 1) // 64 // 8) if lpp == 8 else 256)
+    st = (buf[:, 0] - buf[buf[:, 0] > 0, 0].min()) * 0.01; en = (buf[:, 7] - buf[buf[:, 0] > 0, 0].min()) * 0.01
+    ok = buf[:, 0] > 0
+    print("   blocks probed %d: block start skew us min/median/max %.2f %.2f %.2f ; block end min/median/max %.2f %.2f %.2f" % (
+        ok.sum(), st[ok].min(), np.median(st[ok]), st[ok].max(), en[ok].min(), np.median(en[ok]), en[ok].max()))
     print("   total item       %7.2f ; block span (start -> end of last item) median %.2f" % (np.median(d[:, 1:].sum(axis=1)), np.median((buf[:64, 7] - buf[:64, 0]) * 0.01)))

@@ -44,3 +44,4 @@ if which in ("big", "both"):
         tabs_all.append(ibs_amd.SurfaceTables.from_wout(w, svals))
     big = ibs_amd.SurfaceTables.concat(tabs_all) if hasattr(ibs_amd.SurfaceTables, "concat") else None
     run("config-4 shape", ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), nalpha=na, ntheta0=nt0, tables=big, device=dev))
+print("refine stats of the last call (evaluations, sweeps, rounds, rounds enqueued):", ctx.refine_stats())
