@@ -1068,10 +1068,10 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   const int M = rows_per_lane(N);
   auto eval = ibs::launch_table().refine_f64[M];
   if (!eval) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
-  // LDS of the evaluation kernel: centre line (7 derived arrays) + eigenfunction + alpha-tangent (3 arrays) when they fit
+  // LDS of the evaluation kernel: centre line (7 derived arrays) + eigenfunction + alpha-tangent (4 arrays) when they fit
   const size_t row_b = (size_t)ibs::lds_pitch(N) * sizeof(double);
-  const size_t lds_extra = 4 * sizeof(double) + sizeof(RefineState);
-  const int lds_tangent = (11 * row_b + lds_extra <= (size_t)ctx->lds_per_block) ? 1 : 0;
+  const size_t lds_extra = 32 * sizeof(double) + sizeof(RefineState);
+  const int lds_tangent = (12 * row_b + lds_extra <= (size_t)ctx->lds_per_block) ? 1 : 0;
   if (8 * row_b + lds_extra > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
   // every round = one objective/gradient evaluation of every point still in the batch.  An iteration takes at most
   // maxls = 20 line-search evaluations, and once more after a memory restart
@@ -1167,7 +1167,7 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   // form of round r are functions of the count after round r - 1 - kLook -- of the trajectory, not of host timing, so the
   // arithmetic (summation order of the geometry kernel's forms) is reproducible -- and the GPU never waits for the host.
   // Rounds enqueued after the last point has finished find an empty batch and return at once.
-  constexpr int kLook = 2;
+  constexpr int kLook = 1;
   int enq = 0, rounds = -1;
   const auto t_start = std::chrono::steady_clock::now();
   while (enq < max_rounds) {

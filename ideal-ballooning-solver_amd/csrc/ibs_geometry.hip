@@ -196,18 +196,19 @@ size_t geo_image_doubles(const GeoArgs& a, int lpp) {
 //             computed cos / sin(n phi), 2 = compute them.
 __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double* img) {
   __shared__ int goff1[kGeoMaxRows + 1], goff2[kGeoMaxRows + 1], cnt1[kGeoMaxRows], cnt2[kGeoMaxRows];
+  __shared__ double rm_s[2][kGeoMaxRows], rn_s[2][kGeoMaxRows];
   const int js = blockIdx.x, t = threadIdx.x;
   const int nr1 = a.nrows_mn, nr2 = a.nrows_nyq;
   const GeoImgLayout L = geo_layout(a.mnmax, nr1, a.mnmax_nyq, nr2, lpp);
   double* I = img + (size_t)js * L.total;
-  for (int r = t; r < nr1; r += blockDim.x) cnt1[r] = a.rows_mn[2 * r + 1];
-  for (int r = t; r < nr2; r += blockDim.x) cnt2[r] = a.rows_nyq[2 * r + 1];
+  // (the row tables come in with one load per thread; the serial passes below run on the LDS copies)
+  for (int r = t; r < nr1; r += blockDim.x) { cnt1[r] = a.rows_mn[2 * r + 1]; const int k0 = a.rows_mn[2 * r]; rm_s[0][r] = a.xm[k0]; rn_s[0][r] = a.xn[k0]; }
+  for (int r = t; r < nr2; r += blockDim.x) { cnt2[r] = a.rows_nyq[2 * r + 1]; const int k0 = a.rows_nyq[2 * r]; rm_s[1][r] = a.xm_nyq[k0]; rn_s[1][r] = a.xn_nyq[k0]; }
   __syncthreads();
   int* ints = reinterpret_cast<int*>(I + L.o_int);
   int* igoff1 = ints; int* igoff2 = igoff1 + nr1 + 1; int* code1 = igoff2 + nr2 + 1; int* code2 = code1 + nr1;
   if (t < 2) {                                     // groups per lane and row, running offsets (totals made even), row codes
     int* goff = t ? goff2 : goff1; const int* cnt = t ? cnt2 : cnt1; const int nr = t ? nr2 : nr1;
-    const int* rows = t ? a.rows_nyq : a.rows_mn; const double* xm = t ? a.xm_nyq : a.xm; const double* xn = t ? a.xn_nyq : a.xn;
     const double dn = t ? a.dn_nyq : a.dn_mn;
     int* code = t ? code2 : code1; int* igoff = t ? igoff2 : igoff1; double* ri = I + (t ? L.o_ri2 : L.o_ri1);
     int o = 0;
@@ -217,8 +218,8 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
     double m_prev = 0.0, keep_n = 0.0, keep_adv = 0.0;
     bool keep = false;
     for (int r = 0; r < nr; ++r) {
-      const int k0 = rows[2 * r], gs = goff[r + 1] - goff[r];
-      const double m = xm[k0], n0 = xn[k0], adv = 2.0 * gs * dn;
+      const int gs = goff[r + 1] - goff[r];
+      const double m = rm_s[t][r], n0 = rn_s[t][r], adv = 2.0 * gs * dn;
       ri[4 * r] = m; ri[4 * r + 1] = n0; ri[4 * r + 2] = adv; ri[4 * r + 3] = gs;
       const int mc = (m == m_prev) ? 0 : ((m - m_prev == 1.0) ? 1 : 2);
       int nc;

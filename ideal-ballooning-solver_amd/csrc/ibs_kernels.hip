@@ -56,33 +56,35 @@ struct SrcGCFH {
   __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { const int q = lpos(j); g_ = gs[q]; c_ = cs[q]; f_ = fs[q]; }
 };
 
-template <typename T>
+template <typename T, bool SCALED = false>
 struct SrcGeo {
   static constexpr bool kHasGh = false;
   const T* A1; const T* A3; const T* C0; const T* C1; const T* G0; const T* G1; const T* G2;
   T th0, two_th0, th0sq;
+  T cs = T(1);       // SCALED: common factor of c (C0, C1 staged without -dPdrho: k_refine_eval)
   // (rows are padded: element j at lpos(j))
+  __device__ __forceinline__ T sc(T v) const { if constexpr (SCALED) return cs * v; else return v; }
   __device__ __forceinline__ T gd(int j) const { const int q = lpos(j); return G0[q] + two_th0 * G1[q] + th0sq * G2[q]; }
   __device__ __forceinline__ T g(int j) const { return A1[lpos(j)] * gd(j); }
-  __device__ __forceinline__ T c(int j) const { const int q = lpos(j); return C0[q] + th0 * C1[q]; }
+  __device__ __forceinline__ T c(int j) const { const int q = lpos(j); return sc(C0[q] + th0 * C1[q]); }
   __device__ __forceinline__ T f(int j) const { return A3[lpos(j)] * gd(j); }
   // d/dtheta0 tangents (utils.py:1669-1673)
   __device__ __forceinline__ T gdp(int j) const { const int q = lpos(j); return T(2) * G1[q] + two_th0 * G2[q]; }
   __device__ __forceinline__ T g_t(int j) const { return A1[lpos(j)] * gdp(j); }
-  __device__ __forceinline__ T c_t(int j) const { return C1[lpos(j)]; }
+  __device__ __forceinline__ T c_t(int j) const { return sc(C1[lpos(j)]); }
   __device__ __forceinline__ T f_t(int j) const { return A3[lpos(j)] * gdp(j); }
   // (g, c, f) and their theta0 tangents at one point with each LDS value read once
   __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const {
     const int q = lpos(j);
     const T d = G0[q] + two_th0 * G1[q] + th0sq * G2[q];
-    g_ = A1[q] * d; c_ = C0[q] + th0 * C1[q]; f_ = A3[q] * d;
+    g_ = A1[q] * d; c_ = sc(C0[q] + th0 * C1[q]); f_ = A3[q] * d;
   }
   __device__ __forceinline__ void gcf_with_tangent(int j, T& g_, T& c_, T& f_, T& gt, T& ct, T& ft) const {
     const int q = lpos(j);
     const T g1 = G1[q], g2 = G2[q], a1 = A1[q], a3 = A3[q], c1 = C1[q];
     const T d = G0[q] + two_th0 * g1 + th0sq * g2, dp = T(2) * g1 + two_th0 * g2;
-    g_ = a1 * d; c_ = C0[q] + th0 * c1; f_ = a3 * d;
-    gt = a1 * dp; ct = c1; ft = a3 * dp;
+    g_ = a1 * d; c_ = sc(C0[q] + th0 * c1); f_ = a3 * d;
+    gt = a1 * dp; ct = sc(c1); ft = a3 * dp;
   }
 };
 
@@ -788,16 +790,16 @@ __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const
 }
 
 // ---------------------------------------------------------------- one round of the device-resident maximiser (row F2)
-// alpha-tangent of (g, c, f) staged in LDS by the whole block (same values as AlphaTangent::at)
-template <typename T>
-struct AlphaTangentLds {
-  const T* Tg; const T* Tc; const T* Tf;
-  __device__ __forceinline__ void at(int j, T& ga, T& ca, T& fa) const { const int q = lpos(j); ga = Tg[q]; ca = Tc[q]; fa = Tf[q]; }
-};
-
 // One block (4 waves) per point of the batch; see ibs_refine.hpp.  The objective is utils.py:1632-1728 (as k_obj_w_grad),
 // the optimizer step ibs_lbfgsb2.hpp (= scipy's L-BFGS-B for ball_scan.py:307-314) on the point's state, and the block
 // that finishes last re-packs the batch (finished points leave it) for the next round.
+//   all waves : ONE pass over the three lines -- centre line staged as the 7 derived arrays of the scan kernels (c without
+//               its factor -dPdrho), alpha-tangent of g and f (utils.py:1707-1718) and the two halves of c's, partial sums
+//               of dPdrho of the three lines (utils.py:1657 / 1691 / 1703) -- 24 coalesced loads per grid point in flight
+//   wave 0    : set-up, eigen-solve (warm-started), eigenvector -> X in LDS
+//   all waves : Simpson sums of the growth rate and the two Hellmann-Feynman derivatives (utils.py:1618-1621, 1676-1680,
+//               1721-1725), a quarter of the grid each
+//   wave 0    : gam, jac, optimizer step, state write-back, last-block-done compaction
 template <typename T, int M>
 __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
   static_assert(sizeof(T) == 8, "the refinement is an FP64 path");
@@ -807,75 +809,152 @@ __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
   const int slot = blockIdx.x;
   if (slot >= n_c) return;                                 // (block-uniform: the grid was sized for an earlier, larger batch)
   const T h = a.ctrl->h;
+  IBS_PROBE_AT(0);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int N = a.N;
   const int P = lds_pitch(N);
   T* A1 = smem; T* A3 = A1 + P; T* C0 = A3 + P; T* C1 = C0 + P; T* G0 = C1 + P; T* G1 = G0 + P; T* G2 = G1 + P; T* Xs = G2 + P;
-  T* Tg = Xs + P; T* Tc = Tg + P; T* Tf = Tc + P;
-  T* s_dP = smem + (size_t)(a.lds_tangent ? 11 : 8) * P;
-  double* s_state = s_dP + 4;
+  T* Tg = Xs + P; T* Tf = Tg + P; T* Tcr = Tf + P; T* Tcl = Tcr + P;
+  T* s_red = smem + (size_t)(a.lds_tangent ? 12 : 8) * P;       // [4 waves][8] partial sums
+  double* s_state = s_red + 32;
   constexpr int kStateWords = (int)(sizeof(RefineState) / 8);
   const int k = a.idx[slot];
-  const T th0 = a.th0[slot];
+  const T th0 = a.th0[slot], two_th0 = T(2) * th0, th0sq = th0 * th0;
+  const T inv_da = T(1) / a.prm.del_alpha;
   const long ld = a.ld, as = (long)a.plane;                // line pitch / distance between the 8 arrays of a line
   const T* pl = a.geo + (long)(3 * slot) * ld; const T* pc = pl + ld; const T* pr = pc + ld;
-  if (wave < 3) {                                          // dPdrho of the three lines, one wave each (utils.py:1657 / 1691 / 1703)
-    const T d = line_dPdrho(wave == 0 ? pl : (wave == 1 ? pc : pr), as, N, lane);
-    if (lane == 0) s_dP[wave] = d;
-  } else {                                                 // meanwhile the optimizer state of the point comes into LDS
-    const double* src = reinterpret_cast<const double*>(a.st + k);
-    for (int i = lane; i < kStateWords; i += kWave) s_state[i] = src[i];
+  {
+    T sl = T(0), sc_ = T(0), sr = T(0);
+#pragma unroll 2
+    for (int j = threadIdx.x; j < N; j += 256) {
+      const int q = lpos(j);
+      const T B = pc[j], gp = xabs(pc[as + j]), cv = pc[2 * as + j], cv0 = pc[3 * as + j];
+      const T g0 = pc[4 * as + j], g1 = pc[5 * as + j], g2 = pc[6 * as + j], gb = pc[7 * as + j];
+      const T Bl = pl[j], gpl = xabs(pl[as + j]), cvl = pl[2 * as + j], cv0l = pl[3 * as + j];
+      const T g0l = pl[4 * as + j], g1l = pl[5 * as + j], g2l = pl[6 * as + j], gbl = pl[7 * as + j];
+      const T Br = pr[j], gpr = xabs(pr[as + j]), cvr = pr[2 * as + j], cv0r = pr[3 * as + j];
+      const T g0r = pr[4 * as + j], g1r = pr[5 * as + j], g2r = pr[6 * as + j], gbr = pr[7 * as + j];
+      sc_ += (cv - gb) * B * B; sl += (cvl - gbl) * Bl * Bl; sr += (cvr - gbr) * Br * Br;
+      const T inv = T(1) / (gp * B);
+      A1[q] = gp / B; A3[q] = inv / (B * B);               // g: utils.py:1560, f: utils.py:1562
+      C0[q] = cv * inv; C1[q] = cv0 * inv;                 // c / (-dPdrho): utils.py:1561
+      G0[q] = g0; G1[q] = g1; G2[q] = g2;
+      if (a.lds_tangent) {
+        // (g, c / (-dPdrho), f) of the lines at alpha -+ del_alpha/2 with theta0 folded in (utils.py:1692-1713)
+        const T gdl = g0l + two_th0 * g1l + th0sq * g2l, gdr = g0r + two_th0 * g1r + th0sq * g2r;
+        // (reciprocals good to ~1 ulp instead of IEEE divisions: the tangent is a difference quotient over del_alpha, its
+        //  last bits carry no information; the centre line above keeps the divisions, whose rounding the eigenvector sees)
+        const T rBl = fast_rcp(Bl), rBr = fast_rcp(Br), rgl = fast_rcp(gpl * Bl), rgr = fast_rcp(gpr * Br);
+        const T gl_ = gpl * gdl * rBl, gr_ = gpr * gdr * rBr;
+        const T fl_ = gdl * (rBl * rBl) * rgl, fr_ = gdr * (rBr * rBr) * rgr;
+        Tg[q] = (gr_ - gl_) * inv_da; Tf[q] = (fr_ - fl_) * inv_da;          // utils.py:1716, 1718
+        Tcr[q] = (cvr + th0 * cv0r) * rgr; Tcl[q] = (cvl + th0 * cv0l) * rgl;
+      }
+    }
+    sl = wave_sum(sl); sc_ = wave_sum(sc_); sr = wave_sum(sr);
+    if (lane == 0) { s_red[8 * wave] = sl; s_red[8 * wave + 1] = sc_; s_red[8 * wave + 2] = sr; }
+    if (wave == 3) {                                       // the optimizer state of the point comes into LDS
+      const double* src = reinterpret_cast<const double*>(a.st + k);
+      for (int i = lane; i < kStateWords; i += kWave) s_state[i] = src[i];
+    }
   }
   __syncthreads();
-  const T dP_l = s_dP[0], dP_c = s_dP[1], dP_r = s_dP[2];
-  const AlphaTangent<T> tang{pl, pr, as, -dP_l, -dP_r, th0, T(2) * th0, th0 * th0, T(1) / a.prm.del_alpha};
-  for (int j = threadIdx.x; j < N; j += blockDim.x) {
-    const T B = pc[j], gp = xabs(pc[as + j]);
-    const T inv = T(1) / (gp * B);
-    const int q = lpos(j);
-    A1[q] = gp / B; A3[q] = inv / (B * B);
-    C0[q] = -dP_c * pc[2 * as + j] * inv; C1[q] = -dP_c * pc[3 * as + j] * inv;
-    G0[q] = pc[4 * as + j]; G1[q] = pc[5 * as + j]; G2[q] = pc[6 * as + j];
-    if (a.lds_tangent) {
-      T ga, ca, fa;
-      tang.at(j, ga, ca, fa);
-      Tg[q] = ga; Tc[q] = ca; Tf[q] = fa;
+  const T dP_l = T(-0.5) * (((s_red[0] + s_red[8]) + s_red[16]) + s_red[24]) / T(N);
+  const T dP_c = T(-0.5) * (((s_red[1] + s_red[9]) + s_red[17]) + s_red[25]) / T(N);
+  const T dP_r = T(-0.5) * (((s_red[2] + s_red[10]) + s_red[18]) + s_red[26]) / T(N);
+  IBS_PROBE_AT(2);
+  SrcGeo<T, true> src{A1, A3, C0, C1, G0, G1, G2, th0, two_th0, th0sq, -dP_c};
+  RefineState& S = *reinterpret_cast<RefineState*>(s_state);
+  WaveSolver<T, M> ws;
+  SolveInfo inf{0, 0};
+  T lam = T(0), guess = T(0);
+  bool bad = false, warm = false;
+  T xe0 = T(0), xe1 = T(0);
+  if (wave == 0) {
+    bad = ws.setup(src, N, h);
+    IBS_PROBE_AT(3);
+    // warm start: lam of the point's previous evaluation moved along the Hellmann-Feynman gradient found there; the bracket
+    // still moves on counts only, so a poor guess costs sweeps, never correctness
+    xe0 = S.q.x[0]; xe1 = S.q.x[1];
+    warm = !bad && S.have != 0;
+    if (warm) {
+      const T lin = -(S.g_prev[0] * (xe0 - S.x_prev[0]) + S.g_prev[1] * (xe1 - S.x_prev[1]));
+      guess = S.lam_prev + lin;
+      const T floor_w = T(4096) * T(64) * Eps<T>::v * ws.normA;
+      const T width = xmax(xmax(T(0.5) * xabs(lin), T(4) * S.err_prev), floor_w);
+      lam = ws.solve(inf, true, guess, width);
+    } else if (!bad) {
+      lam = ws.solve(inf);
+    } else {
+      inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi);
+    }
+    IBS_PROBE_AT(4);
+    // eigenvector -> X = v / max|v| with zero end points (utils.py:1602-1608) in the block's LDS row
+    T x[M];
+    ws.assemble(src, nullptr, N, h, x);
+    T m = T(0);
+#pragma unroll
+    for (int i = 0; i < M; ++i) m = xmax(m, xabs(x[i]));
+    m = uniform(wave_max(m));
+    const int a0 = WaveSolver<T, M>::rows_start(lane, N - 2);
+    const T rm = T(1) / m;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+      if ((i < M - 1) || ws.has_last) Xs[lpos(a0 + i + 1)] = x[i] * rm;
+    if (lane == 0) { Xs[lpos(0)] = T(0); Xs[lpos(N - 1)] = T(0); }
+  }
+  __syncthreads();
+  {
+    // dX (utils.py:1610-1616) in the branch-free form of finish(); Simpson weights with the common 1/3 dropped
+    const T ih = T(1) / h;
+    const T A_in = (T(2) / T(3)) * ih, B_in = -ih / T(12), A_e1 = T(0.5) * ih, A_e0 = T(2) * ih, B_e0 = T(-0.5) * ih;
+    const AlphaTangent<T> tang{pl, pr, as, -dP_l, -dP_r, th0, two_th0, th0sq, inv_da};
+    T y0 = T(0), y1 = T(0), hc = T(0), hg = T(0), hf = T(0), ac = T(0), ag = T(0), af = T(0);
+    for (int j = threadIdx.x; j < N; j += 256) {
+      const int jm1 = j > 0 ? j - 1 : 0, jm2 = j > 1 ? j - 2 : 0;
+      const int jp1 = j < N - 1 ? j + 1 : N - 1, jp2 = j < N - 2 ? j + 2 : N - 1;
+      const T X = Xs[lpos(j)];
+      const T d1 = Xs[lpos(jp1)] - Xs[lpos(jm1)], d2 = Xs[lpos(jp2)] - Xs[lpos(jm2)];
+      const bool end0 = (j == 0) || (j == N - 1), end1 = (j == 1) || (j == N - 2);
+      const T A = end0 ? A_e0 : (end1 ? A_e1 : A_in), Bc = end0 ? B_e0 : (end1 ? T(0) : B_in);
+      const T dX = xfma(A, d1, Bc * d2);
+      const T w = end0 ? T(1) : ((j & 1) ? T(4) : T(2));
+      const T X2 = w * (X * X), dX2 = w * (dX * dX);
+      T g_, c_, f_, gt, ct, ft, ga, ca, fa;
+      src.gcf_with_tangent(j, g_, c_, f_, gt, ct, ft);
+      if (a.lds_tangent) {
+        const int q = lpos(j);
+        ga = Tg[q]; fa = Tf[q];
+        ca = (-dP_r * Tcr[q] - (-dP_l) * Tcl[q]) * inv_da;                 // utils.py:1717 (each line with its own dPdrho)
+      } else {
+        tang.at(j, ga, ca, fa);
+      }
+      y0 += c_ * X2 - g_ * dX2;                                            // utils.py:1618
+      y1 = xfma(f_, X2, y1);                                               // utils.py:1619
+      hc = xfma(ct, X2, hc); hg = xfma(gt, dX2, hg); hf = xfma(ft, X2, hf);        // utils.py:1676-1680
+      ac = xfma(ca, X2, ac); ag = xfma(ga, dX2, ag); af = xfma(fa, X2, af);        // utils.py:1721-1725
+    }
+    y0 = wave_sum(y0); y1 = wave_sum(y1); hc = wave_sum(hc); hg = wave_sum(hg); hf = wave_sum(hf);
+    ac = wave_sum(ac); ag = wave_sum(ag); af = wave_sum(af);
+    // (every wave read the dPdrho partial sums in s_red before the barrier above)
+    if (lane == 0) {
+      T* r = s_red + 8 * wave;
+      r[0] = y0; r[1] = y1; r[2] = hc; r[3] = hg; r[4] = hf; r[5] = ac; r[6] = ag; r[7] = af;
     }
   }
   __syncthreads();
   if (wave != 0) return;                                   // (no block barrier below)
-  RefineState& S = *reinterpret_cast<RefineState*>(s_state);
-  SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
-  WaveSolver<T, M> ws;
-  SolveInfo inf{0, 0};
-  const bool bad = ws.setup(src, N, h);
-  // warm start: lam of the point's previous evaluation moved along the Hellmann-Feynman gradient found there; the bracket
-  // still moves on counts only, so a poor guess costs sweeps, never correctness
-  const T xe0 = S.q.x[0], xe1 = S.q.x[1];
-  T lam = T(0), guess = T(0);
-  const bool warm = !bad && S.have != 0;
-  if (warm) {
-    const T lin = -(S.g_prev[0] * (xe0 - S.x_prev[0]) + S.g_prev[1] * (xe1 - S.x_prev[1]));
-    guess = S.lam_prev + lin;
-    const T floor_w = T(4096) * T(64) * Eps<T>::v * ws.normA;
-    const T width = xmax(xmax(T(0.5) * xabs(lin), T(4) * S.err_prev), floor_w);
-    lam = ws.solve(inf, true, guess, width);
-  } else if (!bad) {
-    lam = ws.solve(inf);
-  } else {
-    inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi);
-  }
-  if (a.lds_tangent) {
-    const AlphaTangentLds<T> tl{Tg, Tc, Tf};
-    finish<T, M, SrcGeo<T>, true, AlphaTangentLds<T>>(ws, src, N, h, Xs, lam, inf, slot, nullptr, a.gam, nullptr, nullptr,
-                                                      a.dth0, a.info, &tl, a.dalpha);
-  } else {
-    finish<T, M, SrcGeo<T>, true, AlphaTangent<T>>(ws, src, N, h, Xs, lam, inf, slot, nullptr, a.gam, nullptr, nullptr,
-                                                   a.dth0, a.info, &tang, a.dalpha);
-  }
-  if (lane == 0) {                                         // lane 0 wrote the three scratch values itself
-    const double val = -a.gam[slot];                                 // utils.py:1728
-    const double g[2] = {-a.dalpha[slot], -a.dth0[slot]};
+  IBS_PROBE_AT(5);
+  T t[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) t[q] = ((s_red[q] + s_red[8 + q]) + s_red[16 + q]) + s_red[24 + q];
+  const T gam = t[0] / t[1];                                                // utils.py:1621
+  const T dth0 = t[2] / t[1] - t[3] / t[1] - gam * t[4] / t[1];             // utils.py:1676-1680
+  const T dalpha = t[5] / t[1] - t[6] / t[1] - gam * t[7] / t[1];           // utils.py:1721-1725
+  if (lane == 0) {
+    if (a.info) a.info[slot] = inf.iters | (inf.status << 16);
+    const double val = -gam;                                                // utils.py:1728
+    const double g[2] = {-dalpha, -dth0};
     S.err_prev = warm ? xabs(lam - guess) : T(0);
     S.lam_prev = lam; S.x_prev[0] = xe0; S.x_prev[1] = xe1; S.g_prev[0] = g[0]; S.g_prev[1] = g[1];
     S.have = bad ? 0 : 1;
@@ -883,11 +962,13 @@ __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
     S.nev++;
     S.active = lbfgsb2::step(S.q, val, g) ? 1 : 0;
   }
+  IBS_PROBE_AT(6);
   wave_lds_sync();
   {
     double* dst = reinterpret_cast<double*>(a.st + k);
     for (int i = lane; i < kStateWords; i += kWave) dst[i] = s_state[i];
   }
+  IBS_PROBE_AT(7);
   // ---- last block done: compact the batch for the next round (ibs_refine.hpp)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   int last = 0;
@@ -1149,7 +1230,7 @@ static hipError_t launch_grad(const GradArgs<T>& a, hipStream_t st) {
 
 template <typename T>
 static hipError_t launch_refine_eval(const RefineEvalArgs<T>& a, hipStream_t st) {
-  const size_t lds = (size_t)(a.lds_tangent ? 11 : 8) * lds_pitch(a.N) * sizeof(T) + 4 * sizeof(T) + sizeof(RefineState);
+  const size_t lds = (size_t)(a.lds_tangent ? 12 : 8) * lds_pitch(a.N) * sizeof(T) + 32 * sizeof(T) + sizeof(RefineState);
   auto kern = k_refine_eval<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1182,3 +1263,9 @@ struct IBS_CAT(Registrar, IBS_M) {
 static IBS_CAT(Registrar, IBS_M) IBS_CAT(registrar_instance_, IBS_M);
 
 }  // namespace ibs
+
+#ifdef IBS_PROBE
+extern "C" int ibs_probe_read(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ibs::ibs_probe_buf), sizeof(long long) * n);
+}
+#endif
