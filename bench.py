@@ -380,29 +380,59 @@ def ncsx_pipeline(ctx, device):
 
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters, so nothing has
-    touched the GPU before they start), wait for all of them, return the worst exit code.  If one rank dies the others
-    are stopped (by PID) instead of waiting in a collective for ever."""
+    touched the GPU before they start), wait for all of them, return the worst exit code.  If one rank dies, or this
+    process is told to stop (SIGTERM / SIGINT) or raises, the ranks are stopped -- each by the process group it was
+    started in, first SIGTERM, after a grace period SIGKILL -- instead of sitting in a collective for ever."""
+    import signal
     import socket
     import subprocess
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+
+    def stop_all(grace=5.0):
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            live = [p for p in procs if p.poll() is None]
+            if not live:
+                return
+            for p in live:
+                try:
+                    os.killpg(p.pid, sig)           # (start_new_session: the rank's pid is its group id)
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.time() + grace
+            while time.time() < t_end and any(p.poll() is None for p in live):
+                time.sleep(0.05)
+
+    def on_signal(signum, frame):
+        raise KeyboardInterrupt("signal %d" % signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    alive = list(procs)
-    while alive:
-        time.sleep(0.2)
-        for p in list(alive):
-            r = p.poll()
-            if r is None:
-                continue
-            alive.remove(p)
-            if r != 0:
-                rc = rc or (r if r > 0 else 1)
-                for q in alive:
-                    q.terminate()
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          start_new_session=True))
+        alive = list(procs)
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                r = p.poll()
+                if r is None:
+                    continue
+                alive.remove(p)
+                if r != 0:
+                    rc = rc or (r if r > 0 else 1)
+                    stop_all()
+                    alive = []
+                    break
+    except KeyboardInterrupt:
+        rc = rc or 130
+    finally:
+        stop_all()
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
 
 
@@ -489,12 +519,102 @@ def c2_sharded_leg(ctx, device, rank, world, dist, fence, passes=20, native=Fals
         n = job.NS * job.NA * job.NT0
         out = dict(workload="configs[2]: 64 surfaces x 32 alpha x 16 theta0 = %d solves, N_zeta=1024, NCSX_op wout tables; "
                             "surfaces round-robin over %d ranks, geometry -> scan -> argmax per rank, ONE all-gather of "
-                            "[n_surf_local, 3]" % (n, world),
+                            "[n_surf_local, 3] (%s)" % (n, world, "ncclAllGather issued by the library" if native else "torch.distributed"),
                    scaling="strong", n_gpus=world, passes=passes, ms_per_pass=dt / passes * 1e3,
                    solves_per_s=n * passes / dt, checks_passed=ok, gathered_equals_one_gpu_bitwise=bitwise,
                    max_abs_dgam_vs_single_launch=dmax, same_argmax_as_single_launch=same_arg,
                    gam_max_min=float(full[:, 0].min().item()), gam_max_max=float(full[:, 0].max().item()))
     return out
+
+
+def c2_refined_leg(ctx, device, rank, world, dist, fence, passes=3):
+    """configs[2] as the reference's worker runs it (ball_scan.py:248-347): coarse scan -> argmax -> L-BFGS-B refinement on
+    the device -> final solve per surface, surfaces round-robin over the ranks, ONE gather of the REFINED rows
+    (theta0*, alpha*, gam) -- BallooningScan.run(), the product's own driver."""
+    import torch
+    import ibs_amd
+    job = C2Sharded(ctx, device)
+    svals = np.linspace(0.1, 0.95, job.NS)
+
+    def scan_of(r):
+        return ibs_amd.BallooningScan(ctx, None, job.th, svals, nalpha=job.NA, ntheta0=job.NT0, tables=job.tabs, device=device,
+                                      rank=r, world=world, dist=dist, gather_device=device)
+    scan = scan_of(rank)
+    full = scan.run()                                        # warm-up + the rows to check
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        full = scan.run()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    out = None
+    if rank == 0:
+        full = np.stack(full, axis=1)                        # (n_surf, 3): theta0*, alpha*, gam
+        per_shard = np.empty_like(full)
+        for r in range(world):                               # the same shards, computed here: the gather only moves rows
+            per_shard[ibs_amd.shard_surfaces(job.NS, r, world)] = scan_of(r).local_rows()
+        bitwise = bool(np.array_equal(per_shard, full))
+        coarse_max = job.local_rows(list(range(job.NS)))[:, 0].cpu().numpy()
+        never_below = bool(np.all(full[:, 2] >= coarse_max - 1e-9))          # L-BFGS-B never ends below its start
+        ev = ctx.refine_stats()
+        out = dict(workload="configs[2] with the refinement: 64 surfaces x (32 alpha x 16 theta0 coarse scan + L-BFGS-B on the device "
+                            "+ final solve), N_zeta=1024, surfaces round-robin over %d ranks, ONE gather of the refined rows" % world,
+                   scaling="strong", n_gpus=world, passes=passes, ms_per_pass=dt / passes * 1e3,
+                   checks_passed=bitwise and never_below, gathered_equals_one_gpu_bitwise=bitwise,
+                   refined_never_below_coarse_max=never_below,
+                   gam_refined_min=float(full[:, 2].min()), gam_refined_max=float(full[:, 2].max()),
+                   last_refine_on_rank0={"evaluations": ev[0], "forward_sweeps": ev[1], "rounds": ev[2]})
+    return out
+
+
+class Watchdog:
+    """Bounds the phases that can hang for ever inside a collective (a second RCCL communicator next to torch's, the first
+    multi-rank gathers of a new build).  When a phase overruns, rank 0 prints the JSON line it has so far -- the headline
+    number was measured BEFORE any such phase starts -- and every rank leaves with status 0: the run is not lost.
+    (Nothing is re-executed: a process that has touched the GPU must not exec.)"""
+
+    def __init__(self, rank, get_line):
+        import threading
+        self.rank, self.get_line, self.timer, self.threading = rank, get_line, None, threading
+
+    def arm(self, phase, seconds):
+        self.disarm()
+
+        def fire():
+            if self.rank == 0:
+                line = self.get_line()
+                if line is not None:
+                    line.setdefault("gather_modes", {})["aborted"] = "phase '%s' did not finish within %d s" % (phase, seconds)
+                    print(json.dumps(line), flush=True)
+            print("bench.py: rank %d: phase '%s' overran %d s, leaving" % (self.rank, phase, seconds), file=sys.stderr, flush=True)
+            os._exit(0)
+        self.timer = self.threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
+def rocprof_kernel_ms(prefix):
+    """average duration of the named kernel in the newest committed rocprofv3 kernel-trace summary of this bench
+    (profiles/*_kernel_stats_bench.csv): (ms, file name) or (None, None)"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_bench.csv")))
+    for f in reversed(files):
+        try:
+            for row in csv.DictReader(open(f)):
+                if prefix in row.get("Name", ""):
+                    return float(row["AverageNs"]) * 1e-6, os.path.basename(f)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def main():
@@ -548,64 +668,76 @@ def main():
     use_dist = dist.is_available() and dist.is_initialized()
     n_ranks = dist.get_world_size() if use_dist else 1
     coll_dev = device if backend == "nccl" else torch.device("cpu")
-    # N > 1: the per-surface maxima of every step are all-gathered in-stream (replaces comm_lead.Gather x3,
-    # ball_scan.py:345-347; 256 B per rank, latency-bound).  Overlapping the collective with the next scan on a side
-    # stream was measured (1-rank RCCL group, IBS_BENCH_FORCE_DIST=1): the two event dependencies per step cost more
-    # stream time on this platform (60 us per step) than the collective they hide (39 us in-stream vs 30 us without);
-    # async_op=True from a ring of buffers is host-bound in torch's Work bookkeeping (56 us per step).
+    # N > 1: the per-surface maxima of every step are all-gathered (replaces comm_lead.Gather x3, ball_scan.py:345-347;
+    # 256 B per rank, latency-bound).  THE HEADLINE is timed first and with the plainest form -- torch.distributed's
+    # all_gather_into_tensor in the step's stream: nothing that has never run on more than one GPU stands between the
+    # start of the process and the number.  The library's own ncclAllGather (in-stream, and overlapped with the next scans
+    # on the communicator's stream) is timed AFTERWARDS as extra legs, under a watchdog (`gather_modes`).
     gathered = torch.empty((n_ranks * N_SURF, 2), dtype=torch.float64, device=coll_dev) if use_dist else None
-    # The per-step gather is ONE ncclAllGather issued by libibs_hip.so itself on the step's stream (ibs_comm_*), not by
-    # torch.distributed: measured with a one-rank group, 30.9 us per step against 46.1 us (29.0 us without a collective) --
-    # torch's per-collective host work (~17 us) is what bounded the step.  Every rank creates its communicator or none does
-    # (then torch.distributed carries the gather); IBS_BENCH_NATIVE_COLL=0 switches it off.
-    native = False
-    if use_dist and backend == "nccl" and os.environ.get("IBS_BENCH_NATIVE_COLL", "1") != "0":
-        flag = torch.ones(1, dtype=torch.float64, device=device)
-        try:
-            ctx.comm_init(dist, rank, n_ranks)
-        except Exception as e:
-            print("bench.py: native RCCL communicator not available (%s); using torch.distributed" % e, file=sys.stderr)
-            flag.zero_()
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank or none
-        native = bool(flag.item() == 1.0)
-
-    # Overlap: step k's gather runs on the communicator's own stream while the next steps scan.  Pack / receive buffers
-    # rotate through three slots; before step k+1 is launched the HOST makes sure the gather that last used its slot
-    # (step k-2) has finished (an event query; it blocks only if the ranks have fallen two steps behind), so the compute
-    # stream carries one event record per step and no wait.  Every gather still completes inside the timed region
-    # (fence() = comm_wait + barrier + device synchronize).
-    # Measured with a one-rank group (tools/overlap_probe.py): 33.6 us per step (39.0 with a device-side wait on the compute
-    # stream) against 29.6 us in-stream and 28.2 us without a gather: the event dependency costs ~5 us of stream time per
-    # step whatever the gather takes (bench.py itself, one-rank group: 35.1 against 30.8 us per step), so the overlap pays
-    # once the gather's own latency exceeds ~6 us -- which any gather that crosses GPUs does: default whenever there is
-    # more than one rank (IBS_BENCH_OVERLAP=0 / 1 forces it off / on).
-    ov_env = os.environ.get("IBS_BENCH_OVERLAP", "")
-    overlap = native and (ov_env == "1" or (ov_env != "0" and n_ranks >= 2))
-    gathered3 = [gathered, torch.empty_like(gathered), torch.empty_like(gathered)] if overlap else None
+    gathered3 = [gathered, torch.empty_like(gathered), torch.empty_like(gathered)] if use_dist else None
     n_issued = [0]                       # steps issued so far (the slot rotation must not depend on the caller's k)
+    mode = ["torch" if use_dist else "none"]       # "none" | "torch" | "native" | "overlap"
 
     def step(k=0, ev=None):
         # scan + per-surface first maximum: ONE kernel (the block that completes a surface reduces it)
-        slot = n_issued[0] % 3 if overlap else 0
+        ov = mode[0] == "overlap"
+        slot = n_issued[0] % 3 if ov else 0
         if ev is not None:
             ev[0].record()
         plan.scan_argmax(slot)
         if ev is not None:
             ev[1].record()
-        if overlap:
+        if ov:
+            # step k's gather runs on the communicator's own stream while the next steps scan; pack / receive buffers rotate
+            # through three slots, and before a slot's next scan is launched the HOST makes sure the gather that last used it
+            # has finished (an event query; it blocks only if the ranks have fallen two steps behind)
             ctx.allgather_start(plan.packs[slot], gathered3[slot], slot, same_stream=True, host_wait=(n_issued[0] + 1) % 3)
             n_issued[0] += 1
-        elif native:
+        elif mode[0] == "native":
             ctx.allgather(plan.pack, gathered)
-        elif use_dist:
+        elif mode[0] == "torch":
             dist.all_gather_into_tensor(gathered, plan.pack if backend == "nccl" else plan.pack.cpu())
 
     def fence():
-        if overlap:
+        if mode[0] == "overlap":
             ctx.comm_wait(-1)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed_steps(n_steps, with_events):
+        """K steps between two fences; max over the ranks.  Returns (seconds, live kernel ms or None)."""
+        EV = 8            # the dominant kernel is bracketed on every 8th step (an event pair costs stream time)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((n_steps + EV - 1) // EV)] if with_events else None
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            step(k, evs[k // EV] if (with_events and k % EV == 0) else None)
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, (float(np.mean([a.elapsed_time(b) for a, b in evs])) if with_events else None)
+
+    def roundtrip_ok():
+        """every rank holds every rank's maxima of the last step; its own row must be what it sent"""
+        last = (n_issued[0] - 1) % 3 if mode[0] == "overlap" else 0
+        got = (gathered3[last] if mode[0] == "overlap" else gathered)[rank * N_SURF:(rank + 1) * N_SURF].to(device)
+        okt = torch.tensor([1.0 if torch.equal(got, plan.packs[last]) else 0.0], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)       # (reported, not raised: no rank may leave the others in a collective)
+        return bool(okt.item() == 1.0)
+
+    def ranks_seen(native):
+        """the number of distinct ranks counted INSIDE the collective: every rank contributes its id to one all-gather"""
+        mine = torch.full((1,), float(rank), dtype=torch.float64, device=coll_dev)
+        allr = torch.empty((n_ranks,), dtype=torch.float64, device=coll_dev)
+        if native:
+            ctx.allgather(mine, allr)
+        else:
+            dist.all_gather_into_tensor(allr, mine)
+        torch.cuda.synchronize()
+        return int(len(set(int(v) for v in allr.cpu().tolist())))
 
     for k in range(args.warmup):
         step(k)
@@ -620,21 +752,7 @@ def main():
         torch.cuda.synchronize()
         n_spin += 64
     fence()
-    # the dominant kernel is timed live with HIP events inside the timed region, on every 8th step (an event
-    # pair costs stream time: bracketing every step would measure the events)
-    EV = 8
-    n_ev = (args.steps + EV - 1) // EV
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, evs[k // EV] if k % EV == 0 else None)
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kern_ms_live = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    dt, kern_ms_live = timed_steps(args.steps, True)
     # `kernel_ms`: an UNTIMED pass of 25 brackets, each around 8 back-to-back launches of the step's one kernel, divided
     # by 8.  A bracket around a single launch over-reads rocprofv3's kernel-trace average by ~3 us (the event records
     # are stream work themselves: `event_bracket_ms` is an empty bracket), which is how the figure of a short run could
@@ -652,30 +770,31 @@ def main():
     torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in un])) / per
     empty_ms = float(np.median([c.elapsed_time(d) for c, d in emp]))
-    gather_ok = None
-    if use_dist:      # every rank holds every rank's maxima of the last step; its own row must be what it sent
-        last = (n_issued[0] - 1) % 3 if overlap else 0           # slot of the last timed step
-        got = (gathered3[last] if overlap else gathered)[rank * N_SURF:(rank + 1) * N_SURF].to(device)
-        okt = torch.tensor([1.0 if torch.equal(got, plan.packs[last]) else 0.0], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)       # (reported, not raised: no rank may leave the others in a collective)
-        gather_ok = bool(okt.item() == 1.0)
+    gather_ok = roundtrip_ok() if use_dist else None
+    seen = ranks_seen(False) if use_dist else 1
     info = plan.info.cpu().numpy()
     nbad = int(((info >> 16) != 0).sum())
     sweeps = float((info & 0xffff).mean())
 
-    c2 = None
+    c2 = c2r = None
     if use_dist:
         try:
-            c2 = c2_sharded_leg(ctx, device, rank, world, dist, fence, native=native)
+            c2 = c2_sharded_leg(ctx, device, rank, world, dist, fence, native=False)
         except Exception as e:          # (every rank runs the same collectives inside the leg; an error is reported, not raised)
             c2 = dict(error="%s: %s" % (type(e).__name__, e)) if rank == 0 else None
+        try:
+            c2r = c2_refined_leg(ctx, device, rank, world, dist, fence)
+        except Exception as e:
+            c2r = dict(error="%s: %s" % (type(e).__name__, e)) if rank == 0 else None
 
+    out = None
     if rank == 0:
         bytes_per_solve = (7 * NPTS * 8 + 8) / N_THETA0 + 8            # geometry-fed path
         alg_bytes = n_solves * bytes_per_solve
         gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         pmc_src = "profiles/pmc_current.json (committed rocprofv3 --pmc passes of this workload, set %s; replayed, " \
                   "not measured by this run)" % pmc_set_name()
+        rp_ms, rp_file = rocprof_kernel_ms("k_gamma_scan<double, 8>")
         out = {
             "metric": "field-line eigenvalue solves/sec (N_zeta=512)",
             "value": n_ranks * n_solves * args.steps / dt,
@@ -684,12 +803,15 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (NCSX_op-derived field-line geometry, perturbed per line)",
+            # the same workload priced on the kernel alone (n_ranks x solves per launch / kernel_ms): what a run of any
+            # length converges to; `value` of a 20-step run carries the two fences of a 0.6 ms timed region
+            "solves_per_s_kernel": n_ranks * n_solves / (kern_ms * 1e-3),
             "config": {"workload": "configs[1] D3D-shape: 16 surfaces x 8 alpha x 8 theta0 = 1024 solves/step/GPU, "
                                    "N_zeta=512 (513 points), geometry-fed scan with fused per-surface argmax (one launch)"
-                                   + (" + all-gather (%s, %d ranks) of the per-surface maxima" % (
-                                       ("RCCL, issued natively by the library" + (", overlapped with the next scan" if overlap else "") if native else "RCCL") if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
+                                   + (" + all-gather (%s, %d ranks, in the step's stream) of the per-surface maxima" % (
+                                       "RCCL through torch.distributed" if backend == "nccl" else "gloo rehearsal", n_ranks) if use_dist else ""),
                        "solves_per_step_per_gpu": n_solves, "mean_sweeps_per_solve": sweeps,
-                       "nonconverged": nbad, "ranks_in_collective": n_ranks, "allgather_roundtrip_ok": gather_ok,
+                       "nonconverged": nbad, "ranks_in_collective": seen, "allgather_roundtrip_ok": gather_ok,
                        "untimed_spinup_steps": args.warmup + n_spin},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("ibs::k_gamma_scan<double"),
@@ -697,7 +819,8 @@ def main():
                          "kernel": "k_gamma_scan<double,8> (scan + fused per-surface argmax)", "kernel_ms": kern_ms,
                          "kernel_ms_how": "untimed pass after the timed region: 25 HIP-event brackets around 8 back-to-back "
                                           "launches each, / 8 (includes the launch gap; rocprofv3's kernel-trace average "
-                                          "of the same kernel is under profiles/)",
+                                          "of the same kernel: kernel_ms_rocprof)",
+                         "kernel_ms_rocprof": rp_ms, "kernel_ms_rocprof_source": ("profiles/" + rp_file) if rp_file else None,
                          "event_bracket_ms": empty_ms,
                          "kernel_ms_live_raw": kern_ms_live,
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -719,12 +842,64 @@ def main():
                                              "frac": ach / peak_issue}
         if c2 is not None:
             out["ncsx_c2_sharded"] = c2
-        if world == 1 and not args.no_cpu:
+        if c2r is not None:
+            out["ncsx_c2_sharded_refined"] = c2r
+
+    # ---- N > 1: the library's own collective, as extra legs under a watchdog (the headline above is already in `out`)
+    if use_dist and backend == "nccl" and os.environ.get("IBS_BENCH_NATIVE_COLL", "1") != "0":
+        dog = Watchdog(rank, lambda: out)
+        modes = {"torch_in_stream": {"ms_per_step": dt / args.steps * 1e3, "solves_per_s": n_ranks * n_solves * args.steps / dt,
+                                     "allgather_roundtrip_ok": gather_ok, "ranks_in_collective": seen}}
+        if out is not None:
+            out["gather_modes"] = modes
+        dog.arm("ncclCommInitRank of the library's communicator", 90)
+        flag = torch.ones(1, dtype=torch.float64, device=device)
+        try:
+            ctx.comm_init(dist, rank, n_ranks)
+        except Exception as e:
+            print("bench.py: native RCCL communicator not available (%s)" % e, file=sys.stderr)
+            modes["native_error"] = "%s: %s" % (type(e).__name__, e)
+            flag.zero_()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank or none
+        native = bool(flag.item() == 1.0)
+        if native:
+            for name in ("native", "overlap"):
+                dog.arm("per-step gather, mode '%s'" % name, 120)
+                mode[0] = name
+                n_issued[0] = 0
+                for k in range(max(args.warmup, 16)):
+                    step(k)
+                fence()
+                dtm, _ = timed_steps(args.steps, False)
+                modes["native_in_stream" if name == "native" else "native_overlapped"] = {
+                    "ms_per_step": dtm / args.steps * 1e3, "solves_per_s": n_ranks * n_solves * args.steps / dtm,
+                    "allgather_roundtrip_ok": roundtrip_ok(),
+                    "ranks_in_collective": ranks_seen(True) if name == "native" else None}
+            mode[0] = "native"
+            dog.arm("configs[2] sharded with the library's gather", 180)
+            try:
+                c2n = c2_sharded_leg(ctx, device, rank, world, dist, fence, native=True)
+            except Exception as e:
+                c2n = dict(error="%s: %s" % (type(e).__name__, e)) if rank == 0 else None
+            if out is not None and c2n is not None:
+                out["ncsx_c2_sharded_native"] = c2n
+            dog.arm("ncclCommDestroy", 60)
+            ctx.comm_destroy()
+        mode[0] = "torch"
+        dog.disarm()
+
+    rc = 0
+    if rank == 0:
+        if world == 1 and not use_dist and not args.no_cpu:
             cb, gam_cpu = cpu_baseline(h, base, dP, theta0)
             out["cpu_baseline"] = cb
             out["max_abs_dgam_vs_oracle"] = float(np.abs(plan.gam.cpu().numpy() - gam_cpu).max())
+            # the bench's own workload against the C oracle: 1e-8 is the stated FP64 tolerance
+            out["parity_ok"] = bool(out["max_abs_dgam_vs_oracle"] < 1e-8 and nbad == 0)
+            if not out["parity_ok"]:
+                rc = 3
             out["cpu_reference_cost"] = cpu_reference_cost(h, base, dP, theta0)
-        if world == 1 and not args.no_stress:
+        if world == 1 and not use_dist and not args.no_stress:
             out["stress"] = stress(ctx, device, args.stress_systems, "smooth")
             out["stress_rough"] = stress(ctx, device, max(args.stress_systems // 4, 1024), "rough")
             out["sturm_sweep"] = sturm_sweep(ctx, device, args.stress_systems)
@@ -733,11 +908,14 @@ def main():
             out["batch_scaling"] = batch_scaling(ctx, device, h, geo7, dP_d, th0_d)
             out.update(ncsx_pipeline(ctx, device))
         print(json.dumps(out), flush=True)
+        if rc:
+            print("bench.py: parity check FAILED: max |gam - oracle| = %g (bar 1e-8), flagged solves %d" % (
+                out["max_abs_dgam_vs_oracle"], nbad), file=sys.stderr, flush=True)
     if use_dist:
-        if native:
-            ctx.comm_destroy()
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -73,9 +73,11 @@ struct ibs_ctx {
   hipEvent_t comm_ready = nullptr;
   hipEvent_t comm_done[kCommSlots] = {nullptr, nullptr, nullptr, nullptr};
   bool comm_pending[kCommSlots] = {false, false, false, false};
-  // per-surface arrival counters of the fused scan + argmax kernel (zero between launches)
-  int* surf_counter = nullptr;
-  int surf_counter_n = 0;
+  // per-surface arrival counters of the fused scan + argmax kernel (zero between launches; the last arriver resets its
+  // word).  One buffer PER STREAM the context has been used on: two plans of one context run under different streams may
+  // have their fused kernels in flight at the same time, and shared counters would mix their arrivals.
+  struct SurfCounters { hipStream_t stream; int* buf; int n; };
+  std::vector<SurfCounters> surf_counters;
   // ibs_refine_f64: per-round counts posted by the device (pinned host memory), statistics of the last call
   int* refine_hist = nullptr;
   int refine_hist_len = 0;
@@ -379,7 +381,7 @@ int ibs_destroy(ibs_ctx* c) {
   (void)ibs_comm_destroy(c);
   DeviceGuard g(c->device);
   if (c->ws) hipFree(c->ws);
-  if (c->surf_counter) hipFree(c->surf_counter);
+  for (auto& sc : c->surf_counters) if (sc.buf) hipFree(sc.buf);
   if (c->refine_hist) hipHostFree(c->refine_hist);
   delete c;
   return 0;
@@ -754,14 +756,17 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   a.lam_guess = lam_guess; a.guess_width = guess_width;
   if (pack && fn == ibs::launch_table().scan_f64[M] && G == 1) {
     // one launch: the block that completes a surface reduces it (k_gamma_scan's epilogue)
-    if (ctx->surf_counter_n < n_surf) {
-      if (ctx->surf_counter) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(ctx->surf_counter)); ctx->surf_counter = nullptr; }
+    ibs_ctx::SurfCounters* sc = nullptr;
+    for (auto& e : ctx->surf_counters) if (e.stream == ctx->stream) { sc = &e; break; }
+    if (!sc) { ctx->surf_counters.push_back(ibs_ctx::SurfCounters{ctx->stream, nullptr, 0}); sc = &ctx->surf_counters.back(); }
+    if (sc->n < n_surf) {
+      if (sc->buf) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(sc->buf)); sc->buf = nullptr; sc->n = 0; }
       const int cap_n = n_surf > 1024 ? n_surf : 1024;
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->surf_counter), (size_t)cap_n * sizeof(int)));
-      HIPCHK(hipMemsetAsync(ctx->surf_counter, 0, (size_t)cap_n * sizeof(int), ctx->stream));
-      ctx->surf_counter_n = cap_n;
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&sc->buf), (size_t)cap_n * sizeof(int)));
+      HIPCHK(hipMemsetAsync(sc->buf, 0, (size_t)cap_n * sizeof(int), ctx->stream));
+      sc->n = cap_n;
     }
-    a.lines_per_surf = n_lines / n_surf; a.surf_counter = ctx->surf_counter; a.pack = pack;
+    a.lines_per_surf = n_lines / n_surf; a.surf_counter = sc->buf; a.pack = pack;
     {
       const long nblocks = (long)((n_theta0 + a.wpb - 1) / a.wpb) * n_lines;
       a.pack_mode = (nblocks <= ctx->n_cu && ctx->opt.pack_mode != 2) ? 1 : 2;

@@ -94,6 +94,7 @@ class BallooningScan:
         self.theta0_scan = np.linspace(0.0, 0.5 * np.pi, ntheta0)          # ball_scan.py:225
         self.del_alpha = del_alpha
         self.rank, self.world, self.dist, self.gather_device = rank, world, dist, gather_device
+        self._native_gather = world > 1 and getattr(ctx, "_comm_world", 0) == world
         self.own = shard_surfaces(len(self.rho_arr), rank, world)
 
     def _device_fieldlines_host(self, s, alphas):
@@ -222,17 +223,16 @@ class BallooningScan:
         val, _ = self.ctx.obj_w_grad(self.h, geo, t0, self.del_alpha)
         return -val.cpu().numpy()
 
-    def run(self, refine=True):
-        """returns (theta0_arr, alpha_arr, gam_arr), each (nsurfs,), identical on every rank"""
+    def local_rows(self, refine=True):
+        """(theta0*, alpha*, gam) of the surfaces this rank owns, (n_own, 3): coarse scan -> argmax -> refinement -> final
+        solve (ball_scan.py:248-339), no collective"""
         tabs = self.coarse()
-        rows = []
         if refine and self.tables is not None and self.device is not None and self.own:
             starts = np.array([pick_start(tab, self.alpha_scan, self.theta0_scan)[:2] for tab in tabs])
             xo, fo, _ = self.refine_device(starts)
             gam = self.final_solve_device(xo)                      # ball_scan.py:322-339: one more solve at the optimum
-            local = np.stack([xo[:, 1], xo[:, 0], gam], axis=1)
-            full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device, self.ctx)
-            return full[:, 0], full[:, 1], full[:, 2]
+            return np.stack([xo[:, 1], xo[:, 0], gam], axis=1)
+        rows = []
         for k, tab in zip(self.own, tabs):
             a0, t0, sigma0, ij = pick_start(tab, self.alpha_scan, self.theta0_scan)
             if refine:
@@ -240,8 +240,28 @@ class BallooningScan:
             else:
                 t, a, gam = t0, a0, float(np.max(tab))
             rows.append((t, a, gam))
-        local = np.array(rows, dtype=np.float64).reshape(len(self.own), 3)
-        full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device)
+        return np.array(rows, dtype=np.float64).reshape(len(self.own), 3)
+
+    def run(self, refine=True):
+        """returns (theta0_arr, alpha_arr, gam_arr), each (nsurfs,), identical on every rank.
+        Every rank takes part in the ONE gather whatever happens on its own shard: a rank-local failure (flagged solves,
+        non-finite tables) travels through the collective as NaN rows and is raised on EVERY rank afterwards -- a rank
+        that raised before the gather would leave the others waiting in it."""
+        err = None
+        try:
+            local = self.local_rows(refine)
+        except IbsError as e:
+            err = e
+            local = np.full((len(self.own), 3), np.nan)
+        # one decision for every gather of this object, the same on every rank: the library's own communicator when the
+        # context holds one for this world (Context.comm_init is all-or-none over the ranks), else torch.distributed
+        full = gather_surfaces(local, len(self.rho_arr), self.rank, self.world, self.dist, self.gather_device,
+                               self.ctx if self._native_gather else None)
+        if err is not None:
+            raise err
+        if self.world > 1 and not np.all(np.isfinite(full)):
+            bad = sorted(set(int(j) % self.world for j in np.nonzero(~np.isfinite(full).all(axis=1))[0]))
+            raise IbsError("surface rows of rank(s) %s are not finite: the scan failed there (see that rank's error)" % bad)
         return full[:, 0], full[:, 1], full[:, 2]
 
 

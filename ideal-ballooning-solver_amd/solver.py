@@ -75,6 +75,7 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            self._comm_world = 0
             self._lib.ibs_destroy(self._h)
             self._h = C.c_void_p(None)
 
@@ -140,6 +141,7 @@ class Context:
         check(self._lib.ibs_comm_wait(self._h, int(slot)), "ibs_comm_wait")
 
     def comm_destroy(self):
+        self._comm_world = 0            # gathers go back to torch.distributed
         check(self._lib.ibs_comm_destroy(self._h), "ibs_comm_destroy")
 
     def set_option(self, name, value):

@@ -150,7 +150,9 @@ int ibs_gamma_scan_warm_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int
  * Replaces: ball_scan.py:248-295 (coarse scan loops + argmax with the first-maximum rule :283-288) for all surfaces of a
  * rank at once.  For small batches this is a single kernel launch: the thread block that completes a surface reduces
  * it (agent-scope release / acquire on a per-surface arrival counter); large batches run the chained / sub-wave scan
- * kernels followed by the reduction kernel. */
+ * kernels followed by the reduction kernel.  * The arrival counters are per (context, stream): launches of one context on ONE stream are ordered and may be queued
+ * back to back; the same context used under two streams gets two counter sets.  A launch that faults leaves its
+ * counters undefined: destroy the context. */
 int ibs_gamma_scan_argmax_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
                               const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
                               const double* gds2, const double* gds21, const double* gds22, int64_t ld,

@@ -91,6 +91,62 @@ def test_two_rank_gloo_gather_equals_single_rank():
             assert np.allclose(a, b, rtol=0, atol=0)
 
 
+def _worker_run_edge(rank, world, port, q, case):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = 129
+    th = bo.theta_grid(N)
+    fl = synthetic_fieldlines(th)
+    if case == "empty":                 # one surface, two ranks: rank 1 owns nothing and still takes part in the gather
+        svals = [0.7]
+    else:                               # rank 1's only surface fails (its geometry producer raises): carried through the gather
+        svals = [0.6, 0.8]
+
+        def fl_bad(s, alphas, fl=fl):
+            if s > 0.75:
+                raise ibs_amd.IbsError("injected failure on the surface s = %g" % s)
+            return fl(s, alphas)
+        fl = fl_bad
+    scan = ibs_amd.BallooningScan(OracleContext(), fl, th, svals, nalpha=4, ntheta0=3, rank=rank, world=world, dist=dist)
+    try:
+        out = ("ok", [o.tolist() for o in scan.run(refine=False)])
+    except ibs_amd.IbsError as e:
+        out = ("raised", str(e))
+    q.put((rank, out))
+    dist.barrier()                      # (both ranks are still in step: nobody was left inside the gather)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["empty", "fail"])
+def test_two_rank_run_with_empty_shard_and_with_a_failing_rank(case):
+    """BallooningScan.run(): a rank without surfaces takes part in the one gather; a rank whose shard fails sends NaN rows
+    and EVERY rank raises after the collective (no rank may leave the others waiting in it)."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_run_edge, args=(r, 2, port, q, case)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    if case == "empty":
+        N = 129
+        th = bo.theta_grid(N)
+        single = ibs_amd.BallooningScan(OracleContext(), synthetic_fieldlines(th), th, [0.7], nalpha=4, ntheta0=3).run(refine=False)
+        for r in (0, 1):
+            assert res[r][0] == "ok"
+            for a, b in zip(res[r][1], single):
+                assert np.array_equal(a, b)
+    else:
+        assert res[0][0] == "raised" and res[1][0] == "raised"
+        assert "injected failure" in res[1][1] and "not finite" in res[0][1]
+
+
 def test_history_files_follow_reference_append_semantics(tmp_path):
     # arr_create2.py creates 1-element placeholders; ball_scan.py:369-379 replaces them, then stacks rows
     for name in ("ball_gam", "ball_theta0", "ball_alpha"):
@@ -207,7 +263,7 @@ def test_params_dict_reader_and_grid_rule(tmp_path):
     assert th[0] == -4 * np.pi and th[-1] == 4 * np.pi and np.array_equal(th, ibs_amd.theta_grid(969))
 
 
-def _worker_bench(rank, world, port, q):
+def _worker_bench(rank, world, port, q, n_surf=7):
     """bench.py's own sharded pass (sharded_surface_pass + gather_rows_tensor) under gloo with CPU tensors"""
     import torch
     import torch.distributed as dist
@@ -215,7 +271,6 @@ def _worker_bench(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n_surf = 7
 
     def local_rows(own):     # what C2Sharded.local_rows returns on a GPU: (gam_max, alpha*, theta0*) per own surface
         return torch.tensor([[100.0 + s, 0.5 * s, 0.25 * s] for s in own], dtype=torch.float64).reshape(len(own), 3)
@@ -226,20 +281,21 @@ def _worker_bench(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_sharded_pass_gloo(world):
+@pytest.mark.parametrize("world,n_surf", [(2, 7), (3, 7), (3, 64), (8, 64), (8, 7)])
+def test_bench_sharded_pass_gloo(world, n_surf):
+    """C2Sharded-shaped rows with uneven shards (64 surfaces over 3 ranks) and with empty ones (7 surfaces over 8 ranks)"""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker_bench, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker_bench, args=(r, world, port, q, n_surf)) for r in range(world)]
     for p in ps:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    want = [[100.0 + s, 0.5 * s, 0.25 * s] for s in range(7)]
+    want = [[100.0 + s, 0.5 * s, 0.25 * s] for s in range(n_surf)]
     for r in range(world):
         assert res[r] == want
 
