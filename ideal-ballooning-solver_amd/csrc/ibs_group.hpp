@@ -125,6 +125,7 @@ struct GroupSolver {
   T zu_m1, zw_p1;
   int Eu, Ew;
   T lo, hi, normA;          // group-replicated
+  T trial_rho, trial_del;   // Rayleigh quotient / residual bound of the trial vector (setup<Src, true>; see WaveSolver::setup)
   T shoot_m; int shoot_e;   // shooting value of the last forward sweep (group-replicated), see WaveSolver
   T fu, fw;
   int thr;
@@ -135,7 +136,7 @@ struct GroupSolver {
   }
 
   // Src provides g(j), c(j), f(j) of THIS lane's system
-  template <class Src>
+  template <class Src, bool TRIAL = false>
   __device__ __forceinline__ bool setup(const Src& src, int N, T h) {
     lane = threadIdx.x & 63;
     lg = lane & (P - 1);
@@ -152,6 +153,14 @@ struct GroupSolver {
     T vhi = -T(1e300), vlo = -T(1e300), vna = T(0), sum_c = T(0), sum_f = T(0);
     bool bad = !(g0 > T(0)) || !(gcur > T(0));   // non-finite data, g <= 0 or f <= 0 anywhere in this lane's rows
     const T e_first = e_lo;
+    T ts_prev = T(0), ts_cur = T(0), two_cd = T(0), tA = T(0), tB = T(0), tC = T(0);
+    if constexpr (TRIAL) {               // trial vector x_j = sin(pi j / (N - 1)): WaveSolver::setup
+      const T dl = T(3.14159265358979323846) / T(N - 1);
+      T s0, c0, sd, cd;
+      trial_sincos(T(a) * dl, s0, c0);
+      trial_sincos(dl, sd, cd);
+      ts_prev = s0; ts_cur = xfma(s0, cd, c0 * sd); two_cd = T(2) * cd;
+    }
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const bool act = (i < M - 1) || has_last;
@@ -165,6 +174,12 @@ struct GroupSolver {
         const T s2 = sc * sc;
         D[i] = d * s2; Ph[i] = fj * s2;
         const T rf = fast_rcp(fj);          // bounds only (margins added below)
+        if constexpr (TRIAL) {
+          const T ts_next = xfma(two_cd, ts_cur, -ts_prev);
+          const T Tx = xfma(e_lo, ts_prev, xfma(d, ts_cur, e_hi * ts_next));
+          tA = xfma(ts_cur, Tx, tA); tB = xfma(fj * ts_cur, ts_cur, tB); tC = xfma(Tx * rf, Tx, tC);
+          ts_prev = ts_cur; ts_cur = ts_next;
+        }
         vhi = xmax(vhi, cj * rf);
         vlo = xmax(vlo, d * rf);
         vna = xmax(vna, (xabs(d) + e_lo + e_hi) * rf);
@@ -186,7 +201,25 @@ struct GroupSolver {
     lo = xmax(GP::max(vlo, lane), (sc_all - ends) / sf_all);
     hi += T(8) * Eps<T>::v * normA;
     lo -= T(8) * Eps<T>::v * normA;
+    if constexpr (TRIAL) {
+      const T A = GP::sum(tA, lane), B = GP::sum(tB, lane), C = GP::sum(tC, lane);
+      const T rho = A / B;
+      trial_rho = rho;
+      trial_del = approx_sqrt(xmax(xfma(-rho, A, C), T(0)) / B);
+    } else {
+      trial_rho = T(0); trial_del = T(-1);
+    }
     return GP::sum_i(bad ? 1 : 0, lane) != 0;   // per group
+  }
+
+  // per-group start of a cold solve from the trial vector's bracket (WaveSolver::trial_guess, written with selects: the
+  // groups of a wave decide independently); groups with take == false keep their (guess, width, warm)
+  __device__ __forceinline__ void trial_guess(bool take, T& guess, T& width, bool& warm) {
+    const bool use = take && finite_of(trial_rho) && trial_del > T(0) && trial_del < T(0.25) * (hi - lo);
+    lo = use ? xmax(lo, trial_rho - T(8) * Eps<T>::v * normA) : lo;
+    guess = use ? trial_rho : guess;
+    width = use ? T(0.25) * trial_del : width;
+    warm = use ? true : warm;
   }
 
   // forward sweep; returns the group's Sturm count (eigenvalues > sig), group-replicated.  STORE: keep the

@@ -570,12 +570,15 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
-  const bool bad = ws.setup(src, N, h);
+  const bool bad = ws.template setup<SrcGeo<T>, true>(src, N, h);
   IBS_PROBE_AT(2);
   T lam = T(0);
-  // (two inlined copies of the solver: in the cold one the warm-start bookkeeping is compiled out of the loop)
-  if (!bad) lam = lam_guess ? ws.solve(inf, true, guess, guess_width) : ws.solve(inf);
-  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  if (!bad) {
+    // one inlined copy of the solver: a caller's guess, or the bracket of the trial vector (WaveSolver::trial_guess)
+    T g_ = guess, w_ = guess_width;
+    if (!lam_guess) ws.trial_guess(g_, w_);
+    lam = ws.solve(inf, true, g_, w_);
+  } else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   IBS_PROBE_AT(3);
   if constexpr (M >= 3) {
     finish_chunk<T, M, SrcGeo<T>, true>(ws, src, N, h, Xs, lam, inf, sys, valid ? lam_out : nullptr,
@@ -707,14 +710,15 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan_chain(
     SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
     WaveSolver<T, M> ws;
     SolveInfo inf{0, 0};
-    const bool bad = ws.setup(src, Nq, h);
+    const bool bad = ws.template setup<SrcGeo<T>, true>(src, Nq, h);
     const long sys = (long)line * n_theta0 + it0;
     T lam = T(0);
     if (!bad) {
       const T floor_w = T(4096) * T(64) * Eps<T>::v * ws.normA;
-      const T guess = have == 2 ? T(2) * lam_p1 - lam_p2 : lam_p1;
-      const T width = have == 2 ? xmax(w2 * xabs(lam_p1 - lam_p2), floor_w) : xmax(w1 * xabs(lam_p1), floor_w);
-      lam = ws.solve(inf, have > 0, guess, width);
+      T guess = have == 2 ? T(2) * lam_p1 - lam_p2 : lam_p1;
+      T width = have == 2 ? xmax(w2 * xabs(lam_p1 - lam_p2), floor_w) : xmax(w1 * xabs(lam_p1), floor_w);
+      if (have == 0) ws.trial_guess(guess, width);          // the first solve of a chain starts from the trial vector's bracket
+      lam = ws.solve(inf, true, guess, width);
       lam_p2 = lam_p1; lam_p1 = lam; have = have < 2 ? have + 1 : 2;
     } else {
       inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); have = 0;
@@ -773,9 +777,9 @@ __global__ void __launch_bounds__(256) k_obj_w_grad(int n_pts, int N, T h, const
   SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
-  const bool bad = ws.setup(src, N, h);
+  const bool bad = ws.template setup<SrcGeo<T>, true>(src, N, h);
   T lam = T(0);
-  if (!bad) lam = ws.solve(inf);
+  if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   AlphaTangent<T> tan{pl, pr, ld, -dP_l, -dP_r, th0, T(2) * th0, th0 * th0, T(1) / del_alpha};
   // results land in per-point scratch slots of the output arrays, then are folded into (val, jac)
@@ -871,23 +875,23 @@ __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
   bool bad = false, warm = false;
   T xe0 = T(0), xe1 = T(0);
   if (wave == 0) {
-    bad = ws.setup(src, N, h);
+    bad = ws.template setup<SrcGeo<T, true>, true>(src, N, h);
     IBS_PROBE_AT(3);
     // warm start: lam of the point's previous evaluation moved along the Hellmann-Feynman gradient found there; the bracket
     // still moves on counts only, so a poor guess costs sweeps, never correctness
     xe0 = S.q.x[0]; xe1 = S.q.x[1];
     warm = !bad && S.have != 0;
+    T g_ = T(0), w_ = T(0);
     if (warm) {
       const T lin = -(S.g_prev[0] * (xe0 - S.x_prev[0]) + S.g_prev[1] * (xe1 - S.x_prev[1]));
       guess = S.lam_prev + lin;
       const T floor_w = T(4096) * T(64) * Eps<T>::v * ws.normA;
-      const T width = xmax(xmax(T(0.5) * xabs(lin), T(4) * S.err_prev), floor_w);
-      lam = ws.solve(inf, true, guess, width);
+      g_ = guess; w_ = xmax(xmax(T(0.5) * xabs(lin), T(4) * S.err_prev), floor_w);
     } else if (!bad) {
-      lam = ws.solve(inf);
-    } else {
-      inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi);
+      ws.trial_guess(g_, w_);                              // first evaluation of a point: the trial vector's bracket
     }
+    if (!bad) lam = ws.solve(inf, true, g_, w_);
+    else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
     IBS_PROBE_AT(4);
     // eigenvector -> X = v / max|v| with zero end points (utils.py:1602-1608) in the block's LDS row
     T x[M];

@@ -216,9 +216,12 @@ __global__ void __launch_bounds__(scan_max_threads_g(M), 2) k_gamma_scan_g(
   const T th0 = theta0[it0c];
   SrcGeoG<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
   GroupSolver<T, M, P> ws;
-  const bool bad = ws.setup(src, N, h);
+  const bool bad = ws.template setup<SrcGeoG<T>, true>(src, N, h);
   int iters = 0, status = 0;
-  const T lam = ws.solve(bad, iters, status);
+  T g_ = T(0), w_ = T(0);
+  bool warm_ = false;
+  ws.trial_guess(true, g_, w_, warm_);                 // cold solves start from the trial vector's bracket
+  const T lam = ws.solve(bad, iters, status, warm_, g_, w_);
   const long sys = (long)line * n_theta0 + it0c;
   finish_chunk_g<T, M, P, SrcGeoG<T>, true>(ws, src, N, h, Xs, lam, iters, status, sys, valid, lam_out, gam_out, X_out,
                                       dX_out, dth0_out, info_out);
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(scan_max_threads_g(M), 2) k_gamma_scan_g_chain
     const T th0 = theta0[it0c];
     SrcGeoG<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
     GroupSolver<T, M, P> ws;
-    const bool bad = ws.setup(src, Nq, h);
+    const bool bad = ws.template setup<SrcGeoG<T>, true>(src, Nq, h);
     const long sys = (long)line * n_theta0 + it0c;
     int iters = 0, status = 0;
     const T floor_w = T(4096) * T(64) * Eps<T>::v * ws.normA;
@@ -288,6 +291,7 @@ __global__ void __launch_bounds__(scan_max_threads_g(M), 2) k_gamma_scan_g_chain
     T width = have == 2 ? xmax(w2 * xabs(lam_p1 - lam_p2), floor_w) : xmax(w1 * xabs(lam_p1), floor_w);
     bool warm = have > 0;
     if (lam_guess) { guess = lam_guess[sys]; width = guess_width; warm = true; }
+    ws.trial_guess(!warm, guess, width, warm);           // the first solve of a chain: the trial vector's bracket
     const T lam = ws.solve(bad, iters, status, warm, guess, width);
     lam_p2 = lam_p1; lam_p1 = lam; have = bad ? 0 : (have < 2 ? have + 1 : 2);
     finish_chunk_g<T, M, P, SrcGeoG<T>, true>(ws, src, Nq, h, Xs, lam, iters, status, sys, valid, lam_out, gam_out, X_out,

@@ -93,6 +93,28 @@ __device__ __forceinline__ double approx_sqrt(double x) {      // x >= 0, well s
 }
 __device__ __forceinline__ float approx_sqrt(float x) { return __builtin_sqrtf(x); }
 
+// sin and cos of an angle in [0, pi] (the trial vector of WaveSolver::setup): Cody-Waite reduction by pi/2 and the fdlibm
+// kernels, ~1 ulp; the float form uses the fast hardware functions (the trial vector only steers the iteration)
+__device__ __forceinline__ void trial_sincos(double x, double& sn, double& cs) {
+  const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
+  r = __builtin_fma(-k, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06); ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03); ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+  const double s_ = __builtin_fma(z * r, ps, r);
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07); pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03); pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double c_ = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+  const int q = (int)k;
+  const double s1 = (q & 1) ? c_ : s_, c1 = (q & 1) ? s_ : c_;
+  sn = (q & 2) ? -s1 : s1;
+  cs = ((q + 1) & 2) ? -c1 : c1;
+}
+__device__ __forceinline__ void trial_sincos(float x, float& sn, float& cs) { sn = __sinf(x); cs = __cosf(x); }
+
 // integer-built exponent helpers (v_frexp_exp / v_ldexp are slow-rate FP64 instructions):
 // expo_of: e with |x| in [2^e, 2^(e+1)) for normal x, a large negative number for 0 / denormals
 __device__ __forceinline__ int expo_of(double x) { const int eb = (__double2hiint(x) >> 20) & 0x7ff; return eb ? eb - 1023 : -(1 << 28); }
@@ -314,6 +336,9 @@ struct WaveSolver {
   T sig_vec;       // shift of the last twisted() call (assemble() replays the forward solution at it)
   // bounds
   T lo, hi, normA;
+  // Rayleigh quotient and residual bound of the trial vector x_j = sin(pi j / (N - 1)) (setup<Src, true>): lam_max >= rho,
+  // and some eigenvalue lies within del of rho
+  T trial_rho, trial_del;
   // shooting value of the last forward sweep (mantissa-like, power-of-two exponent)
   T shoot_m; int shoot_e;
 
@@ -325,7 +350,15 @@ struct WaveSolver {
   }
 
   // Src provides g(j), c(j), f(j) for grid point j in [0, N) (LDS-backed)
-  template <class Src>
+  // TRIAL: also forms the Rayleigh quotient rho = x'Tx / x'Fx and the residual bound del = |Tx - rho Fx|_{F^-1} / |x|_F of the
+  // fundamental mode of the grid, x_j = sin(pi j / (N - 1)) (zero at both ends like the eigenfunctions; = cos(theta / 8) on the
+  // reference's [-4 pi, 4 pi] grids, the long-wavelength factor of its own start vector, ball_scan.py:209).  rho is a
+  // rigorous lower bound of lam_max (Courant-Fischer) that needs no count, and [rho, rho + del] is where trial_guess() lets
+  // the shift iteration start: on the NCSX lines rho sits 2-4 eigenvalue gaps below lam_max where the Gershgorin /
+  // diagonal-quotient bracket is ~500 gaps wide (10.8 instead of 15.3 forward sweeps per solve, 14 instead of 19 at the
+  // worst; numpy model of the iteration in tools/sim_solve.py).  ~0.6 of a sweep: one fma recurrence for x, 7 flops per row, three
+  // wave sums.
+  template <class Src, bool TRIAL = false>
   __device__ __forceinline__ bool setup(const Src& src, int N, T h) {
     lane = threadIdx.x & (kWave - 1);
     const int n = N - 2;
@@ -350,6 +383,14 @@ struct WaveSolver {
     }
     T vhi = -T(1e300), vlo = -T(1e300), vna = T(0), sum_c = T(0), sum_f = T(0);
     const T e_first = e_lo;
+    T ts_prev = T(0), ts_cur = T(0), two_cd = T(0), tA = T(0), tB = T(0), tC = T(0);
+    if constexpr (TRIAL) {
+      const T dl = T(3.14159265358979323846) / T(N - 1);
+      T s0, c0, sd, cd;
+      trial_sincos(T(a) * dl, s0, c0);                 // grid point a = the left neighbour of this lane's first row
+      trial_sincos(dl, sd, cd);
+      ts_prev = s0; ts_cur = xfma(s0, cd, c0 * sd); two_cd = T(2) * cd;
+    }
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const bool act = (i < M - 1) || has_last;
@@ -363,6 +404,12 @@ struct WaveSolver {
         const T s2 = sc * sc;
         D[i] = d * s2; Ph[i] = fj * s2;
         const T rf = fast_rcp(fj);          // bounds only (margins added below)
+        if constexpr (TRIAL) {
+          const T ts_next = xfma(two_cd, ts_cur, -ts_prev);
+          const T Tx = xfma(e_lo, ts_prev, xfma(d, ts_cur, e_hi * ts_next));
+          tA = xfma(ts_cur, Tx, tA); tB = xfma(fj * ts_cur, ts_cur, tB); tC = xfma(Tx * rf, Tx, tC);
+          ts_prev = ts_cur; ts_cur = ts_next;
+        }
         vhi = xmax(vhi, cj * rf);
         vlo = xmax(vlo, d * rf);
         vna = xmax(vna, (xabs(d) + e_lo + e_hi) * rf);
@@ -389,8 +436,27 @@ struct WaveSolver {
     lo = uniform(xmax(wave_max(vlo), (sc_all - e0 - en) / sf_all));
     hi += T(8) * Eps<T>::v * normA;
     lo -= T(8) * Eps<T>::v * normA;
+    if constexpr (TRIAL) {
+      const T A = wave_sum(tA), B = wave_sum(tB), C = wave_sum(tC);
+      const T rho = A / B;
+      trial_rho = rho;
+      trial_del = approx_sqrt(xmax(xfma(-rho, A, C), T(0)) / B);       // |r|^2 = x'T F^-1 T x - rho x'Tx  (rho = x'Tx / x'Fx)
+    } else {
+      trial_rho = T(0); trial_del = T(-1);
+    }
     IBS_PROBE_AT(9);
     return __any(bad) != 0;
+  }
+
+  // Start of a cold solve from the trial vector's bracket (setup<Src, true>): raises lo to rho (no count needed) and
+  // returns the (guess, width) = (rho, del / 4) that makes solve()'s warm path test rho + del / 4 first and walk up from
+  // there; when the bracket is not worth it (del not well below the Gershgorin width: a localized mode the trial vector
+  // does not resemble) the guess is NaN, which solve() treats as a cold start.
+  __device__ __forceinline__ void trial_guess(T& guess, T& width) {
+    const bool use = U(finite_of(trial_rho) && trial_del > T(0) && trial_del < T(0.25) * (hi - lo));
+    if (use) lo = xmax(lo, trial_rho - T(8) * Eps<T>::v * normA);
+    guess = use ? trial_rho : T(__builtin_nanf(""));
+    width = T(0.25) * trial_del;
   }
 
   // forward sweep at shift sig (solution from the left end).  Returns the Sturm count (eigenvalues > sig).
