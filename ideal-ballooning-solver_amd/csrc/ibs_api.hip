@@ -252,6 +252,12 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
       if (fn) { launch = fn; M = Mg; per_wave = (size_t)(64 / P) * ibs::lds_pitch(N) * sizeof(T); }
     }
   }
+  if constexpr (sizeof(T) == 4) {
+    // FP32 systems whose growth rate or eigenfunction is wanted: widened to FP64 while they are staged (k_solve_gcf_wide);
+    // lam alone stays with the all-FP32 kernel
+    auto fw = ibs::launch_table().gcf_f32_wide[M];
+    if ((gam || X || dX) && fw) { launch = fw; per_wave = (size_t)3 * ibs::lds_pitch(N) * sizeof(double); }
+  }
   if constexpr (sizeof(T) == 8) {
     // long grids, one wave per system: stream the three rows through ONE LDS row per wave (k_solve_gcf_rows) -- the
     // 3-row staging of k_solve_gcf leaves two waves per CU at N_zeta = 2048 and five at 1024

@@ -90,6 +90,7 @@ struct SrcGeo {
 
 
 struct NoTangent {};
+template <typename U> struct TypeId { using type = U; };     // (keeps an output type out of template argument deduction)
 
 // alpha-tangent of (g, c, f): central difference between the field lines at alpha +- del_alpha/2,
 // each with ITS OWN dPdrho (utils.py:1683-1718); lines are read from global memory.
@@ -111,11 +112,13 @@ struct AlphaTangent {
 };
 
 // shared tail: eigenvector -> X in LDS -> growth rate (and optional outputs)
-template <typename T, int M, class Src, bool HF, class Tan = NoTangent>
+template <typename T, int M, class Src, bool HF, class Tan = NoTangent, typename TO = T>
 __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int N, T h, T* Xs,
-                                       T lam, const SolveInfo& inf, long sys, T* lam_out, T* gam_out,
-                                       T* X_out, T* dX_out, T* dth0_out, int* info_out,
-                                       const Tan* tan = nullptr, T* dalpha_out = nullptr, const T* gh = nullptr) {
+                                       T lam, const SolveInfo& inf, long sys, typename TypeId<TO>::type* lam_out,
+                                       typename TypeId<TO>::type* gam_out, typename TypeId<TO>::type* X_out,
+                                       typename TypeId<TO>::type* dX_out, typename TypeId<TO>::type* dth0_out, int* info_out,
+                                       const Tan* tan = nullptr, typename TypeId<TO>::type* dalpha_out = nullptr,
+                                       const T* gh = nullptr) {
   const int lane = ws.lane;
   const int n = N - 2;
   T x[M];
@@ -172,8 +175,8 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
       tan->at(jc, ga, ca, fa);
       ac = xfma(ca, X2, ac); ag = xfma(ga, dX2, ag); af = xfma(fa, X2, af);
     }
-    if (X_out && in) X_out[sys * N + j] = X;
-    if (dX_out && in) dX_out[sys * N + j] = dX;
+    if (X_out && in) X_out[sys * N + j] = (TO)X;
+    if (dX_out && in) dX_out[sys * N + j] = (TO)dX;
   }
   IBS_PROBE_AT(14);
   y0 = wave_sum(y0); y1 = wave_sum(y1);
@@ -182,18 +185,18 @@ __device__ __forceinline__ void finish(WaveSolver<T, M>& ws, const Src& src, int
     if (do_hf) {
       hc = wave_sum(hc); hg = wave_sum(hg); hf = wave_sum(hf);
       const T jac = hc / y1 - hg / y1 - gam * hf / y1;               // utils.py:1676-1680
-      if (lane == 0) dth0_out[sys] = jac;
+      if (lane == 0) dth0_out[sys] = (TO)jac;
     }
   }
   if constexpr (!std::is_same<Tan, NoTangent>::value) {
     ac = wave_sum(ac); ag = wave_sum(ag); af = wave_sum(af);
     const T jac = ac / y1 - ag / y1 - gam * af / y1;                 // utils.py:1721-1725
-    if (lane == 0 && dalpha_out) dalpha_out[sys] = jac;
+    if (lane == 0 && dalpha_out) dalpha_out[sys] = (TO)jac;
   }
   if (lane == 0) {
-    if (lam_out) lam_out[sys] = lam;
+    if (lam_out) lam_out[sys] = (TO)lam;
     // (write-through, agent scope: the fused per-surface reduction of k_gamma_scan reads it from another CU)
-    if (gam_out) __hip_atomic_store(gam_out + sys, gam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gam_out) __hip_atomic_store(gam_out + sys, (TO)gam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (info_out) info_out[sys] = inf.iters | (inf.status << 16);
   }
 }
@@ -223,10 +226,12 @@ __device__ __forceinline__ void simpson_point(const Src& src, int j, T w, T X, T
 // PASSES > 1 (row-streamed raw systems, k_solve_gcf_rows): the Simpson sums are separable in (g, c, f), so they are
 // accumulated in PASSES sweeps over the rows, `src.begin_pass(p)` putting the p-th coefficient array into the wave's one
 // LDS row in between (the other two read as zero).
-template <typename T, int M, class Src, bool HF, int PASSES = 1>
+template <typename T, int M, class Src, bool HF, int PASSES = 1, typename TO = T>
 __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, Src& src, int N, T h, T* Xs, T lam,
-                                             const SolveInfo& inf, long sys, T* lam_out, T* gam_out,
-                                             T* X_out, T* dX_out, T* dth0_out, int* info_out, const T* gh = nullptr) {
+                                             const SolveInfo& inf, long sys, typename TypeId<TO>::type* lam_out,
+                                             typename TypeId<TO>::type* gam_out, typename TypeId<TO>::type* X_out,
+                                             typename TypeId<TO>::type* dX_out, typename TypeId<TO>::type* dth0_out,
+                                             int* info_out, const T* gh = nullptr) {
   static_assert(M >= 3, "the halo exchange takes two rows from each neighbour lane");
   const int lane = ws.lane;
   const int n = N - 2;
@@ -296,18 +301,18 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, Src& src, int
     if (do_hf) {
       hc = wave_sum(hc); hg = wave_sum(hg); hf = wave_sum(hf);
       const T jac = hc / y1 - hg / y1 - gam * hf / y1;               // utils.py:1676-1680
-      if (lane == 0) dth0_out[sys] = jac;
+      if (lane == 0) dth0_out[sys] = (TO)jac;
     }
   }
   if (lane == 0) {
-    if (lam_out) lam_out[sys] = lam;
+    if (lam_out) lam_out[sys] = (TO)lam;
     // (write-through, agent scope: the fused per-surface reduction of k_gamma_scan reads it from another CU)
-    if (gam_out) __hip_atomic_store(gam_out + sys, gam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gam_out) __hip_atomic_store(gam_out + sys, (TO)gam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (info_out) info_out[sys] = inf.iters | (inf.status << 16);
   }
   if (X_out || dX_out) {                   // wave-uniform
     for (int pass = 0; pass < 2; ++pass) {
-      T* out = pass ? dX_out : X_out;
+      TO* out = pass ? dX_out : X_out;
       if (!out) continue;
       wave_lds_sync();                     // the row's previous content (f of k_solve_gcf, or X) has been consumed
 #pragma unroll
@@ -320,7 +325,7 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, Src& src, int
       if (lane == 0) Xs[lpos(0)] = pass ? dX_end : T(0);                                        // utils.py:1607, 1610
       if (lane == kWave - 1) Xs[lpos(N - 1)] = pass ? dX_end : T(0);                            // utils.py:1608, 1614
       wave_lds_sync();
-      for (int j = lane; j < N; j += kWave) out[sys * N + j] = Xs[lpos(j)];
+      for (int j = lane; j < N; j += kWave) out[sys * N + j] = (TO)Xs[lpos(j)];
     }
   }
 }
@@ -368,6 +373,59 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
                                    valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
                                    nullptr, valid ? info_out : nullptr, static_cast<const NoTangent*>(nullptr), nullptr,
                                    gh ? gh + sysc * ld : nullptr);
+  }
+}
+
+// FP32 systems whose growth rate (or eigenfunction) is wanted: FP32 in HBM, FP64 in the solver.  The FD4 / Simpson growth rate
+// subtracts two sums of size ||A|| ~ 4 / h^2, so an FP32 eigenvector's noise is multiplied by ~N^2 (usable at N_zeta <= 512,
+// noise above: round 2); the rows are therefore widened while they are staged -- exactly: every float is a double -- and the
+// system the FP32 arrays DEFINE is solved by the FP64 path (certified by counts, gam to ~1e-12 of that system), results
+// rounded to FP32 on the way out.  Half the HBM bytes of the FP64 entry point, the same arithmetic.  (lam alone, the
+// throughput / stress form of config 5, stays with the all-FP32 kernel k_solve_gcf<float, M>.)
+// growth-rate stage of k_solve_gcf_wide at M < 3: g, c from the widened LDS rows, f (whose row now holds X) re-read from global memory
+struct SrcGCFW {
+  static constexpr bool kHasGh = false;
+  const double* gs; const double* cs; const float* fg;
+  __device__ __forceinline__ double g(int j) const { return gs[lpos(j)]; }
+  __device__ __forceinline__ void gcf(int j, double& g_, double& c_, double& f_) const { const int q = lpos(j); g_ = gs[q]; c_ = cs[q]; f_ = (double)fg[j]; }
+};
+template <int M>
+__global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float h, const float* __restrict__ g,
+                                                        const float* __restrict__ c, const float* __restrict__ f, long ld,
+                                                        float* lam_out, float* gam_out, float* X_out, float* dX_out,
+                                                        int* info_out) {
+  using T = double;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const long sys = (long)blockIdx.x * wpb + wave;
+  const bool valid = sys < n_sys;
+  const long sysc = valid ? sys : (n_sys - 1);
+  const int P = lds_pitch(N);
+  T* gs = smem + (size_t)wave * 3 * P;
+  T* cs = gs + P; T* fs = cs + P; T* Xs = fs;
+  const float* gg = g + sysc * ld; const float* cg = c + sysc * ld; const float* fg = f + sysc * ld;
+  for (int j = lane; j < N; j += kWave) { const int q = lpos(j); gs[q] = (T)gg[j]; cs[q] = (T)cg[j]; fs[q] = (T)fg[j]; }
+  wave_lds_sync();
+  SrcGCF<T> src{gs, cs, fs};
+  WaveSolver<T, M> ws;
+  SolveInfo inf{0, 0};
+  const bool bad = ws.setup(src, N, (T)h);
+  wave_lds_sync();
+  T lam = T(0);
+  if (!bad) lam = ws.solve(inf);
+  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  if constexpr (M >= 3) {
+    finish_chunk<T, M, SrcGCF<T>, false, 1, float>(ws, src, N, (T)h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                                    valid ? gam_out : nullptr, valid ? X_out : nullptr,
+                                                    valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
+  } else {
+    // (the LDS-round-trip growth-rate stage needs f after X has taken its row: re-read, widened, from global memory)
+    const SrcGCFW srcf{gs, cs, fg};
+    finish<T, M, SrcGCFW, false, NoTangent, float>(ws, srcf, N, (T)h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                                valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                                nullptr, valid ? info_out : nullptr);
   }
 }
 
@@ -1163,6 +1221,17 @@ static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
                      a.lam, a.gam, a.X, a.dX, a.info, a.gh);
   return hipGetLastError();
 }
+static hipError_t launch_gcf_wide(const GcfArgs<float>& a, hipStream_t st) {
+  const int wpb = a.wpb;
+  const size_t lds = (size_t)wpb * 3 * lds_pitch(a.N) * sizeof(double);
+  const long nblk = (a.n_sys + wpb - 1) / wpb;
+  auto kern = k_solve_gcf_wide<IBS_M>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
+                     a.lam, a.gam, a.X, a.dX, a.info);
+  return hipGetLastError();
+}
 template <typename T>
 static hipError_t launch_gcf_rows(const GcfArgs<T>& a, hipStream_t st) {
   if constexpr (IBS_M >= 3) {
@@ -1261,6 +1330,7 @@ struct IBS_CAT(Registrar, IBS_M) {
     t.refine_f64[IBS_M] = &launch_refine_eval<double>;
 #ifdef IBS_WITH_F32
     t.gcf_f32[IBS_M] = &launch_gcf<float>;
+    t.gcf_f32_wide[IBS_M] = &launch_gcf_wide;
 #endif
   }
 };

@@ -80,6 +80,7 @@ struct LaunchTable {
   hipError_t (*gcf_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);
   hipError_t (*gcf_rows_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);   // row-streamed form (k_solve_gcf_rows)
   hipError_t (*gcf_f32[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);
+  hipError_t (*gcf_f32_wide[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);   // FP32 in HBM, FP64 in the solver (gam / X wanted)
   hipError_t (*scan_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
   hipError_t (*scan_chain_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
   hipError_t (*sturm_f64[kMaxM + 1])(const SturmArgs<double>&, hipStream_t);

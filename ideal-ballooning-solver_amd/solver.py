@@ -154,9 +154,10 @@ class Context:
         self.set_option("all", None)
 
     # ---- raw (g, c, f) systems --------------------------------------------------------------
-    def solve_gcf(self, h, g, c, f, want_X=False, want_info=False, dtype=np.float64, gh=None):
+    def solve_gcf(self, h, g, c, f, want_X=False, want_info=False, dtype=np.float64, gh=None, want_gam=True):
         """g, c, f: (n_sys, N).  Returns dict(lam, gam[, X, dX][, info]).  gh (n_sys, N) optional half-grid g
-        (first N-1 columns used): see ibs_solve_gcfh_f64."""
+        (first N-1 columns used): see ibs_solve_gcfh_f64.  float32: with want_gam / want_X the systems are widened to
+        FP64 inside the solver (FP32 in HBM only); want_gam=False and no X = the all-FP32 kernel, eigenvalues only."""
         ar = _Args(dtype)
         n_sys, N = g.shape
         pg, pc, pf = ar.inp(g), ar.inp(c), ar.inp(f)
@@ -164,7 +165,7 @@ class Context:
         if ref is not None:
             self._stream_from_torch(ref)
         lam, plam = ar.out((n_sys,), ref)
-        gam, pgam = ar.out((n_sys,), ref)
+        gam, pgam = ar.out((n_sys,), ref, want=want_gam)
         X, pX = ar.out((n_sys, N), ref, want=want_X)
         dX, pdX = ar.out((n_sys, N), ref, want=want_X)
         info, pinfo = ar.out((n_sys,), ref, dtype=np.int32, want=want_info)

@@ -117,6 +117,11 @@ int ibs_solve_gcf_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const do
 int ibs_solve_gcfh_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* gh,
                        const double* c, const double* f, int64_t ld, double* lam, double* gam, double* X, double* dX,
                        int32_t* info, int32_t mem);
+/* FP32 form (BASELINE configs[4], the stress leg).  With lam alone (gam, X, dX all null) the whole solve is FP32 -- the
+ * throughput form; |lam - lam64| <= 16 eps32 ||A|| (median), <= N_zeta eps32 ||A|| (99.9 %).  When gam, X or dX is asked
+ * for the arrays are widened to FP64 as they are staged and the FP64 solver runs on them (FP32 in HBM only; results
+ * rounded to FP32): an FP32 eigenvector's noise is multiplied by ~N^2 in the FD4 / Simpson quotient, so an all-FP32
+ * growth rate is noise above N_zeta = 512.  |gam - gam64| <= 1e-6 at every N_zeta on smooth systems. */
 int ibs_solve_gcf_f32(ibs_ctx* ctx, int64_t n_sys, int32_t N, float h, const float* g, const float* c,
                       const float* f, int64_t ld, float* lam, float* gam, float* X, float* dX,
                       int32_t* info, int32_t mem);

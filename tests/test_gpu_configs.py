@@ -95,37 +95,50 @@ def test_config5_fp64_one_million_systems(ctx, nz, family):
     assert float(((r2["lam"] - (lam[:m] + 0.25)).abs() / nA[:m]).max()) < 3e-13
 
 
-# FP32 tolerances of config 5, measured with tests/tools/fp32_probe.py (65,536 systems per leg) and stated with margin.
-#   lam: the scan-form Sturm counts certify eigenvalues of a matrix perturbed by ~n eps, n = N_zeta rows:
+# FP32 entry point of config 5 (ibs_solve_gcf_f32), measured with tests/tools/fp32_wide_probe.py and stated with margin.
+#   lam-only requests run the all-FP32 kernel (the throughput / stress form): the scan-form Sturm counts certify eigenvalues
+#        of a matrix perturbed by ~n eps, n = N_zeta rows:
 #        median <= 16 eps32 ||A||,  99.9 % <= n eps32 ||A||,  every system <= 16 n eps32 ||A||
 #        (the outliers beyond n eps32 ||A|| -- 1e-4 of the smooth family at N_zeta <= 512 -- sit on lam_2: an FP32 count
 #        off by one between lam_2 and lam_1; FP64 is the parity path)
-#   gam (smooth family only; SURVEY 8d C5-ii pins lam alone on the rough one): the FD4 / Simpson growth rate subtracts
-#        two sums of size ||A|| ~ 4/h^2, so FP32 eigenvector noise is multiplied by ~N_zeta^2: usable at N_zeta <= 512,
-#        noise above (stated so; the FP32 variant exists for throughput / stress, not for the growth rate)
+#   requests for gam (or X) are WIDENED: FP32 in HBM, FP64 in the solver (k_solve_gcf_wide) -- an FP32 eigenvector's noise is
+#        multiplied by ~N_zeta^2 in the FD4 / Simpson quotient (round 2: noise above N_zeta = 512).  What is left is the
+#        rounding of the inputs and of the result to FP32:  |lam - lam64| <= 2 eps32 ||A|| on every system (measured 0.2),
+#        |gam - gam64| <= 1e-6 on every system of the smooth family (measured 6e-8 = gam eps32) at EVERY N_zeta;
+#        SURVEY 8d C5-ii pins lam alone on the rough family (near-degenerate pairs: gam is first order in the inputs there).
 EPS32 = 1.1920929e-07
-GAM32_TOL = {256: (2e-5, 1e-3), 512: (5e-4, 5e-2), 1024: (5e-2, 20.0), 2048: (5.0, 2e3)}     # (median, 99 %) of |gam32 - gam64|
+GAM32_WIDE_TOL = 1.0e-6
 
 
 @pytest.mark.parametrize("nz", [256, 512, 1024, 2048])
 def test_config5_fp32_stated_tolerances(ctx, nz):
-    """FP32 legs of config 5 against FP64 on the same systems: 2 families x 131,072 systems per N_zeta"""
+    """FP32 legs of config 5 against FP64 on the same systems, 2 families x 10^6 systems per N_zeta (BASELINE's size)"""
     import torch
     dev = torch.device("cuda:0")
-    n, N = 131072, nz + 1
+    n, N = 1000000, nz + 1
     q = lambda t, pr: float(torch.quantile(t, pr))
     for family in ("smooth", "rough"):
         h, g, c, f = c5_family(dev, family, n, N, seed=20240 + nz)
         r64 = ctx.solve_gcf(h, g, c, f)
-        r32 = ctx.solve_gcf(h, g.float(), c.float(), f.float(), want_info=True, dtype=np.float32)
-        assert r32["lam"].dtype == torch.float32 and int(((r32["info"] >> 16) != 0).sum()) == 0
         nA = norm_a(h, g, c, f)
+        g32, c32, f32 = g.float(), c.float(), f.float()
+        del g, c, f
+        # (a) eigenvalues only: the all-FP32 kernel
+        r32 = ctx.solve_gcf(h, g32, c32, f32, want_info=True, dtype=np.float32, want_gam=False)
+        assert r32["lam"].dtype == torch.float32 and r32["gam"] is None and int(((r32["info"] >> 16) != 0).sum()) == 0
         el = (r32["lam"].double() - r64["lam"]).abs() / nA
         assert float(el.median()) < 16 * EPS32 and q(el, 0.999) < nz * EPS32 and float(el.max()) < 16 * nz * EPS32, \
             (float(el.median()), q(el, 0.999), float(el.max()))
+        # (b) growth rate wanted: widened to FP64 inside the solver
+        rw = ctx.solve_gcf(h, g32, c32, f32, want_info=True, dtype=np.float32)
+        assert rw["gam"].dtype == torch.float32 and int(((rw["info"] >> 16) != 0).sum()) == 0
+        ew = (rw["lam"].double() - r64["lam"]).abs() / nA
+        assert float(ew.max()) < 2 * EPS32, float(ew.max())
         if family == "smooth":
-            eg = (r32["gam"].double() - r64["gam"]).abs()
-            assert float(eg.median()) < GAM32_TOL[nz][0] and q(eg, 0.99) < GAM32_TOL[nz][1], (float(eg.median()), q(eg, 0.99))
+            eg = (rw["gam"].double() - r64["gam"]).abs()
+            assert float(eg.max()) < GAM32_WIDE_TOL, (float(eg.median()), float(eg.max()))
+        del g32, c32, f32, r64, r32, rw
+        torch.cuda.empty_cache()
 
 
 # ---------------------------------------------------------------------------------------------- configs[3]
