@@ -161,6 +161,7 @@ struct GeoImgLayout {      // offsets (in doubles) inside one surface's image: a
   int o_int;               // ints: goff1[nr1 + 1], goff2[nr2 + 1], code1[nr1], code2[nr2]
   int o_lm, o_amn, o_anq;  // lane-major lists
   int s_lm, s_amn, s_anq;  // lane strides
+  int Tsc, o_sy0, o_sym;   // n-symmetric form of the lmns rows (one lane per point): capacity, [nr1][2] + 2, [Tsc][nr1][2]
   int total;
 };
 __host__ __device__ inline GeoImgLayout geo_layout(int mnmax, int nr1, int mnmax_nyq, int nr2, int lpp) {
@@ -178,7 +179,10 @@ __host__ __device__ inline GeoImgLayout geo_layout(int mnmax, int nr1, int mnmax
   L.s_amn = 2 * (10 * L.T1c + 1);
   L.o_anq = L.o_amn + lpp * L.s_amn;
   L.s_anq = 2 * (10 * L.T2c + 1);
-  L.total = L.o_anq + lpp * L.s_anq;
+  L.Tsc = mnmax < 64 ? mnmax : 64;
+  L.o_sy0 = L.o_anq + lpp * L.s_anq;
+  L.o_sym = L.o_sy0 + 2 * nr1 + 2;
+  L.total = L.o_sym + (lpp == 1 ? 2 * L.Tsc * nr1 : 0);
   return L;
 }
 int geo_lpp_index(int lpp) { return lpp == 1 ? 0 : (lpp == 2 ? 1 : (lpp == 4 ? 2 : 3)); }
@@ -253,7 +257,43 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
     I[10] = -1.0 * 2 * shat / sq * sgn;                   // gbdrift0 = I10 BxgB_psi / B^3
     I[11] = 2 * Bref * Lm * Lm * sq * mu0 * dp * sgn / etf;   // cvdrift = gbdrift - I11 / B^2
     I[12] = Lm * iota;                                    // gradpar = I12 B^phi / B
-    I[13] = (double)T1; I[14] = (double)T2; I[15] = 0.0;
+    I[13] = (double)T1; I[14] = (double)T2;
+    if (lpp != 1) I[15] = -1.0;                             // (lpp == 1: set with the n-symmetric lists below)
+  }
+  // ---- lmns rows in n-symmetric form (one lane per point): with the row's n = n_c + t dn, t = -k0 .. cnt-1-k0 (n_c = 0
+  // whenever the row holds n = 0: VMEC's rows run n = -ntor .. ntor, or 0 .. ntor for m = 0),
+  //   sum_n l cos(n phi) = cos(n_c phi) A_c - sin(n_c phi) A_s,   sum_n l sin(n phi) = sin(n_c phi) A_c + cos(n_c phi) A_s,
+  //   A_c = l_0 + sum_{t>0} (l_t + l_-t) cos(t D),   A_s = sum_{t>0} (l_t - l_-t) sin(t D),   D = dn phi
+  // and cos / sin(t D) are the same for EVERY row: the (P_m, Q_m) pass of the root solve becomes one recurrence over t with
+  // two fma per row instead of four per mode
+  if (lpp == 1) {
+    __shared__ int k0_s[kGeoMaxRows], tmax_s;
+    const double* lmn = a.tab_mn + (size_t)js * 6 * a.mnmax + 2 * (size_t)a.mnmax;
+    double* sy0 = I + L.o_sy0;
+    if (t == 0) tmax_s = 0;
+    __syncthreads();
+    for (int r = t; r < nr1; r += blockDim.x) {
+      const double n0 = rn_s[0][r];
+      int k0 = 0; double nc = n0;
+      const double kz = -n0 / a.dn_mn;
+      const int kr = (int)(kz + (kz >= 0 ? 0.5 : -0.5));
+      if (kr >= 0 && kr < cnt1[r] && fabs(n0 + kr * a.dn_mn) <= 1e-9 * fabs(a.dn_mn)) { k0 = kr; nc = 0.0; }
+      k0_s[r] = k0;
+      sy0[2 * r] = lmn[a.rows_mn[2 * r] + k0]; sy0[2 * r + 1] = nc;
+      const int tm = k0 > cnt1[r] - 1 - k0 ? k0 : cnt1[r] - 1 - k0;
+      atomicMax(&tmax_s, tm);
+      if (nc != 0.0) atomicMax(&tmax_s, 1 << 20);            // (marks "some row is centred away from n = 0")
+    }
+    __syncthreads();
+    const int any_nc = tmax_s >> 20, Ts = tmax_s & ((1 << 20) - 1);
+    if (t == 0) { sy0[2 * nr1] = any_nc ? 1.0 : 0.0; I[15] = Ts <= L.Tsc ? (double)Ts : -1.0; }
+    double* sym = I + L.o_sym;
+    for (int e = t; e < L.Tsc * nr1; e += blockDim.x) {
+      const int tt = e / nr1 + 1, r = e - (tt - 1) * nr1;
+      const int k0 = k0_s[r], kp = k0 + tt, km = k0 - tt;
+      const double lp = kp < cnt1[r] ? lmn[a.rows_mn[2 * r] + kp] : 0.0, lq = km >= 0 ? lmn[a.rows_mn[2 * r] + km] : 0.0;
+      sym[2 * e] = lp + lq; sym[2 * e + 1] = lp - lq;
+    }
   }
   auto row_of = [](int g, int nr, const int* goff) { int r = 0; while (r + 1 < nr && goff[r + 1] <= g) ++r; return r; };
   // source mode of slot u (0 | 1) of group g of lane sub, or -1 (padding)
@@ -504,9 +544,53 @@ __device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, cons
   RowTrig<PPL> rs;
   rs.init_phi(phi);
   GEO_PROBE_AT(2);
-  // ---- (P_m, Q_m) of the root solve: one pass over lmns with the n-recurrence alone
+  // ---- (P_m, Q_m) of the root solve
   double Pm[PPL][MAXR], Qm[PPL][MAXR];
-  {
+  const int Tsym = LPP == 1 ? __builtin_amdgcn_readfirstlane((int)I[15]) : -1;
+  if (LPP == 1 && Tsym >= 0) {
+    // n-symmetric rows (k_geo_prepare): one recurrence for cos / sin(t D), two fma per row and t
+    const double2* Sy = reinterpret_cast<const double2*>(I + L.o_sym);
+    const double* sy0 = I + L.o_sy0;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) { Pm[p][r] = r < nr1 ? sy0[2 * (r < nr1 ? r : 0)] : 0.0; Qm[p][r] = 0.0; }
+    double ct[PPL], st[PPL], ctm[PPL], stm[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) { ct[p] = cD[p]; st[p] = sD[p]; ctm[p] = 1.0; stm[p] = 0.0; }
+    for (int t = 0; t < Tsym; ++t) {
+      const double2* row = Sy + (size_t)t * nr1;
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r) {
+        if (r < nr1) {
+          const double2 u = row[r];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) { Pm[p][r] = fma(u.x, ct[p], Pm[p][r]); Qm[p][r] = fma(u.y, st[p], Qm[p][r]); }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) {
+        const double cn = fma(two_cD[p], ct[p], -ctm[p]), sn = fma(two_cD[p], st[p], -stm[p]);
+        ctm[p] = ct[p]; stm[p] = st[p]; ct[p] = cn; st[p] = sn;
+      }
+    }
+    if (__builtin_amdgcn_readfirstlane((int)sy0[2 * nr1]) != 0) {             // rows centred away from n = 0 (not VMEC's)
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r) {
+        if (r < nr1) {
+          const double nc = sy0[2 * r + 1];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            double sn, cn;
+            geo_sincos(nc * phi[p], &sn, &cn);
+            const double P_ = cn * Pm[p][r] - sn * Qm[p][r], Q_ = sn * Pm[p][r] + cn * Qm[p][r];
+            Pm[p][r] = P_; Qm[p][r] = Q_;
+          }
+        }
+      }
+    }
+  } else {
+    // one pass over lmns with the n-recurrence alone (several lanes per point: every lane its n-segment of every row)
     const double2* Lp = reinterpret_cast<const double2*>(I + L.o_lm + (size_t)sub * L.s_lm);
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
