@@ -32,3 +32,20 @@ for _ in range(3):
     ctx.fieldline_geometry(tabs, surf, al, ibs_amd.theta_grid(1025), device=dev)
 torch.cuda.synchronize()
 print("geometry done", flush=True)
+
+# F2 refinement: the reference batch (5 surfaces, N = 969) twice and the config-4 shape (365 maxima in one batch) once
+th = ibs_amd.theta_grid(969)
+sv5 = np.linspace(0.5, 0.95, 5)
+tabs5 = ibs_amd.SurfaceTables.from_wout(wout, sv5)
+scan5 = ibs_amd.BallooningScan(ctx, None, th, sv5, tables=tabs5, device=dev)
+st5 = np.array([ibs_amd.pick_start(t, scan5.alpha_scan, scan5.theta0_scan)[:2] for t in scan5.coarse()])
+for _ in range(2):
+    scan5.refine_device(st5)
+print("refine (reference batch) stats", ctx.refine_stats(), flush=True)
+if os.environ.get("IBS_PROFILE_BIG", "1") != "0":
+    big = ibs_amd.SurfaceTables.concat([tabs5] * 73)
+    scanb = ibs_amd.BallooningScan(ctx, None, th, np.tile(sv5, 73), tables=big, device=dev)
+    scanb.own = list(range(365))
+    surf_b = np.arange(365)
+    xo, fo, ne, rounds = ctx.refine(big, surf_b, np.tile(st5, (73, 1)), th, device=dev)
+    print("refine (365 maxima) stats", ctx.refine_stats(), flush=True)
