@@ -267,10 +267,10 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
   // and cos / sin(t D) are the same for EVERY row: the (P_m, Q_m) pass of the root solve becomes one recurrence over t with
   // two fma per row instead of four per mode
   if (lpp == 1) {
-    __shared__ int k0_s[kGeoMaxRows], tmax_s;
+    __shared__ int k0_s[kGeoMaxRows], tmax_s, anync_s;
     const double* lmn = a.tab_mn + (size_t)js * 6 * a.mnmax + 2 * (size_t)a.mnmax;
     double* sy0 = I + L.o_sy0;
-    if (t == 0) tmax_s = 0;
+    if (t == 0) { tmax_s = 0; anync_s = 0; }
     __syncthreads();
     for (int r = t; r < nr1; r += blockDim.x) {
       const double n0 = rn_s[0][r];
@@ -282,10 +282,10 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
       sy0[2 * r] = lmn[a.rows_mn[2 * r] + k0]; sy0[2 * r + 1] = nc;
       const int tm = k0 > cnt1[r] - 1 - k0 ? k0 : cnt1[r] - 1 - k0;
       atomicMax(&tmax_s, tm);
-      if (nc != 0.0) atomicMax(&tmax_s, 1 << 20);            // (marks "some row is centred away from n = 0")
+      if (nc != 0.0) atomicMax(&anync_s, 1);                  // some row is centred away from n = 0
     }
     __syncthreads();
-    const int any_nc = tmax_s >> 20, Ts = tmax_s & ((1 << 20) - 1);
+    const int any_nc = anync_s, Ts = tmax_s;
     if (t == 0) { sy0[2 * nr1] = any_nc ? 1.0 : 0.0; I[15] = Ts <= L.Tsc ? (double)Ts : -1.0; }
     double* sym = I + L.o_sym;
     for (int e = t; e < L.Tsc * nr1; e += blockDim.x) {

@@ -153,3 +153,30 @@ def test_J1_cobravmec_profile(ctx):
         worst = max(worst, abs(ref["gam"] - gam[k]))
         assert abs(ref["gam"] - gam[k]) < 1e-8, (k, svals[k], ref["gam"], gam[k], ref["x_opt"], (al[k], t0[k]))
     print("J1: gam_max/stored in [%.2f, %.2f]; worst |gam - oracle| on 6 surfaces %.2e" % (ratio.min(), ratio.max(), worst))
+
+
+def test_geometry_row_kernel_variants(ctx):
+    """k_geo_rows on row structures other than VMEC's own: rows split into pieces of <= 12 modes (21 + 29 rows: the MAXR = 24
+    instantiation, rows that repeat an m, rows centred away from n = 0 in the (P, Q) pass) and pieces of <= 5 modes (more rows
+    than the register-resident (P, Q) pass holds: the one-sincos-per-mode kernel); every form, against the default rows."""
+    import torch
+    import ibs_amd
+    from ibs_amd.geometry import mode_rows
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    dev = torch.device("cuda:0")
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, [0.35, 0.8])
+    surf = [0, 0, 1, 1, 1, 0]; al = [0.0, 1.3, 0.4, 2.0, np.pi, 2.9]
+    for N in (969, 257):
+        th = ibs_amd.theta_grid(N)
+        ref = ctx.fieldline_geometry(tabs, surf, al, th, device=dev)["geo"].cpu().numpy()
+        scale = np.abs(ref).max(axis=2, keepdims=True)
+        for max_len in (12, 5):
+            t2 = ibs_amd.SurfaceTables.from_wout(wout, [0.35, 0.8])
+            t2.rows_mn, t2.dn_mn = mode_rows(t2.xm, t2.xn, max_len=max_len)
+            t2.rows_nyq, t2.dn_nyq = mode_rows(t2.xm_nyq, t2.xn_nyq, max_len=max_len)
+            assert (len(t2.rows_mn) > 12) and (len(t2.rows_mn) <= 24) == (max_len == 12)
+            for lpp in (0, 1, -2, 4):
+                ctx.set_option("geo_lpp", lpp)
+                r = ctx.fieldline_geometry(t2, surf, al, th, device=dev)
+                assert (np.abs(r["geo"].cpu().numpy() - ref) / scale).max() < 1e-11, (N, max_len, lpp)
+            ctx.set_option("geo_lpp", None)
