@@ -180,3 +180,56 @@ def test_geometry_row_kernel_variants(ctx):
                 r = ctx.fieldline_geometry(t2, surf, al, th, device=dev)
                 assert (np.abs(r["geo"].cpu().numpy() - ref) / scale).max() < 1e-11, (N, max_len, lpp)
             ctx.set_option("geo_lpp", None)
+
+
+def _subset_wout(wout, keep_mn, keep_nyq):
+    """the same equilibrium file with a subset of its Fourier modes (a data manipulation for shape coverage: both sides
+    evaluate the same formulas on it)"""
+    w = dict(wout)
+    for k in ("rmnc", "zmns", "lmns"):
+        w[k] = wout[k][keep_mn]
+    for k in ("gmnc", "bmnc", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc"):
+        w[k] = wout[k][keep_nyq]
+    w["xm"], w["xn"] = wout["xm"][keep_mn], wout["xn"][keep_mn]
+    w["xm_nyq"], w["xn_nyq"] = wout["xm_nyq"][keep_nyq], wout["xn_nyq"][keep_nyq]
+    return w
+
+
+@pytest.mark.parametrize("shape", ["axisymmetric", "few_modes", "one_sided_n"])
+def test_geometry_on_other_mode_sets(ctx, shape):
+    """F1 on mode tables that are NOT NCSX's 12 x 23 / 14 x 29 rectangles, against the numpy oracle (utils.py:359-720 restated):
+    a tokamak-like table (n = 0 only: every row is one mode -- the D3D equilibria of configs[1] look like this), a table with
+    a handful of modes (rows of different lengths, some m missing) and one whose rows are not symmetric in n (the (P, Q) pass's
+    centred-row logic); one line and many lines, N = 67 .. 2049, every lanes-per-point form."""
+    import torch
+    import ibs_amd
+    from oracle import geometry_oracle as go
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    xm, xn, xmq, xnq = wout["xm"], wout["xn"], wout["xm_nyq"], wout["xn_nyq"]
+    nfp = int(np.min(np.abs(xn[xn != 0])))
+    if shape == "axisymmetric":
+        kmn, knq = xn == 0, xnq == 0
+    elif shape == "few_modes":
+        kmn = ((xm <= 3) & (np.abs(xn) <= 2 * nfp) & (xm != 2)) | ((xm == 7) & (xn == 0)) | ((xm == 0) & (xn == 0))
+        knq = ((xmq <= 4) & (np.abs(xnq) <= nfp)) | ((xmq == 9) & (xnq == 3 * nfp))
+    else:
+        kmn = (xn >= 0) | ((xm == 1) & (xn >= -2 * nfp))
+        knq = (xnq <= 0) | ((xmq == 2) & (xnq <= 4 * nfp))
+    w = _subset_wout(wout, kmn, knq)
+    svals = np.array([0.3, 0.77])
+    tabs = ibs_amd.SurfaceTables.from_wout(w, svals)
+    otab = go.surface_tables_from_wout(w, svals)
+    dev = torch.device("cuda:0")
+    for N, surf, al in ((67, [1], [0.7]), (969, [0, 1, 1], [0.0, 2.2, np.pi]), (2049, [0, 0, 1, 0], [0.3, 1.1, 2.9, 3.0])):
+        th = ibs_amd.theta_grid(N)
+        ref = np.stack([go.fieldline_geometry(otab, s, np.array([a]), th)[0] for s, a in zip(surf, al)])     # (lines, 8, N)
+        scale = np.abs(ref).max(axis=2, keepdims=True)
+        for lpp in (None, 1, -2, 2, 8):
+            ctx.set_option("geo_lpp", lpp)
+            r = ctx.fieldline_geometry(tabs, surf, al, th, device=dev)
+            got = r["geo"].cpu().numpy().transpose(1, 0, 2)             # planes [8][lines][N] -> (lines, 8, N)
+            err = (np.abs(got - ref) / scale).max()
+            assert err < 1e-10, (shape, N, lpp, err)
+            dP = -0.5 * np.mean((ref[:, 2] - ref[:, 7]) * ref[:, 0] ** 2, axis=1)
+            assert np.abs(r["dPdrho"].cpu().numpy() - dP).max() < 1e-12 * max(1.0, np.abs(dP).max())
+        ctx.set_option("geo_lpp", None)
