@@ -1061,9 +1061,10 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   if (nrows_mn < 0 || nrows_nyq < 0 || (nrows_mn > 0 && !rows_mn) || (nrows_nyq > 0 && !rows_nyq))
     return fail(IBS_ERR_ARG, "bad row tables");
   if (n_surf <= 0 || mnmax <= 0 || mnmax_nyq <= 0 || n_pts < 0 || !xm || !xn || !xm_nyq || !xn_nyq || !tab_mn ||
-      !tab_nyq || !scal || !pt_surf || !start || !theta || !x_opt || !f_opt || !(del_alpha > 0) || maxiter < 0)
+      !tab_nyq || !scal || !theta || !(del_alpha > 0) || maxiter < 0)
     return fail(IBS_ERR_ARG, "bad arguments");
-  if (n_pts == 0) return 0;
+  if (n_pts == 0) return 0;                   // (an empty batch -- a rank without surfaces -- has no per-point arrays to point at)
+  if (!pt_surf || !start || !x_opt || !f_opt) return fail(IBS_ERR_ARG, "bad arguments");
   ON_DEVICE(ctx);
   const bool host = (mem == IBS_MEM_HOST);
   if (N < 2) return fail(IBS_ERR_ARG, "N=%d", N);

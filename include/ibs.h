@@ -217,8 +217,11 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
  * count it has seen (csrc/ibs_refine.hpp).
  *   surface tables, mode tables, row tables: as for ibs_fieldline_geometry_f64;  pt_surf[n_pts] surface of each point;
  *   start[n_pts][2] = (alpha, theta0);  theta[N] uniform theta_PEST grid;  del_alpha (utils.py:1639: 0.004);
- *   maxiter, ftol, gtol: ball_scan.py:312-313 (30, 5e-11, 2e-8).
- *   x_opt[n_pts][2], f_opt[n_pts] = -gam at x_opt (utils.py:1728 sign), n_evals[n_pts] (optional).
+ *   maxiter, ftol, gtol: ball_scan.py:312-313 (30, 5e-11, 2e-8); like scipy's driver the limit is tested after each
+ *   completed iteration, so maxiter = 0 performs one.
+ *   x_opt[n_pts][2], f_opt[n_pts] = -gam at x_opt (utils.py:1728 sign), n_evals[n_pts] (optional).  x_opt lies in the box up
+ *   to the rounding of x + stp d (L-BFGS-B projects directions, not points).
+ *   n_pts = 0 (a rank without surfaces) is a no-op: the per-point pointers may be null, 0 rounds are returned.
  * `mem` applies to every pointer.  Synchronous.  Returns the number of rounds (>= 0) or an error (< 0). */
 int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm, const double* xn,
                    const double* xm_nyq, const double* xn_nyq, const double* tab_mn, const double* tab_nyq,

@@ -233,3 +233,59 @@ def test_geometry_on_other_mode_sets(ctx, shape):
             dP = -0.5 * np.mean((ref[:, 2] - ref[:, 7]) * ref[:, 0] ** 2, axis=1)
             assert np.abs(r["dPdrho"].cpu().numpy() - dP).max() < 1e-12 * max(1.0, np.abs(dP).max())
         ctx.set_option("geo_lpp", None)
+
+
+def test_refinement_edge_batches(ctx):
+    """ibs_refine_f64 on the batch shapes the scan driver never produces: no point, one point, every point on ONE surface,
+    starts on the corners and edges of the box (the reference's bounds, ball_scan.py:311), maxiter = 0 (one iteration, like
+    scipy's driver), host-pointer and device-pointer calls.  Checks: same optimum whatever the batch a point is refined in (1e-9 in gam:
+    the batch size picks the geometry form, and the optimizer's path reacts to its rounding), every optimum inside the box (to rounding),
+    gam(x_opt) recomputed by the scan kernel on the oracle's geometry to 1e-8, never below the start's value."""
+    import torch
+    import ibs_amd
+    from oracle import geometry_oracle as go
+    from oracle import ballooning_oracle as bo
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    svals = np.array([0.4, 0.9])
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
+    otab = go.surface_tables_from_wout(wout, svals)
+    N = 513; th = ibs_amd.theta_grid(N); dev = torch.device("cuda:0")
+    # no point
+    xo, fo, ne, rounds = ctx.refine(tabs, np.zeros(0, dtype=np.int32), np.zeros((0, 2)), th, device=dev)
+    assert xo.shape == (0, 2) and fo.shape == (0,) and rounds == 0
+    xo, fo, ne, rounds = ctx.refine(tabs, np.zeros(0, dtype=np.int32), np.zeros((0, 2)), th)
+    assert xo.shape == (0, 2) and rounds == 0
+    starts = np.array([[0.0, 0.0], [np.pi, 0.5 * np.pi], [0.0, 0.5 * np.pi], [np.pi, 0.0], [1.7, 0.0], [0.0, 0.6], [2.4, 0.9],
+                       [0.9, 0.5 * np.pi], [2.0, 1.2]])
+    ps = np.array([1, 1, 1, 1, 1, 1, 1, 1, 1], dtype=np.int32)
+
+    def gam_at(s_idx, x):
+        line = go.fieldline_geometry(otab, int(s_idx), np.array([x[0]]), th)[0]
+        dP = -0.5 * np.mean((line[2] - line[7]) * line[0] ** 2)
+        cv, gd = bo.fold_theta0(x[1], line[2], line[3], line[4], line[5], line[6])
+        return bo.gamma_ball_full(dP, th, line[0], line[1], cv, gd)[0]
+
+    xb, fb, nb, rb = ctx.refine(tabs, ps, starts, th, device=dev)                 # all nine on one surface, device pointers
+    xh, fh, nh, rh = ctx.refine(tabs, ps, starts, th)                             # host pointers
+    assert np.abs(fb - fh).max() < 1e-9 and rb >= 1
+    # (inside the box up to the rounding of x = x_k + stp d in the line search, lnsrlb: L-BFGS-B projects the search direction, not x)
+    eb = 1e-15
+    assert (xb[:, 0] >= -eb).all() and (xb[:, 0] <= np.pi + eb).all() and (xb[:, 1] >= -eb).all() and (xb[:, 1] <= 0.5 * np.pi + eb).all()
+    for k in range(len(ps)):
+        x1, f1, n1, r1 = ctx.refine(tabs, ps[k:k + 1], starts[k:k + 1], th, device=dev)       # the same point alone
+        assert abs(f1[0] - fb[k]) < 1e-9, (k, f1[0], fb[k])
+        assert abs(gam_at(ps[k], xb[k]) + fb[k]) < 1e-8                                           # f_opt = -gam(x_opt)
+        assert -fb[k] >= gam_at(ps[k], starts[k]) - 1e-12                                         # a maximiser never ends below its start
+    # maxiter = 0: scipy's driver tests the limit after each COMPLETED iteration, so it performs exactly one (as maxiter = 1;
+    # tests/test_lbfgsb2.py::test_iteration_limit_like_scipy pins that on the CPU)
+    x0, f0, n0, r0 = ctx.refine(tabs, ps[:3], starts[:3], th, maxiter=0, device=dev)
+    x1_, f1_, n1_, r1_ = ctx.refine(tabs, ps[:3], starts[:3], th, maxiter=1, device=dev)
+    assert np.array_equal(x0, x1_) and np.array_equal(f0, f1_) and np.array_equal(n0, n1_) and (n0 <= 22).all()
+    for k in range(3):
+        assert abs(gam_at(ps[k], x0[k]) + f0[k]) < 1e-8 and -f0[k] >= gam_at(ps[k], starts[k]) - 1e-12
+    # mixed surfaces, unsorted
+    psm = np.array([1, 0, 1, 0], dtype=np.int32); stm = starts[[6, 6, 8, 8]]
+    xm_, fm, nm, rm = ctx.refine(tabs, psm, stm, th, device=dev)
+    assert abs(fm[0] - fb[6]) < 1e-9 and abs(fm[2] - fb[8]) < 1e-9
+    for k in (1, 3):
+        assert abs(gam_at(0, xm_[k]) + fm[k]) < 1e-8
