@@ -126,6 +126,7 @@ struct GroupSolver {
   int Eu, Ew;
   T lo, hi, normA;          // group-replicated
   T trial_rho, trial_del;   // Rayleigh quotient / residual bound of the trial vector (setup<Src, true>; see WaveSolver::setup)
+  T trial_mrg;              // allowance for the rounding of rho's sums: (8 + N / 2) eps |A|
   T shoot_m; int shoot_e;   // shooting value of the last forward sweep (group-replicated), see WaveSolver
   T fu, fw;
   int thr;
@@ -209,6 +210,7 @@ struct GroupSolver {
     } else {
       trial_rho = T(0); trial_del = T(-1);
     }
+    trial_mrg = T(8 + N / 2) * Eps<T>::v * normA;
     return GP::sum_i(bad ? 1 : 0, lane) != 0;   // per group
   }
 
@@ -216,7 +218,7 @@ struct GroupSolver {
   // groups of a wave decide independently); groups with take == false keep their (guess, width, warm)
   __device__ __forceinline__ void trial_guess(bool take, T& guess, T& width, bool& warm) {
     const bool use = take && finite_of(trial_rho) && trial_del > T(0) && trial_del < T(0.25) * (hi - lo);
-    lo = use ? xmax(lo, trial_rho - T(8) * Eps<T>::v * normA) : lo;
+    lo = use ? xmax(lo, trial_rho - trial_mrg) : lo;
     guess = use ? trial_rho : guess;
     width = use ? T(0.25) * trial_del : width;
     warm = use ? true : warm;

@@ -356,12 +356,18 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
   bool bad;
-  if (gh) { SrcGCFH<T> srch{gs, cs, fs, gh + sysc * ld}; bad = ws.setup(srch, N, h); }   // wave-uniform branch
-  else bad = ws.setup(src, N, h);
+  // FP64 solves start from the trial vector's bracket (10 instead of 14.5 sweeps on the smooth family of config 5, 17 instead of
+  // 22.6 on the rough one: there the Rayleigh quotient alone helps, as a lower bound).  The all-FP32 kernel keeps its cold start:
+  // its stated outlier tolerance (tests/test_gpu_configs.py) was measured on that path.
+  constexpr bool kTrial = sizeof(T) == 8;
+  if (gh) { SrcGCFH<T> srch{gs, cs, fs, gh + sysc * ld}; bad = ws.template setup<SrcGCFH<T>, kTrial>(srch, N, h); }   // wave-uniform branch
+  else bad = ws.template setup<SrcGCF<T>, kTrial>(src, N, h);
   wave_lds_sync();   // every lane has taken its f chunk: the (wave-private) slot can be reused for X
   T lam = T(0);
-  if (!bad) lam = ws.solve(inf);
-  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  if (!bad) {
+    if constexpr (kTrial) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
+    else lam = ws.solve(inf);
+  } else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   if constexpr (M >= 3) {                  // f is read from its LDS slot, which X / dX reuse afterwards
     finish_chunk<T, M, SrcGCF<T>, false>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                          valid ? gam_out : nullptr, valid ? X_out : nullptr,
@@ -411,10 +417,10 @@ __global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float
   SrcGCF<T> src{gs, cs, fs};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
-  const bool bad = ws.setup(src, N, (T)h);
+  const bool bad = ws.template setup<SrcGCF<T>, true>(src, N, (T)h);
   wave_lds_sync();
   T lam = T(0);
-  if (!bad) lam = ws.solve(inf);
+  if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   if constexpr (M >= 3) {
     finish_chunk<T, M, SrcGCF<T>, false, 1, float>(ws, src, N, (T)h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
@@ -557,6 +563,8 @@ __global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, 
   SrcRows<T, M> src{row, g + sysc * ld, c + sysc * ld, f + sysc * ld, N, lane, -1};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
+  // (no trial-vector bracket here: its sums need g, c and f of a row at once, which the row-streamed set-up never holds; as a
+  //  pass of its own over global memory it cost what it saved -- 10.0 instead of 16.2 sweeps, 1.73e7 solves/s either way)
   const bool bad = setup_rows<T, M>(ws, src, N, h);
   T lam = T(0);
   if (!bad) lam = ws.solve(inf);

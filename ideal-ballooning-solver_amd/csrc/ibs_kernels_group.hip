@@ -164,9 +164,12 @@ __global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, 
   T* Xs = smem + ((size_t)wave * G + gid) * lds_pitch(N);
   SrcGlobal<T> src{g + sysc * ld, c + sysc * ld, f + sysc * ld};
   GroupSolver<T, M, P> ws;
-  const bool bad = ws.setup(src, N, h);
+  const bool bad = ws.template setup<SrcGlobal<T>, true>(src, N, h);
   int iters = 0, status = 0;
-  const T lam = ws.solve(bad, iters, status);
+  T g_ = T(0), w_ = T(0);
+  bool warm_ = false;
+  ws.trial_guess(true, g_, w_, warm_);                 // cold solves start from the trial vector's bracket
+  const T lam = ws.solve(bad, iters, status, warm_, g_, w_);
   finish_chunk_g<T, M, P, SrcGlobal<T>, false>(ws, src, N, h, Xs, lam, iters, status, sysc, valid, lam_out, gam_out, X_out,
                                          dX_out, nullptr, info_out);
 }

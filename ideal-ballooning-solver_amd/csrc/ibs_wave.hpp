@@ -339,6 +339,7 @@ struct WaveSolver {
   // Rayleigh quotient and residual bound of the trial vector x_j = sin(pi j / (N - 1)) (setup<Src, true>): lam_max >= rho,
   // and some eigenvalue lies within del of rho
   T trial_rho, trial_del;
+  T trial_mrg;     // allowance for the rounding of rho's sums (N terms): (8 + N / 2) eps |A|
   // shooting value of the last forward sweep (mantissa-like, power-of-two exponent)
   T shoot_m; int shoot_e;
 
@@ -444,6 +445,7 @@ struct WaveSolver {
     } else {
       trial_rho = T(0); trial_del = T(-1);
     }
+    trial_mrg = T(8 + N / 2) * Eps<T>::v * normA;
     IBS_PROBE_AT(9);
     return __any(bad) != 0;
   }
@@ -454,7 +456,7 @@ struct WaveSolver {
   // does not resemble) the guess is NaN, which solve() treats as a cold start.
   __device__ __forceinline__ void trial_guess(T& guess, T& width) {
     const bool use = U(finite_of(trial_rho) && trial_del > T(0) && trial_del < T(0.25) * (hi - lo));
-    if (use) lo = xmax(lo, trial_rho - T(8) * Eps<T>::v * normA);
+    if (use) lo = xmax(lo, trial_rho - trial_mrg);      // (the computed quotient is a lower bound of lam_max up to its own rounding)
     guess = use ? trial_rho : T(__builtin_nanf(""));
     width = T(0.25) * trial_del;
   }
