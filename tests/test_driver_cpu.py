@@ -1,5 +1,6 @@
 """CPU: host driver logic (sharding, argmax rule, refinement plumbing, gather, on-disk contract) with the
 oracle standing in for the GPU, including a world_size-2 gloo run."""
+import json
 import os
 import socket
 
@@ -364,3 +365,33 @@ def test_two_rank_comm_init_agrees_before_the_collective_init(failing_rank):
         assert p.exitcode == 0
     want = ("ok", 1) if failing_rank < 0 else ("refused", 0)
     assert res[0] == want and res[1] == want
+
+
+def test_bench_watchdog_prints_the_headline_once_and_leaves_with_status_zero():
+    """bench.py's N > 1 phases run under a watchdog: a phase that overruns must end with rank 0 printing the JSON line it
+    has (the headline is measured before any such phase) and status 0 -- and after the regular line has been printed, a late
+    overrun must not print a second one."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, time
+        sys.path.insert(0, %r)
+        import bench
+        out = {"metric": "m", "value": 1.0, "config": {"a": 1}}
+        dog = bench.Watchdog(int(sys.argv[1]), lambda: out)
+        if sys.argv[2] == "printed":
+            dog.line_printed()
+        dog.arm("test phase", 1)
+        time.sleep(20)
+        print("not reached")
+    ''' % root)
+    for rank, state, want in ((0, "pending", 1), (0, "printed", 0), (1, "pending", 0)):
+        r = subprocess.run([sys.executable, "-c", code, str(rank), state], capture_output=True, text=True, timeout=60)
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert r.returncode == 0 and "not reached" not in r.stdout and len(lines) == want, (rank, state, r.stdout, r.stderr)
+        if want:
+            d = json.loads(lines[0])
+            assert d["value"] == 1.0 and "test phase" in d["aborted"]
+        assert "overran" in r.stderr
