@@ -458,7 +458,7 @@ struct GroupSolver {
         const Pt b = sel(b_is_lo, Plo, Phi), a = sel(b_is_lo, Phi, Plo);
         const bool use_o = old_ok && Pold.x != a.x && Pold.x != b.x;
         T r;
-        const bool got = WS::interpolate(Pold, use_o, a, b, lo, hi, r);
+        const bool got = WS::interpolate_lazy(Pold, use_o, a, b, lo, hi, want_i, r);
         const T q = T(0.25) * (T(3) * a.x + b.x);
         const bool inside = r >= xmin(q, b.x) && r <= xmax(q, b.x);
         const T stepb = xabs(r - b.x);
@@ -470,26 +470,38 @@ struct GroupSolver {
       }
       // next shift
       const T mid = T(0.5) * (lo + hi);
+      // (the certificate placement and the warm-start prologue are skipped while no group of the wave is in that state: the
+      //  decision code between two sweeps costs these kernels as many instructions as the sweep itself)
       const bool trust = ok && near;
-      const bool fresh = trust && !cert && xabs(rho - rho_trust) > T(4096) * tol;
-      off_up = fresh ? tol : off_up; off_dn = fresh ? tol : off_dn;
-      rho_trust = trust ? rho : rho_trust;
-      const T up = xmax(rho, lo), dn = xmin(rho, hi);
-      const bool c_up = hi > up + T(2) * off_up, c_dn = lo < dn - T(2) * off_dn;
-      const T cand = c_up ? up + off_up : dn - off_dn;
-      const bool aim_ok = trust && (c_up || c_dn) && cand > lo && cand < hi;
+      bool c_up = false, aim_ok = false;
+      T cand = mid;
+      if (__any(trust)) {
+        const bool fresh = trust && !cert && xabs(rho - rho_trust) > T(4096) * tol;
+        off_up = fresh ? tol : off_up; off_dn = fresh ? tol : off_dn;
+        rho_trust = trust ? rho : rho_trust;
+        const T up = xmax(rho, lo), dn = xmin(rho, hi);
+        c_up = hi > up + T(2) * off_up;
+        const bool c_dn = lo < dn - T(2) * off_dn;
+        cand = c_up ? up + off_up : dn - off_dn;
+        aim_ok = trust && (c_up || c_dn) && cand > lo && cand < hi;
+      }
       const bool interp_now = ok && !near;
       const T nxt = aim_ok ? cand : (interp_now ? rho : mid);
       // warm start prologue: keep walking up while the count says lam_max is still above; afterwards, while lam_max
       // is not yet isolated, try the lower end of the guessed interval once
-      const bool exp_go = go && expand && C != 0 && sig + wstep < hi;
-      const bool locate = go && !exp_go && !lo1;
-      const bool tb = locate && try_below && g_below > lo && g_below < hi;
-      const bool ovr = exp_go || tb;
-      sig = go ? (exp_go ? sig + wstep : (tb ? g_below : nxt)) : sig;
-      wstep = exp_go ? T(4) * wstep : wstep;
-      expand = exp_go;
-      try_below = locate ? false : try_below;
+      bool ovr = false;
+      if (__any(expand || try_below)) {
+        const bool exp_go = go && expand && C != 0 && sig + wstep < hi;
+        const bool locate = go && !exp_go && !lo1;
+        const bool tb = locate && try_below && g_below > lo && g_below < hi;
+        ovr = exp_go || tb;
+        sig = go ? (exp_go ? sig + wstep : (tb ? g_below : nxt)) : sig;
+        wstep = exp_go ? T(4) * wstep : wstep;
+        expand = exp_go;
+        try_below = locate ? false : try_below;
+      } else {
+        sig = go ? nxt : sig;
+      }
       aimed = (go && !ovr) ? (aim_ok ? (c_up ? 1 : -1) : 0) : 0;
       was_interp = go && interp_now && !ovr;
     }

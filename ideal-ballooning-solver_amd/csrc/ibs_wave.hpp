@@ -720,6 +720,48 @@ struct WaveSolver {
     rho = pick1 ? r1 : (in2 ? r2 : r_s);
     return in1 || in2 || in_s;
   }
+  // The same for lanes that hold DIFFERENT problems (GroupSolver::solve): the parabola's root nearer to b is formed first; it is
+  // the root of smaller magnitude, so the form above takes it whenever it lies in the bracket, and the other root and the secant
+  // are only evaluated when some lane that wants a proposal (`need`) has that root outside.  Same values as interpolate().
+  __device__ __forceinline__ static bool interpolate_lazy(const Pt& o, bool use_o, const Pt& a, const Pt& b,
+                                                          T lo_, T hi_, bool need, T& rho) {
+    constexpr int L = ExpLim<T>::v;
+    int emax = a.e > b.e ? a.e : b.e;
+    if (use_o && o.e > emax) emax = o.e;
+    auto val = [&](const Pt& p) { int d = p.e - emax; d = d < -L ? -L : d; return p.m * pow2_of<T>(d); };
+    const T x2 = b.x, f1 = val(a), f2 = val(b), f0 = val(o);
+    const T h2r = x2 - a.x;
+    int k = expo_of(h2r);
+    k = k < -L ? -L : (k > L ? L : k);
+    const T sc = pow2_of<T>(-k), back = pow2_of<T>(k);
+    const T h2 = h2r * sc, h1 = (a.x - o.x) * sc;
+    const T df21 = f2 - f1;
+    const T S = h1 + h2;
+    const T QA = xfma(df21, h1, -(f1 - f0) * h2);
+    const T QB = xfma(QA, h2, df21 * h1 * S);
+    const T H = h1 * h2 * S;
+    const T disc = xfma(QB, QB, -T(4) * QA * f2 * H);
+    const T sq = approx_sqrt(xmax(disc, T(0)));
+    const T den = QB >= T(0) ? QB + sq : QB - sq;          // the denominator of larger magnitude
+    const T z1 = -T(2) * f2 * H * approx_rcp(den);          // root nearer to b
+    const T r1 = xfma(z1, back, x2);
+    const bool par = use_o && disc >= T(0) && H != T(0);
+    const bool in1 = par && finite_of(r1) && r1 > lo_ && r1 < hi_;
+    rho = r1;
+    bool got = in1;
+    if (__builtin_amdgcn_ballot_w64(need && !in1) != 0ull) {
+      const T z2 = -den * approx_rcp(T(2) * QA);            // the other root
+      const T r2 = xfma(z2, back, x2);
+      const bool in2 = par && finite_of(r2) && r2 > lo_ && r2 < hi_;
+      const T z_s = -f2 * h2 * approx_rcp(df21);            // secant
+      const T r_s = xfma(z_s, back, x2);
+      const bool in_s = finite_of(r_s) && r_s > lo_ && r_s < hi_;
+      const bool pick1 = in1 && (!in2 || xabs(z1) <= xabs(z2));
+      rho = pick1 ? r1 : (in2 ? r2 : r_s);
+      got = in1 || in2 || in_s;
+    }
+    return got;
+  }
   // Optional warm start: `guess` is an estimate of lam_max from a nearby problem (previous optimizer
   // iteration, DOF-perturbed equilibrium: sims_runner_NCSX.py:151-276 re-scans 72 perturbed equilibria),
   // `width` its expected error.  The first shift is guess + width; if the count says lam_max is still
