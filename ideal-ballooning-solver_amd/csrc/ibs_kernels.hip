@@ -442,7 +442,8 @@ __global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float
 // rate re-stages g (scaling of the eigenvector + the g dX^2 sum), then c, then f.  LDS per wave: N doubles.
 template <typename T, int M>
 __device__ __forceinline__ void stage_row(T* row, const T* __restrict__ src, int N, int lane) {
-  // batches of up to 17 coalesced loads in flight (34 VGPRs), then their LDS writes
+  // batches of up to 17 coalesced loads in flight (34 VGPRs), then their LDS writes.  (The whole row in one batch -- 33 loads at
+  // N_zeta = 2048, one exposed memory latency per row instead of two -- spills more than it hides: 1.72e7 against 1.83e7 solves/s.)
   constexpr int B = 17;
 #pragma unroll
   for (int k0 = 0; k0 <= M; k0 += B) {
@@ -473,6 +474,10 @@ struct SrcRows {
 };
 // set-up of WaveSolver from the three rows streamed through `s.row` (same quantities as WaveSolver::setup; the bounds are
 // formed from the scaled rows: c/f = (c s^2)/(f s^2), ...)
+// Also forms the Rayleigh quotient of the trial vector x_j = sin(pi j / (N - 1)) (WaveSolver::setup<Src, true>) -- from sums that
+// are SEPARABLE in (g, c, f), so they fit the three passes:  x'Tx = sum_j c_j x_j^2 - sum_edges e_{j+1/2} (x_{j+1} - x_j)^2
+// (summation by parts, x_0 = x_{N-1} = 0),  x'Fx = sum_j f_j x_j^2.  (The residual bound del is not separable: the kernel
+// estimates it from a sample of rows, see k_solve_gcf_rows.)
 template <typename T, int M>
 __device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& s, int N, T h) {
   const int lane = s.lane;
@@ -485,8 +490,18 @@ __device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& 
   const T ih2 = T(1) / (h * h);
   T esum[M], s2[M];
   bool bad = false;
+  // trial vector at grid points a and a + 1 (a = the left neighbour of this lane's first row); every pass replays the recurrence
+  T x_a, x_a1, two_cd;
+  {
+    const T dl = T(3.14159265358979323846) / T(N - 1);
+    T s0, c0, sd, cd;
+    trial_sincos(T(a) * dl, s0, c0);
+    trial_sincos(dl, sd, cd);
+    x_a = s0; x_a1 = xfma(s0, cd, c0 * sd); two_cd = T(2) * cd;
+  }
   s.hold(0);                                             // ---- g: half-grid e (utils.py:1574-1576), scaling e s_i s_{i+1} = 1
   T e_first, e_last;
+  T tE;                                                  // sum over this lane's edges of e (x_{j+1} - x_j)^2
   {
     const T g0 = s.row[lpos(a)];
     T gcur = s.row[lpos(a + 1)];
@@ -494,6 +509,8 @@ __device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& 
     e_first = e_lo;
     bad = !(g0 > T(0)) || !(gcur > T(0));
     T sc = T(1);
+    T xp = x_a, xc = x_a1;
+    tE = lane == 0 ? e_first * (xc - xp) * (xc - xp) : T(0);   // the edge below row 1 (x_0 = 0); every other edge is its lower row's
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       if ((i < M - 1) || hl) {
@@ -503,6 +520,9 @@ __device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& 
         esum[i] = e_lo + e_hi; s2[i] = sc * sc;
         sc = fast_rcp(e_hi * sc);
         gcur = gnext; e_lo = e_hi;
+        const T xn = xfma(two_cd, xc, -xp), dx = xn - xc;
+        tE = xfma(e_hi * dx, dx, tE);
+        xp = xc; xc = xn;
       } else { esum[i] = T(0); s2[i] = T(0); }
       if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -510,32 +530,44 @@ __device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& 
     e_last = e_lo;
     bad = bad || !(e_first > T(0));
   }
-  T sum_c = T(0), sum_f = T(0);
+  T sum_c = T(0), sum_f = T(0), tB = T(0), tCx = T(0);
   s.hold(2);                                             // ---- f
+  {
+    T xp = x_a, xc = x_a1;
 #pragma unroll
-  for (int i = 0; i < M; ++i) {
-    if ((i < M - 1) || hl) {
-      const T fj = s.row[lpos(a + i + 1)];
-      ws.Ph[i] = fj * s2[i];
-      sum_f += fj;
-      bad = bad || !(fj > T(0));
-    } else ws.Ph[i] = T(0);
+    for (int i = 0; i < M; ++i) {
+      if ((i < M - 1) || hl) {
+        const T fj = s.row[lpos(a + i + 1)];
+        ws.Ph[i] = fj * s2[i];
+        sum_f += fj;
+        tB = xfma(fj * xc, xc, tB);
+        bad = bad || !(fj > T(0));
+        const T xn = xfma(two_cd, xc, -xp);
+        xp = xc; xc = xn;
+      } else ws.Ph[i] = T(0);
+    }
   }
   s.hold(1);                                             // ---- c: d = c - (e_lo + e_hi)  (utils.py:1584-1592)
   T vhi = -T(1e300), vlo = -T(1e300), vna = T(0);
+  {
+    T xp = x_a, xc = x_a1;
 #pragma unroll
-  for (int i = 0; i < M; ++i) {
-    if ((i < M - 1) || hl) {
-      const T cj = s.row[lpos(a + i + 1)];
-      const T d = cj - esum[i];
-      ws.D[i] = d * s2[i];
-      const T rPh = fast_rcp(ws.Ph[i]);                  // bounds only (margins added below)
-      vhi = xmax(vhi, (cj * s2[i]) * rPh);
-      vlo = xmax(vlo, ws.D[i] * rPh);
-      vna = xmax(vna, ((xabs(d) + esum[i]) * s2[i]) * rPh);
-      sum_c += cj;
-      bad = bad || !finite_of(cj);
-    } else ws.D[i] = T(0);
+    for (int i = 0; i < M; ++i) {
+      if ((i < M - 1) || hl) {
+        const T cj = s.row[lpos(a + i + 1)];
+        const T d = cj - esum[i];
+        ws.D[i] = d * s2[i];
+        const T rPh = fast_rcp(ws.Ph[i]);                // bounds only (margins added below)
+        vhi = xmax(vhi, (cj * s2[i]) * rPh);
+        vlo = xmax(vlo, ws.D[i] * rPh);
+        vna = xmax(vna, ((xabs(d) + esum[i]) * s2[i]) * rPh);
+        sum_c += cj;
+        tCx = xfma(cj * xc, xc, tCx);
+        bad = bad || !finite_of(cj);
+        const T xn = xfma(two_cd, xc, -xp);
+        xp = xc; xc = xn;
+      } else ws.D[i] = T(0);
+    }
   }
   const T e0 = readlane_t(e_first, 0), en = readlane_t(e_last, kWave - 1);
   const T sc_all = wave_sum(sum_c), sf_all = wave_sum(sum_f);
@@ -544,7 +576,48 @@ __device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& 
   ws.lo = uniform(xmax(wave_max(vlo), (sc_all - e0 - en) / sf_all));
   ws.hi += T(8) * Eps<T>::v * ws.normA;
   ws.lo -= T(8) * Eps<T>::v * ws.normA;
+  ws.trial_rho = wave_sum(tCx - tE) / wave_sum(tB);
+  ws.trial_del = T(-1);                                  // (set by the caller)
+  ws.trial_mrg = T(8 + N / 2) * Eps<T>::v * ws.normA;
   return __any(bad) != 0;
+}
+
+// Estimate of the trial vector's residual bound del (WaveSolver::setup<Src, true>) from every fourth row, straight from global
+// memory before anything else is live: (T x)_j needs g, c and f of a row at once.  8 rows per lane at N_zeta = 2048, all 40 loads in
+// flight together.  del only sets the width of the first bracket (rho + del / 4 and up): an estimate will do.
+template <typename T>
+__device__ __forceinline__ T trial_del_sampled(const T* gq, const T* cq, const T* fq, int N, T h, int lane) {
+  constexpr int kS = 8, kStep = 4;
+  const T ih2 = T(1) / (h * h);
+  const T dl = T(3.14159265358979323846) / T(N - 1);
+  T gm[kS], g0[kS], gp[kS], cc[kS], ff[kS];
+#pragma unroll
+  for (int k = 0; k < kS; ++k) {
+    const int j = 2 + kStep * (lane + kWave * k);
+    const int jc = j <= N - 2 ? j : 2;
+    gm[k] = gq[jc - 1]; g0[k] = gq[jc]; gp[k] = gq[jc + 1]; cc[k] = cq[jc]; ff[k] = fq[jc];
+  }
+  T sj, cj, s1, c1, sW, cW;
+  trial_sincos(T(2 + kStep * lane) * dl, sj, cj);
+  trial_sincos(dl, s1, c1);
+  trial_sincos(T(kStep * kWave) * dl, sW, cW);
+  T tA = T(0), tB = T(0), tC = T(0);
+#pragma unroll
+  for (int k = 0; k < kS; ++k) {
+    const int j = 2 + kStep * (lane + kWave * k);
+    if (j <= N - 2) {
+      const T e_lo = T(0.5) * (gm[k] + g0[k]) * ih2, e_hi = T(0.5) * (g0[k] + gp[k]) * ih2;
+      const T d = cc[k] - (e_lo + e_hi);
+      const T xm = xfma(sj, c1, -cj * s1), xp = xfma(sj, c1, cj * s1);            // sin((j -+ 1) dl)
+      const T Tx = xfma(e_lo, xm, xfma(d, sj, e_hi * xp));
+      tA = xfma(sj, Tx, tA); tB = xfma(ff[k] * sj, sj, tB); tC = xfma(Tx * fast_rcp(ff[k]), Tx, tC);
+    }
+    const T sn = xfma(sj, cW, cj * sW);
+    cj = xfma(cj, cW, -sj * sW); sj = sn;
+  }
+  const T A = wave_sum(tA), B = wave_sum(tB), C = wave_sum(tC);
+  const T rho_s = A / B;
+  return approx_sqrt(xmax(xfma(-rho_s, A, C), T(0)) / B);
 }
 
 template <typename T, int M>
@@ -563,11 +636,13 @@ __global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, 
   SrcRows<T, M> src{row, g + sysc * ld, c + sysc * ld, f + sysc * ld, N, lane, -1};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
-  // (no trial-vector bracket here: its sums need g, c and f of a row at once, which the row-streamed set-up never holds; as a
-  //  pass of its own over global memory it cost what it saved -- 10.0 instead of 16.2 sweeps, 1.73e7 solves/s either way)
+  // trial-vector bracket (WaveSolver::trial_guess): rho from set-up's separable sums, del from a sample of rows (a full pass over
+  // global memory for del cost what the bracket saved: 10.0 instead of 16.2 sweeps, 1.73e7 solves/s either way)
+  const T t_del = trial_del_sampled<T>(src.gg, src.cg, src.fg, N, h, lane);
   const bool bad = setup_rows<T, M>(ws, src, N, h);
+  ws.trial_del = t_del;
   T lam = T(0);
-  if (!bad) lam = ws.solve(inf);
+  if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   src.hold(0);                                           // g: the eigenvector's scaling is rebuilt from it, then the g dX^2 sum
   finish_chunk<T, M, SrcRows<T, M>, false, 3>(ws, src, N, h, row, lam, inf, sysc, valid ? lam_out : nullptr,
