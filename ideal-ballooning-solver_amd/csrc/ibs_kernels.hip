@@ -638,16 +638,24 @@ __global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, 
   SolveInfo inf{0, 0};
   // trial-vector bracket (WaveSolver::trial_guess): rho from set-up's separable sums, del from a sample of rows (a full pass over
   // global memory for del cost what the bracket saved: 10.0 instead of 16.2 sweeps, 1.73e7 solves/s either way)
+  IBS_PROBE_AT(0);                                       // (phase stamps: tools/rows_probe.py, debug builds only)
   const T t_del = trial_del_sampled<T>(src.gg, src.cg, src.fg, N, h, lane);
+  IBS_PROBE_AT(1);
   const bool bad = setup_rows<T, M>(ws, src, N, h);
   ws.trial_del = t_del;
+  IBS_PROBE_AT(2);
   T lam = T(0);
   if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  IBS_PROBE_AT(3);
+  // (the first batch of the next row requested while the current row is worked on -- to hide one of the two exposed memory
+  //  latencies per staged row, 33 of this kernel's 63 us -- was built and measured: the 34 registers it keeps live cost more in
+  //  AGPR traffic than the latency it hides, 1.71e7 against 1.83e7 solves/s)
   src.hold(0);                                           // g: the eigenvector's scaling is rebuilt from it, then the g dX^2 sum
   finish_chunk<T, M, SrcRows<T, M>, false, 3>(ws, src, N, h, row, lam, inf, sysc, valid ? lam_out : nullptr,
                                               valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
                                               nullptr, valid ? info_out : nullptr);
+  IBS_PROBE_AT(4);
 }
 
 // ---------------------------------------------------------------- geometry-fed theta0 scan
