@@ -51,6 +51,7 @@ struct ibs_options {
   int geo_lpp = 0;        // lanes per grid point of the geometry kernel: 1 | 2 | 4
   int gcf_rows = -1;      // raw systems on long grids: -1 / 1 = row-streamed kernel, 0 = the 3-row staging of k_solve_gcf
   int pack_mode = 0;      // hand-off of the fused scan + argmax: 1 = write-through + sc1 loads, 2 = release / acquire fences
+  int refine_tangent = -1; // refinement: alpha-tangent of a point staged in LDS (1) or read from global memory in the sums (0); -1 = by batch size
   double chain_w1 = 0.25, chain_w2 = 1.0;   // relative widths of the chain's warm starts
 };
 
@@ -408,6 +409,7 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   else if (n == "geo_lpp") c->opt.geo_lpp = reset ? c->opt_created.geo_lpp : (int)value;
   else if (n == "gcf_rows") c->opt.gcf_rows = reset ? c->opt_created.gcf_rows : (int)value;
   else if (n == "pack_mode") c->opt.pack_mode = reset ? c->opt_created.pack_mode : (int)value;
+  else if (n == "refine_tangent") c->opt.refine_tangent = reset ? c->opt_created.refine_tangent : (int)value;
   else if (n == "chain_w1") c->opt.chain_w1 = reset ? c->opt_created.chain_w1 : value;
   else if (n == "chain_w2") c->opt.chain_w2 = reset ? c->opt_created.chain_w2 : value;
   else if (n == "all" && reset) c->opt = c->opt_created;
@@ -1083,7 +1085,11 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   // LDS of the evaluation kernel: centre line (7 derived arrays) + eigenfunction + alpha-tangent (4 arrays) when they fit
   const size_t row_b = (size_t)ibs::lds_pitch(N) * sizeof(double);
   const size_t lds_extra = 32 * sizeof(double) + sizeof(RefineState);
-  const int lds_tangent = (12 * row_b + lds_extra <= (size_t)ctx->lds_per_block) ? 1 : 0;
+  // The alpha-tangent (4 more rows) in LDS saves the evaluation's sums a second trip to global memory but leaves room for ONE
+  // block per CU at N = 969 (105 of 160 KB); without it two fit (70 KB each).  Batches with more points than CUs take the
+  // second form: their first rounds would otherwise run in two waves of blocks.
+  int lds_tangent = (12 * row_b + lds_extra <= (size_t)ctx->lds_per_block) ? 1 : 0;
+  if (ctx->opt.refine_tangent == 0 || (ctx->opt.refine_tangent < 0 && n_pts > ctx->n_cu)) lds_tangent = 0;
   if (8 * row_b + lds_extra > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
   // every round = one objective/gradient evaluation of every point still in the batch.  An iteration takes at most
   // maxls = 20 line-search evaluations, and once more after a memory restart
