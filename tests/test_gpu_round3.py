@@ -283,6 +283,11 @@ def test_refinement_edge_batches(ctx):
     assert np.array_equal(x0, x1_) and np.array_equal(f0, f1_) and np.array_equal(n0, n1_) and (n0 <= 22).all()
     for k in range(3):
         assert abs(gam_at(ps[k], x0[k]) + f0[k]) < 1e-8 and -f0[k] >= gam_at(ps[k], starts[k]) - 1e-12
+    # the alpha-tangent read from global memory in the sums (the form batches larger than the chip take) against staged in LDS
+    ctx.set_option("refine_tangent", 0)
+    xt, ft, nt, rt = ctx.refine(tabs, ps, starts, th, device=dev)
+    ctx.set_option("refine_tangent", None)
+    assert np.abs(ft - fb).max() < 1e-9
     # mixed surfaces, unsorted
     psm = np.array([1, 0, 1, 0], dtype=np.int32); stm = starts[[6, 6, 8, 8]]
     xm_, fm, nm, rm = ctx.refine(tabs, psm, stm, th, device=dev)

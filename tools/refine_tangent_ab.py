@@ -1,8 +1,10 @@
+"""ibs_refine_f64 with the alpha-tangent staged in LDS (option refine_tangent = 1: one evaluation block per CU at N = 969) against read
+from global memory in the sums (0: two blocks per CU) on 365 and 2,000 points."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, ibs_amd
 ctx = ibs_amd.Context(0); dev = torch.device("cuda", 0)
-wout = dict(np.load("/root/repo/tests/golden/G8_wout_ncsx_op.npz"))
+wout = dict(np.load(os.path.join(ROOT, "tests/golden/G8_wout_ncsx_op.npz")))
 N, ns = 969, 5
 svals = np.linspace(0.5, 0.95, ns); th = ibs_amd.theta_grid(N)
 for n_eq in (73, 400):
