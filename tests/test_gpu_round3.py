@@ -294,3 +294,24 @@ def test_refinement_edge_batches(ctx):
     assert abs(fm[0] - fb[6]) < 1e-9 and abs(fm[2] - fb[8]) < 1e-9
     for k in (1, 3):
         assert abs(gam_at(0, xm_[k]) + fm[k]) < 1e-8
+
+
+def test_refinement_is_bitwise_repeatable(ctx):
+    """The rounds are plain launches enqueued ahead of the device, the batch is re-packed by whichever block finishes last and the
+    geometry form follows the batch size: none of it may leak into the results.  Same call, same bits (x_opt, f_opt, evaluation
+    counts), for a batch smaller and one larger than the number of CUs."""
+    import torch
+    import ibs_amd
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    dev = torch.device("cuda:0")
+    N = 513; th = ibs_amd.theta_grid(N)
+    svals = np.linspace(0.3, 0.9, 4)
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
+    rng = np.random.default_rng(5)
+    for n in (7, 300):
+        ps = rng.integers(0, len(svals), n).astype(np.int32)
+        st = np.stack([rng.uniform(0.2, 3.0, n), rng.uniform(0.05, 1.5, n)], axis=1)
+        runs = [ctx.refine(tabs, ps, st, th, device=dev) for _ in range(3)]
+        for r in runs[1:]:
+            assert np.array_equal(runs[0][0], r[0]) and np.array_equal(runs[0][1], r[1]) and np.array_equal(runs[0][2], r[2]) and runs[0][3] == r[3]
+        assert np.isfinite(runs[0][1]).all()
