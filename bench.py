@@ -33,59 +33,74 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
-    (tools/profile_run.py -> tools/pmc_summary.py -> profiles/pmc_current.json); None if absent."""
-    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
-    if not os.path.exists(fn):
-        return None
-    for k, v in json.load(open(fn)).items():
-        if k.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
-            return v["hbm_bytes_per_launch"]
-    return None
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_current.json")
+ISSUE_PEAK = 256 * 4 * 2.4e9 / 4      # wave64 VALU instructions per second: 256 CUs x 4 SIMDs, one per 4 clocks at 2.4 GHz
+
+
+def _pmc_file():
+    if not hasattr(_pmc_file, "cache"):
+        _pmc_file.cache = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
+    return _pmc_file.cache
 
 
 def pmc_set_name():
     """name of the profile set profiles/pmc_current.json was summarised from (its "_set" entry), or 'unnamed'"""
-    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
-    if os.path.exists(fn):
-        v = json.load(open(fn)).get("_set")
-        if isinstance(v, str):
-            return v
-    return "unnamed"
+    d = _pmc_file() or {}
+    return d["_set"] if isinstance(d.get("_set"), str) else "unnamed"
 
 
-def pmc_value(kernel_prefix, key):
-    """any other figure of the committed PMC summary for a kernel (None if absent)"""
-    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
-    if os.path.exists(fn):
-        for k, v in json.load(open(fn)).items():
-            if k.startswith(kernel_prefix) and key in v:
-                return v[key]
-    return None
+def pmc_entry(kernel, waves):
+    """The committed rocprofv3 --pmc figures of ONE leg (tools/profile_run.py -> tools/pmc_summary.py ->
+    profiles/pmc_current.json): the entry whose kernel name is EXACTLY `kernel` ("ibs::k_gamma_scan<double, 8>") and whose
+    launches held `waves` waves (SQ_WAVES, i.e. the leg's own batch size) and were all alike (a persistent kernel's grid does
+    not show the batch size; the spread of its launches' instruction counts does).  Returns (entry, None) or (None, reason):
+    a leg never quotes another kernel's or another batch size's counters."""
+    d = _pmc_file()
+    if d is None:
+        return None, "profiles/pmc_current.json is absent"
+    cands = [v for k, v in d.items() if isinstance(v, dict) and v.get("kernel", k.split(" @")[0]) == kernel]
+    if not cands:
+        return None, "no PMC entry for the kernel '%s'" % kernel
+    fit = [v for v in cands if "SQ_WAVES" in v and abs(v["SQ_WAVES"]["mean"] - waves) < 0.5]
+    if len(fit) != 1:
+        return None, "%d PMC entries of '%s' hold %d waves per launch (found: %s)" % (
+            len(fit), kernel, waves, sorted(int(v["SQ_WAVES"]["mean"]) for v in cands if "SQ_WAVES" in v))
+    if fit[0].get("valu_spread", 1.0) > 1.05:
+        return None, "the PMC entry of '%s' mixes launches of different batch sizes (instruction counts spread %.2fx)" % (
+            kernel, fit[0]["valu_spread"])
+    return fit[0], None
 
 
-def pmc_kernel_name(kernel_prefix, default):
-    """full name of the kernel the committed PMC pass saw for this leg (the library picks lanes per system)"""
-    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
-    if os.path.exists(fn):
-        for k in json.load(open(fn)):
-            if k.startswith(kernel_prefix):
-                return k.replace("ibs::", "")
-    return default
+def pmc_fields(kernel, waves, ms, alg_bytes=None):
+    """roofline fields every leg with a PMC entry reports: `traffic` (HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE in
+    KiB, the gfx950 correction of MI355X_MICROARCH.md), its ratio to the algorithmic bytes, VALU instructions per wave and
+    the bound that binds: `valu_issue` = wave64 VALU instructions issued per second (count from the PMC pass, time from
+    THIS run) against one instruction per SIMD per 4 clocks."""
+    e, why = pmc_entry(kernel, waves)
+    src = "profiles/pmc_current.json (committed rocprofv3 --pmc passes of this leg at this size, set %s; replayed, not " \
+          "measured by this run)" % pmc_set_name()
+    if e is None:
+        return dict(traffic=None, counters_error=why, counters_kernel=kernel, counters_waves_per_launch=waves)
+    out = dict(traffic=e.get("hbm_bytes_per_launch"), counters_kernel=kernel, counters_waves_per_launch=waves,
+               counters_source=src, valu_insts_per_wave=e.get("valu_insts_per_wave"),
+               valu_busy_frac=e.get("valu_busy_frac_of_wave_lifetime"))
+    if alg_bytes and out["traffic"]:
+        out["traffic_over_algorithmic"] = out["traffic"] / alg_bytes
+    if "SQ_INSTS_VALU" in e and ms:
+        ach = e["SQ_INSTS_VALU"]["mean"] / (ms * 1e-3)
+        out["valu_issue"] = dict(achieved=ach, peak=ISSUE_PEAK, unit="wave-instructions/s", frac=ach / ISSUE_PEAK)
+    return out
 
 
-def valu_issue_frac(kernel_prefix, n_sys, ms):
-    """wave64 VALU instructions per second of a launch (instruction count per system from the committed PMC pass of
-    the same workload) against the chip's issue peak: 256 CUs x 4 SIMDs x one instruction per 4 clocks at 2.4 GHz"""
-    fn = os.path.join(ROOT, "profiles", "pmc_current.json")
-    if not os.path.exists(fn):
-        return None
-    for k, v in json.load(open(fn)).items():
-        if k.startswith(kernel_prefix) and "SQ_INSTS_VALU" in v:
-            per_launch = v["SQ_INSTS_VALU"]["mean"]          # the PMC pass ran the same 262,144-system launch
-            return per_launch / (ms * 1e-3) / (256 * 4 * 2.4e9 / 4)
-    return None
+def hbm_roofline(alg_bytes, ms, bound, kernel, waves, **extra):
+    """the `roofline` object of a leg: HBM figures on ALGORITHMIC bytes (`achieved`, `peak`, `frac` = `hbm_frac`, the
+    task's definition) whatever binds, `bound` = what does bind, and the PMC fields of the leg's kernel"""
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    out = dict(bound=bound, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, hbm_frac=gbs / HBM_PEAK_GBS,
+               kernel=kernel.replace("ibs::", ""), algorithmic_bytes_per_launch=alg_bytes)
+    out.update(pmc_fields(kernel, waves, ms, alg_bytes))
+    out.update(extra)
+    return out
 
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -178,14 +193,10 @@ def stress(ctx, device, n_sys, family, reps=3):
     torch.cuda.synchronize()
     ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     bytes_per = (3 * N + 1) * 8
-    gbs = n_sys * bytes_per / (ms * 1e-3) / 1e9
+    kern, waves = ctx.last_launch()
     return dict(workload="config 5 raw (g,c,f), %s family, %d systems, N_zeta=512, f64" % (family, n_sys),
                 solves_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms, mean_sweeps=sweeps, nonconverged=nbad,
-                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                              traffic=(pmc_traffic("ibs::k_solve_gcf") if n_sys == 262144 and family == "smooth"
-                                       else None),
-                              kernel=pmc_kernel_name("ibs::k_solve_gcf", "k_solve_gcf"), bytes_per_solve=bytes_per,
-                              valu_issue_frac=valu_issue_frac("ibs::k_solve_gcf", n_sys, ms) if family == "smooth" and n_sys == 262144 else None))
+                roofline=hbm_roofline(n_sys * bytes_per, ms, "valu_issue", kern, waves, bytes_per_solve=bytes_per))
 
 
 def sturm_sweep(ctx, device, n_sys, reps=5):
@@ -209,12 +220,10 @@ def sturm_sweep(ctx, device, n_sys, reps=5):
     torch.cuda.synchronize()
     ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
     bytes_per = (3 * N + 1) * 8 + 4
-    gbs = n_sys * bytes_per / (ms * 1e-3) / 1e9
+    kern, waves = ctx.last_launch()
     return dict(workload="one Sturm-count sweep per system, %d random systems, N_zeta=512, f64" % n_sys,
                 sweeps_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms,
-                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                              traffic=(pmc_traffic("ibs::k_sturm_count<double") if n_sys == 262144 else None),
-                              kernel="k_sturm_count<double,8>", bytes_per_sweep=bytes_per))
+                roofline=hbm_roofline(n_sys * bytes_per, ms, "hbm", kern, waves, bytes_per_sweep=bytes_per))
 
 
 def warm_rescan(ctx, device, h, geo7, dP_d, th0_d, reps=20):
@@ -267,13 +276,12 @@ def scan_large(ctx, device, geo7, dP_d, reps=3):
     ms = float(np.min([a.elapsed_time(b) for a, b in evs]))
     n = out["gam"].numel()
     bytes_per = (7 * NPTS * 8 + 8) / 16 + 8
-    gbs = n * bytes_per / (ms * 1e-3) / 1e9
+    kern, waves = ctx.last_launch()
     return dict(workload="%d lines x 16 theta0 = %d solves, N_zeta=512, f64" % (g7[0].shape[0], n),
                 solves_per_s=n / (ms * 1e-3), ms_per_launch_incl_host=ms,
                 mean_sweeps=float((out["info"] & 0xffff).double().mean().item()),
                 nonconverged=int(((out["info"] >> 16) != 0).sum().item()),
-                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                              traffic=None, kernel="k_gamma_scan_g_chain<double,16,32>", bytes_per_solve=bytes_per))
+                roofline=hbm_roofline(n * bytes_per, ms, "valu_issue", kern, waves, bytes_per_solve=bytes_per))
 
 
 def batch_scaling(ctx, device, h, geo7, dP_d, th0_d):
@@ -343,8 +351,10 @@ def ncsx_pipeline(ctx, device):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
             r = ctx.fieldline_geometry(tabs, surf, al, th_d, device=device)
+            k_geo = ctx.last_launch()
             e[1].record()
             sc = ctx.gamma_scan(th[1] - th[0], *[r["geo"][k] for k in range(7)], r["dPdrho"], t0, want_info=True)
+            k_scan = ctx.last_launch()
             e[2].record()
             idx, val = ctx.surface_argmax(sc["gam"].reshape(ns, -1))
             e[3].record()
@@ -354,15 +364,14 @@ def ncsx_pipeline(ctx, device):
                 best = t
         n = ns * na * nt0
         bytes_per = (7 * N * 8 + 8) / nt0 + 8
-        gbs = n * bytes_per / (best[1] * 1e-3) / 1e9
         leg = dict(workload="%d surfaces x %d alpha x %d theta0, N=%d, NCSX_op wout tables" % (ns, na, nt0, N),
                    geometry_ms=best[0], geometry_points_per_s=ns * na * N / (best[0] * 1e-3),
                    scan_ms=best[1], scan_solves_per_s=n / (best[1] * 1e-3), argmax_ms=best[2],
                    mean_sweeps=float((sc["info"] & 0xffff).double().mean().item()),
                    nonconverged=int(((sc["info"] >> 16) != 0).sum().item()),
-                   roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                                 traffic=None, bytes_per_solve=bytes_per,
-                                 kernel="k_gamma_scan_chain (4 theta0 per wave)" if n >= 8192 else "k_gamma_scan"))
+                   roofline=hbm_roofline(n * bytes_per, best[1], "valu_issue", *k_scan, bytes_per_solve=bytes_per),
+                   # the geometry kernel writes 8 arrays per grid point (its algorithmic bytes); what binds is FP64 issue
+                   geometry_roofline=hbm_roofline(ns * na * N * 64.0, best[0], "valu_issue", *k_geo, bytes_per_point=64))
         if tag == "reference_batch":
             scan = ibs_amd.BallooningScan(ctx, None, th, svals, nalpha=na, ntheta0=nt0, tables=tabs, device=device)
             tab = sc["gam"].reshape(ns, na, nt0).cpu().numpy()
@@ -573,8 +582,10 @@ def c2_refined_leg(ctx, device, rank, world, dist, fence, passes=3):
 class Watchdog:
     """Bounds the phases that can hang for ever inside a collective (a second RCCL communicator next to torch's, the first
     multi-rank gathers of a new build).  When a phase overruns, rank 0 prints the JSON line it has so far -- the headline
-    number was measured BEFORE any such phase starts -- and every rank leaves with status 0: the run is not lost.
-    (Nothing is re-executed: a process that has touched the GPU must not exec.)"""
+    number was measured BEFORE any such phase starts, so the measurement is not lost -- and every rank leaves with status
+    EXIT_CODE (5): a hung run must not look like a healthy one.  (Nothing is re-executed: a process that has touched the
+    GPU must not exec.)"""
+    EXIT_CODE = 5
 
     def __init__(self, rank, get_line):
         import threading
@@ -603,7 +614,7 @@ class Watchdog:
                         print(text, flush=True)
                 print("bench.py: rank %d: phase '%s' overran %d s, leaving" % (self.rank, phase, seconds), file=sys.stderr, flush=True)
             finally:
-                os._exit(0)
+                os._exit(self.EXIT_CODE)
         self.timer = self.threading.Timer(seconds, fire)
         self.timer.daemon = True
         self.timer.start()
@@ -782,6 +793,7 @@ def main():
         c.record(); d.record()
     torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in un])) / per
+    head_kernel, head_waves = ctx.last_launch()          # the step's one kernel: ibs::k_gamma_scan<double, 8>, 1,024 waves
     empty_ms = float(np.median([c.elapsed_time(d) for c, d in emp]))
     gather_ok = roundtrip_ok() if use_dist else None
     seen = ranks_seen(False) if use_dist else 1
@@ -793,10 +805,7 @@ def main():
     if rank == 0:
         bytes_per_solve = (7 * NPTS * 8 + 8) / N_THETA0 + 8            # geometry-fed path
         alg_bytes = n_solves * bytes_per_solve
-        gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
-        pmc_src = "profiles/pmc_current.json (committed rocprofv3 --pmc passes of this workload, set %s; replayed, " \
-                  "not measured by this run)" % pmc_set_name()
-        rp_ms, rp_file = rocprof_kernel_ms("k_gamma_scan<double, 8>")
+        rp_ms, rp_file = rocprof_kernel_ms(head_kernel.replace("ibs::", ""))
         out = {
             "metric": "field-line eigenvalue solves/sec (N_zeta=512)",
             "value": n_ranks * n_solves * args.steps / dt,
@@ -816,37 +825,24 @@ def main():
                        "nonconverged": nbad, "ranks_in_collective": seen, "allgather_roundtrip_ok": gather_ok,
                        "untimed_spinup_steps": args.warmup + n_spin,
                        "headline_gather": "torch_in_stream" if use_dist else None},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("ibs::k_gamma_scan<double"),
-                         "traffic_source": pmc_src,
-                         "kernel": "k_gamma_scan<double,8> (scan + fused per-surface argmax)", "kernel_ms": kern_ms,
-                         "kernel_ms_how": "untimed pass after the timed region: 25 HIP-event brackets around 8 back-to-back "
-                                          "launches each, / 8 (includes the launch gap; rocprofv3's kernel-trace average "
-                                          "of the same kernel: kernel_ms_rocprof)",
-                         "kernel_ms_rocprof": rp_ms, "kernel_ms_rocprof_source": ("profiles/" + rp_file) if rp_file else None,
-                         "event_bracket_ms": empty_ms,
-                         "kernel_ms_live_raw": kern_ms_live,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         # what actually binds (committed PMC pass, profiles/pmc_current.json): VALU instructions per
-                         # wave and the fraction of the wave's lifetime its SIMD's VALU is busy (1 wave per SIMD here)
-                         "valu_insts_per_wave": pmc_value("ibs::k_gamma_scan<double", "valu_insts_per_wave"),
-                         "valu_busy_frac": pmc_value("ibs::k_gamma_scan<double", "valu_busy_frac_of_wave_lifetime"),
-                         "counters_source": pmc_src,
-                         "note": "FP64-VALU-issue bound, not HBM bound (DESIGN.md 4); every step re-scans the same "
-                                 "3.7 MB of geometry, which stays in L2 / Infinity Cache: 'HBM' is nominal for this leg"},
+            # `bound` = what binds this launch (FP64 VALU issue: 1,024 waves on 1,024 SIMDs); achieved / peak /
+            # frac (= hbm_frac) are the HBM figures on algorithmic bytes the task defines; `valu_issue` prices the launch
+            # against the binding bound.  Counters: the PMC entry of EXACTLY this kernel at this launch size.
+            "roofline": hbm_roofline(
+                alg_bytes, kern_ms, "valu_issue", head_kernel, head_waves,
+                kernel_role="scan + fused per-surface argmax, one launch", kernel_ms=kern_ms,
+                kernel_ms_how="untimed pass after the timed region: 25 HIP-event brackets around 8 back-to-back launches "
+                              "each, / 8 (includes the launch gap; rocprofv3's kernel-trace average of the same kernel: "
+                              "kernel_ms_rocprof)",
+                kernel_ms_rocprof=rp_ms, kernel_ms_rocprof_source=("profiles/" + rp_file) if rp_file else None,
+                event_bracket_ms=empty_ms, kernel_ms_live_raw=kern_ms_live,
+                note="FP64-VALU-issue bound, not HBM bound (DESIGN.md 4); every step re-scans the same 3.7 MB of geometry, "
+                     "which stays in L2 / Infinity Cache: the HBM figures are nominal for this leg"),
         }
-        # the bound that does bind: wave64 VALU instructions issued per second against one instruction per SIMD per
-        # 4 clocks (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz), instruction count from the committed PMC pass
-        vi = pmc_value("ibs::k_gamma_scan<double", "valu_insts_per_wave")
-        if vi:
-            peak_issue = 256 * 4 * 2.4e9 / 4
-            ach = vi * n_solves / (kern_ms * 1e-3)
-            out["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak_issue, "unit": "wave-instructions/s",
-                                             "frac": ach / peak_issue}
 
     # ---- N > 1: everything after the headline runs under a watchdog -- `out` already holds the headline, and a phase that
     # overruns (a rank that left a leg early while the others wait in its collective, a communicator that never comes up)
-    # ends with rank 0 printing what it has and every rank leaving with status 0
+    # ends with rank 0 printing what it has and every rank leaving with status 5 (Watchdog.EXIT_CODE)
     dog = Watchdog(rank, lambda: out)
     if use_dist:
         for key, leg, label in (("ncsx_c2_sharded", lambda: c2_sharded_leg(ctx, device, rank, world, dist, fence, native=False),

@@ -37,6 +37,7 @@ SYMBOLS = {
     "ibs_lbfgsb2_step": (C.c_int, [_P, _D, _P, _P]),
     "ibs_lbfgsb2_result": (C.c_int, [_P, _P, _P, _P]),
     "ibs_device_count": (C.c_int, []),
+    "ibs_last_launch": (C.c_int, [C.c_char_p, _I32, C.POINTER(_I64), C.POINTER(_I32)]),
     "ibs_solve_gcf_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
     "ibs_solve_gcfh_f64": (C.c_int, [_P, _I64, _I32, _D, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),
     "ibs_solve_gcf_f32": (C.c_int, [_P, _I64, _I32, C.c_float, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I32]),

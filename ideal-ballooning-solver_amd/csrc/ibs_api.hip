@@ -24,6 +24,18 @@ LaunchTable& launch_table() {
   static LaunchTable t{};
   return t;
 }
+LaunchNote& last_launch() {
+  static thread_local LaunchNote n{};
+  return n;
+}
+void note_launch(long blocks, int threads, const char* fmt, ...) {
+  LaunchNote& n = last_launch();
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(n.name, sizeof(n.name), fmt, ap);
+  va_end(ap);
+  n.blocks = blocks; n.threads = threads;
+}
 }  // namespace ibs
 
 static thread_local std::string g_err;
@@ -351,6 +363,14 @@ extern "C" {
 
 int ibs_version(void) { return 100; }
 const char* ibs_last_error(void) { return g_err.c_str(); }
+
+int ibs_last_launch(char* name, int32_t len, int64_t* blocks, int32_t* threads) {
+  const ibs::LaunchNote& n = ibs::last_launch();
+  if (name && len > 0) { strncpy(name, n.name, (size_t)len - 1); name[len - 1] = 0; }
+  if (blocks) *blocks = n.blocks;
+  if (threads) *threads = n.threads;
+  return 0;
+}
 
 int ibs_device_count(void) {
   int n = 0;
@@ -1187,10 +1207,10 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   // Rounds enqueued after the last point has finished find an empty batch and return at once.
   constexpr int kLook = 1;
   int enq = 0, rounds = -1;
-  const auto t_start = std::chrono::steady_clock::now();
   while (enq < max_rounds) {
     const int need_r = enq > kLook ? enq - kLook : 0;
     int spins = 0;
+    const auto t_start = std::chrono::steady_clock::now();       // (the limit is per awaited round, not per call)
     while (hist[need_r] == 0) {
       if (++spins > 2000) {
         std::this_thread::yield();

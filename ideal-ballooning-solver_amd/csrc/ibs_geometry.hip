@@ -941,19 +941,20 @@ hipError_t launch_geometry(GeoArgs& a, hipStream_t st, int n_cu) {
     long nblk = units;
     if (nblk > n_cu) nblk = n_cu;
     if (nblk < 1) nblk = 1;
-    auto go = [&](auto kern) {
+    auto go = [&](auto kern, int ppl, int lpp, int maxr) {
       hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e1 != hipSuccess) return e1;
       hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kGeoBlock), lds, st, b, (const double*)a.img[li]);
+      note_launch(nblk, kGeoBlock, "ibs::k_geo_rows<%d, %d, %d>", ppl, lpp, maxr);
       return hipSuccess;
     };
     hipError_t e2;
-    if (a.nrows_mn > 12) e2 = go(k_geo_rows<1, 1, 24>);
-    else if (f.ppl == 2) e2 = go(k_geo_rows<2, 1, 12>);
-    else if (f.lpp == 1) e2 = go(k_geo_rows<1, 1, 12>);
-    else if (f.lpp == 2) e2 = go(k_geo_rows<1, 2, 12>);
-    else if (f.lpp == 4) e2 = go(k_geo_rows<1, 4, 12>);
-    else e2 = go(k_geo_rows<1, 8, 12>);
+    if (a.nrows_mn > 12) e2 = go(k_geo_rows<1, 1, 24>, 1, 1, 24);
+    else if (f.ppl == 2) e2 = go(k_geo_rows<2, 1, 12>, 2, 1, 12);
+    else if (f.lpp == 1) e2 = go(k_geo_rows<1, 1, 12>, 1, 1, 12);
+    else if (f.lpp == 2) e2 = go(k_geo_rows<1, 2, 12>, 1, 2, 12);
+    else if (f.lpp == 4) e2 = go(k_geo_rows<1, 4, 12>, 1, 4, 12);
+    else e2 = go(k_geo_rows<1, 8, 12>, 1, 8, 12);
     if (e2 != hipSuccess) return e2;
     if (b.j_end < a.N) {
       GeoArgs c = a;
@@ -963,6 +964,7 @@ hipError_t launch_geometry(GeoArgs& a, hipStream_t st, int n_cu) {
     }
   } else {
     hipLaunchKernelGGL(k_fieldline_geometry, dim3((a.N + 255) / 256, a.n_lines), dim3(256), 0, st, a);
+    note_launch((long)((a.N + 255) / 256) * a.n_lines, 256, "ibs::k_fieldline_geometry");
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -1310,6 +1310,7 @@ static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
                      a.lam, a.gam, a.X, a.dX, a.info, a.gh);
+  note_launch(nblk, wpb * 64, "ibs::k_solve_gcf<%s, %d>", type_name<T>(), IBS_M);
   return hipGetLastError();
 }
 static hipError_t launch_gcf_wide(const GcfArgs<float>& a, hipStream_t st) {
@@ -1321,6 +1322,7 @@ static hipError_t launch_gcf_wide(const GcfArgs<float>& a, hipStream_t st) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
                      a.lam, a.gam, a.X, a.dX, a.info);
+  note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_wide<%d>", IBS_M);
   return hipGetLastError();
 }
 template <typename T>
@@ -1334,6 +1336,7 @@ static hipError_t launch_gcf_rows(const GcfArgs<T>& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
                        a.lam, a.gam, a.X, a.dX, a.info);
+    note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_rows<%s, %d>", type_name<T>(), IBS_M);
     return hipGetLastError();
   } else {
     return hipErrorInvalidValue;
@@ -1350,6 +1353,7 @@ static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
                      a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
                      a.dX, a.dth0, a.info, a.lam_guess, a.guess_width, a.lines_per_surf, a.surf_counter, a.pack, a.pack_mode);
+  note_launch(grid.x, wpb * 64, "ibs::k_gamma_scan<%s, %d>", type_name<T>(), IBS_M);
   return hipGetLastError();
 }
 template <typename T>
@@ -1365,6 +1369,7 @@ static hipError_t launch_scan_chain(const ScanArgs<T>& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
                      a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
                      a.dX, a.dth0, a.info, chain, a.chain_w1, a.chain_w2);
+  note_launch(grid.x, wpb * 64, "ibs::k_gamma_scan_chain<%s, %d>", type_name<T>(), IBS_M);
   return hipGetLastError();
 }
 template <typename T>
@@ -1377,6 +1382,7 @@ static hipError_t launch_sturm(const SturmArgs<T>& a, hipStream_t st) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
                      a.shift, a.count);
+  note_launch(nblk, wpb * 64, "ibs::k_sturm_count<%s, %d>", type_name<T>(), IBS_M);
   return hipGetLastError();
 }
 
@@ -1389,6 +1395,7 @@ static hipError_t launch_grad(const GradArgs<T>& a, hipStream_t st) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((a.n_pts + wpb - 1) / wpb), dim3(wpb * 64), lds, st, a.n_pts, a.N, a.h, a.geo,
                      a.arr_stride ? a.arr_stride : a.ld, a.line_stride ? a.line_stride : 8 * a.ld, a.theta0, a.del_alpha, a.val, a.jac, a.gam, a.dalpha, a.dth0, a.info);
+  note_launch((a.n_pts + wpb - 1) / wpb, wpb * 64, "ibs::k_obj_w_grad<%s, %d>", type_name<T>(), IBS_M);
   return hipGetLastError();
 }
 
@@ -1399,6 +1406,7 @@ static hipError_t launch_refine_eval(const RefineEvalArgs<T>& a, hipStream_t st)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(a.n_c_max), dim3(256), lds, st, a);
+  note_launch(a.n_c_max, 256, "ibs::k_refine_eval<%s, %d>", type_name<T>(), IBS_M);
   return hipGetLastError();
 }
 

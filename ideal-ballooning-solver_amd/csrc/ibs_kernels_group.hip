@@ -315,6 +315,7 @@ static hipError_t launch_gcf_g(const GcfArgs<T>& a, hipStream_t st) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
                      a.lam, a.gam, a.X, a.dX, a.info);
+  note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_g<%s, %d, %d>", type_name<T>(), IBS_M, IBS_P);
   return hipGetLastError();
 }
 template <typename T>
@@ -330,6 +331,7 @@ static hipError_t launch_scan_g(const ScanArgs<T>& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
                      a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
                      a.dX, a.dth0, a.info);
+  note_launch(grid.x, wpb * 64, "ibs::k_gamma_scan_g<%s, %d, %d>", type_name<T>(), IBS_M, IBS_P);
   return hipGetLastError();
 }
 
@@ -347,6 +349,7 @@ static hipError_t launch_scan_g_chain(const ScanArgs<T>& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
                      a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
                      a.dX, a.dth0, a.info, chain, a.chain_w1, a.chain_w2, a.lam_guess, a.guess_width);
+  note_launch(grid.x, wpb * 64, "ibs::k_gamma_scan_g_chain<%s, %d, %d>", type_name<T>(), IBS_M, IBS_P);
   return hipGetLastError();
 }
 

@@ -2,6 +2,8 @@
 // rows-per-lane value M) and ibs_api.hip (the C-ABI layer).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
 
 namespace ibs {
 
@@ -92,6 +94,14 @@ struct LaunchTable {
   hipError_t (*scan_chain_f64_g[2][kMaxM + 1])(const ScanArgs<double>&, hipStream_t);   // chained / warm-started
 };
 LaunchTable& launch_table();
+
+// Diagnostic record of the solver / geometry kernel most recently launched by this thread (C ABI: ibs_last_launch): the
+// name as rocprofv3 prints it ("ibs::k_gamma_scan<double, 8>") and the launch dimensions -- the library picks lanes per
+// system, chaining and geometry form from the batch size, and a measurement must be able to say which kernel it timed.
+struct LaunchNote { char name[96]; long blocks; int threads; };
+LaunchNote& last_launch();      // thread-local (ibs_api.hip)
+void note_launch(long blocks, int threads, const char* fmt, ...);
+template <typename T> constexpr const char* type_name() { return sizeof(T) == 8 ? "double" : "float"; }
 
 // threads per block the scan kernel is compiled for (register budget: 5M doubles per lane)
 // LDS rows of the wave kernels are padded by one element per 8 (element j lives at j + (j >> 3)): a lane reads a

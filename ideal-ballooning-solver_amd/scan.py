@@ -244,13 +244,14 @@ class BallooningScan:
 
     def run(self, refine=True):
         """returns (theta0_arr, alpha_arr, gam_arr), each (nsurfs,), identical on every rank.
-        Every rank takes part in the ONE gather whatever happens on its own shard: a rank-local failure (flagged solves,
-        non-finite tables) travels through the collective as NaN rows and is raised on EVERY rank afterwards -- a rank
-        that raised before the gather would leave the others waiting in it."""
+        Every rank takes part in the ONE gather whatever happens on its own shard: a rank-local failure of ANY kind (flagged
+        solves, non-finite tables, a geometry producer that raises, an out-of-memory error of the framework) travels through
+        the collective as NaN rows and is raised on EVERY rank afterwards -- a rank that raised before the gather would
+        leave the others waiting in it."""
         err = None
         try:
             local = self.local_rows(refine)
-        except IbsError as e:
+        except Exception as e:             # (re-raised after the gather, whatever it is)
             err = e
             local = np.full((len(self.own), 3), np.nan)
         # one decision for every gather of this object, the same on every rank: the library's own communicator when the

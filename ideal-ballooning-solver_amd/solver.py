@@ -144,6 +144,13 @@ class Context:
         self._comm_world = 0            # gathers go back to torch.distributed
         check(self._lib.ibs_comm_destroy(self._h), "ibs_comm_destroy")
 
+    def last_launch(self):
+        """(kernel name as rocprofv3 prints it, waves of the launch) of the solver / geometry kernel this thread launched last"""
+        buf = C.create_string_buffer(96)
+        nb, nt = _lib._I64(0), _lib._I32(0)
+        self._lib.ibs_last_launch(buf, 96, C.byref(nb), C.byref(nt))
+        return buf.value.decode(), int(nb.value) * int(nt.value) // 64
+
     def set_option(self, name, value):
         """diagnostic override of a dispatch heuristic of this context (include/ibs.h: ibs_set_option);
         value None = back to the context's default"""

@@ -225,7 +225,11 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
  *   x_opt[n_pts][2], f_opt[n_pts] = -gam at x_opt (utils.py:1728 sign), n_evals[n_pts] (optional).  x_opt lies in the box up
  *   to the rounding of x + stp d (L-BFGS-B projects directions, not points).
  *   n_pts = 0 (a rank without surfaces) is a no-op: the per-point pointers may be null, 0 rounds are returned.
- * `mem` applies to every pointer.  Synchronous.  Returns the number of rounds (>= 0) or an error (< 0). */
+ * `mem` applies to every pointer.  IBS_MEM_HOST: synchronous.  IBS_MEM_DEVICE: the host returns once every round's count
+ * has been read, but the kernel that writes x_opt / f_opt / n_evals may still be running: the outputs are STREAM-ORDERED
+ * on the context's stream like those of every other device-pointer call (read them from that stream, or after
+ * ibs_synchronize()).  A round that does not report within 120 s fails with IBS_ERR_HIP.
+ * Returns the number of rounds (>= 0) or an error (< 0). */
 int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm, const double* xn,
                    const double* xm_nyq, const double* xn_nyq, const double* tab_mn, const double* tab_nyq,
                    const double* scal, int32_t nrows_mn, const int32_t* rows_mn, int32_t nrows_nyq,
@@ -236,6 +240,12 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
 /* Statistics of the last ibs_refine_f64 call of this context (diagnostic; no reference counterpart):
  * out4 = {objective evaluations, forward sweeps of their eigen-solves, rounds needed, rounds enqueued}. */
 int ibs_refine_stats(ibs_ctx* ctx, int64_t* out4);
+
+/* Diagnostic (no reference counterpart): the solver / geometry kernel most recently launched by the calling thread -- its
+ * name as rocprofv3 prints it ("ibs::k_gamma_scan<double, 8>"; the library picks lanes per system, theta0 chaining and the
+ * geometry form from the batch size) and the launch dimensions (blocks, threads per block; waves = blocks * threads / 64).
+ * bench.py uses it to look a leg's kernel up in the committed PMC passes by its exact name and batch size. */
+int ibs_last_launch(char* name, int32_t len, int64_t* blocks, int32_t* threads);
 
 /* Number of eigenvalues of (T, F) strictly above shift[i] for each system (Sturm sequence).
  * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0). */

@@ -107,23 +107,26 @@ def _worker_run_edge(rank, world, port, q, case):
 
         def fl_bad(s, alphas, fl=fl):
             if s > 0.75:
+                if case == "fail_other":          # not an IbsError: a numpy / framework error on one rank
+                    raise ValueError("injected failure on the surface s = %g" % s)
                 raise ibs_amd.IbsError("injected failure on the surface s = %g" % s)
             return fl(s, alphas)
         fl = fl_bad
     scan = ibs_amd.BallooningScan(OracleContext(), fl, th, svals, nalpha=4, ntheta0=3, rank=rank, world=world, dist=dist)
     try:
         out = ("ok", [o.tolist() for o in scan.run(refine=False)])
-    except ibs_amd.IbsError as e:
+    except (ibs_amd.IbsError, ValueError) as e:
         out = ("raised", str(e))
     q.put((rank, out))
     dist.barrier()                      # (both ranks are still in step: nobody was left inside the gather)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["empty", "fail"])
+@pytest.mark.parametrize("case", ["empty", "fail", "fail_other"])
 def test_two_rank_run_with_empty_shard_and_with_a_failing_rank(case):
-    """BallooningScan.run(): a rank without surfaces takes part in the one gather; a rank whose shard fails sends NaN rows
-    and EVERY rank raises after the collective (no rank may leave the others waiting in it)."""
+    """BallooningScan.run(): a rank without surfaces takes part in the one gather; a rank whose shard fails -- with an
+    IbsError or with any other exception -- sends NaN rows and EVERY rank raises after the collective
+    (no rank may leave the others waiting in it)."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
@@ -367,10 +370,10 @@ def test_two_rank_comm_init_agrees_before_the_collective_init(failing_rank):
     assert res[0] == want and res[1] == want
 
 
-def test_bench_watchdog_prints_the_headline_once_and_leaves_with_status_zero():
+def test_bench_watchdog_prints_the_headline_once_and_leaves_with_its_own_status():
     """bench.py's N > 1 phases run under a watchdog: a phase that overruns must end with rank 0 printing the JSON line it
-    has (the headline is measured before any such phase) and status 0 -- and after the regular line has been printed, a late
-    overrun must not print a second one."""
+    has (the headline is measured before any such phase) and the watchdog's own NON-ZERO status (a hung run must not look like
+    a healthy one) -- and after the regular line has been printed, a late overrun must not print a second one."""
     import subprocess
     import sys
     import textwrap
@@ -390,7 +393,7 @@ def test_bench_watchdog_prints_the_headline_once_and_leaves_with_status_zero():
     for rank, state, want in ((0, "pending", 1), (0, "printed", 0), (1, "pending", 0)):
         r = subprocess.run([sys.executable, "-c", code, str(rank), state], capture_output=True, text=True, timeout=60)
         lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-        assert r.returncode == 0 and "not reached" not in r.stdout and len(lines) == want, (rank, state, r.stdout, r.stderr)
+        assert r.returncode == 5 and "not reached" not in r.stdout and len(lines) == want, (rank, state, r.stdout, r.stderr)
         if want:
             d = json.loads(lines[0])
             assert d["value"] == 1.0 and "test phase" in d["aborted"]
