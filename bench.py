@@ -128,6 +128,39 @@ def build_workload(rank, device):
     return h, geo7, t(dP), t(theta0), base, dP, theta0
 
 
+def ncsx_boundary_dofs(xm, xn, nfp):
+    """the 72 boundary DOFs of the NCSX / HBERG set-up (create_dict.py:29-34, 47-55): RBC(m, n) and ZBS(m, n) for
+    m = 0..6 with |n| <= (4, 3, 3, 2, 2, 2, 1)[m] (m = 0: n = 1..tor only) -> list of (table name, row in the wout mode list)"""
+    pol = [0, 1, 2, 3, 4, 5, 6]; tor = [4, 3, 3, 2, 2, 2, 1]
+    dofs = []
+    for name in ("rmnc", "zmns"):
+        for m, t in zip(pol, tor):
+            for n in (range(1, t + 1) if m == 0 else range(-t, t + 1)):
+                row = np.nonzero((xm == m) & (xn == n * nfp))[0]
+                assert len(row) == 1, (m, n)
+                dofs.append((name, int(row[0])))
+    return dofs
+
+
+def emulated_equilibria(wout0):
+    """without VMEC the 72 DOF-perturbed equilibria are emulated on the shipped NCSX_op tables: the boundary
+    value x of DOF k is stepped by abs 1e-3 if |x| <= 1e-2 else rel 2e-3 (create_dict.py:67, 70; ball_scan.py:129-139)
+    and the change carried inward with an s^2 profile.  Identical arithmetic, not a consistent equilibrium."""
+    nfp = int(wout0["nfp"])
+    dofs = ncsx_boundary_dofs(np.asarray(wout0["xm"]), np.asarray(wout0["xn"]), nfp)
+    assert len(dofs) == 72
+    prof = np.linspace(0, 1, wout0["rmnc"].shape[1]) ** 2
+    wouts, steps, x0 = [wout0], [1.0], []
+    for name, row in dofs:
+        w = dict(wout0)
+        w[name] = wout0[name].copy()
+        x = w[name][row, -1]
+        step = 1.0e-3 if abs(x) <= 1.0e-2 else 2.0e-3 * x
+        w[name][row, :] += step * prof
+        wouts.append(w); steps.append(step); x0.append(x)
+    return wouts, np.array(steps), np.array(x0)
+
+
 def cpu_baseline(h, base, dP, theta0, budget_s=12.0):
     """C oracle (oracle/ibs_oracle.c, 'port') on the same D3D-shape batch, all host cores."""
     from oracle import c_oracle as co
@@ -385,6 +418,175 @@ def ncsx_pipeline(ctx, device):
             leg["gam_refined"] = [float(-v) for v in fo]
         out[tag] = leg
     return out
+
+
+def c5_family(dev, family, n, N, seed):
+    """'smooth' = s-alpha coefficients (bishop_ball_s-alpha.py:30-45, f = g), shat ~ U(0.1, 2), alpha ~ U(0, 1.2),
+    theta0 ~ U(0, pi/2); 'rough' = iid per point inside the measured NCSX_op envelopes."""
+    import torch
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    u = lambda lo, hi, shape: lo + (hi - lo) * torch.rand(shape, dtype=torch.float64, device=dev, generator=gen)
+    h = 8 * np.pi / (N - 1)
+    if family == "smooth":
+        th = torch.linspace(-4 * np.pi, 4 * np.pi, N, dtype=torch.float64, device=dev)
+        sh, al, t0 = u(0.1, 2.0, (n, 1)), u(0.0, 1.2, (n, 1)), u(0.0, np.pi / 2, (n, 1))
+        lam = sh * (th[None] - t0) - al * (torch.sin(th)[None] - torch.sin(t0))
+        g = 1 + lam ** 2
+        c = al * (torch.cos(th)[None] + torch.sin(th)[None] * lam)
+        del lam
+        return h, g, c, g
+    g = torch.exp(u(np.log(0.01), np.log(50.0), (n, N)))
+    c = u(-2.5, 3.5, (n, N))
+    f = torch.exp(u(np.log(0.2), np.log(3e3), (n, N)))
+    return h, g, c, f
+
+
+def norm_a(h, g, c, f, chunk=65536):
+    """the solver's ||A|| bound per system: max_r (|d_r| + e_r + e_{r+1}) / f_r   (utils.py:1584-1592 rows)"""
+    import torch
+    out = torch.empty(g.shape[0], dtype=torch.float64, device=g.device)
+    for a in range(0, g.shape[0], chunk):
+        gg, cc, ff = g[a:a + chunk], c[a:a + chunk], f[a:a + chunk]
+        e = 0.5 * (gg[:, :-1] + gg[:, 1:]) / h ** 2
+        d = cc[:, 1:-1] - (e[:, :-1] + e[:, 1:])
+        out[a:a + chunk] = ((d.abs() + e[:, :-1] + e[:, 1:]) / ff[:, 1:-1]).amax(dim=1)
+    return out
+
+
+def c4_adjoint_step(ctx, device, n_oracle=4, reps=3):
+    """BASELINE configs[3] END TO END on one GPU (the reference: 73 x `srun ball_scan.py`, ball_scan.py:248-347, consumed by
+    sims_runner_NCSX.py:249-261): 73 emulated equilibria (base + the 72 NCSX boundary DOFs stepped by create_dict.py:67-70 on
+    the shipped tables; every equilibrium holds ITS OWN arrays: 115 MB of wout tables) x 5 surfaces x 24 alpha x 15 theta0,
+    N = 969 -- ibs_amd.AdjointStep.run(): host tables (radial splines of all equilibria, native threaded routine) -> geometry
+    -> coarse scan + per-surface argmax -> L-BFGS-B refinement of all 365 maxima -> final solve -> objective + 72-gradient.
+    `total_ms` is the wall time of run() (it ends with the one copy of the rows to the host); the phases come from a separate
+    pass with HIP events between them.  n_oracle (equilibrium, surface) pairs are re-done by the oracle pipeline."""
+    import ibs_amd
+    wout0 = dict(np.load(os.path.join(ROOT, "tests", "golden", "G8_wout_ncsx_op.npz")))
+    wouts, steps, x0 = emulated_equilibria(wout0)
+    wouts = [{k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in w.items()} for w in wouts]
+    n_eq, ns, na, nt0 = len(wouts), 5, 24, 15
+    svals = np.linspace(0.5, 0.95, ns)                                   # ball_scan.py:197
+    th = ibs_amd.theta_grid_for(11, 11)                                  # ball_scan.py:201-208: 969 points
+    f_other = 0.8 + 0.01 * np.arange(n_eq)
+    step = ibs_amd.AdjointStep(ctx, th, svals, device, nalpha=na, ntheta0=nt0, gamma_thresh=-2.0e-4, prefac=50.0)
+    step.run(wouts, f_other, steps)                                       # warm-up (spline weights, workspaces, resident inputs)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = step.run(wouts, f_other, steps)
+        times.append((time.perf_counter() - t0) * 1e3)
+    ev = ctx.refine_stats()
+    ph = {}
+    step.run(wouts, f_other, steps, phases=ph)
+    leg = dict(workload="configs[3]: %d emulated equilibria x %d surfaces x %d alpha x %d theta0 = %d coarse solves, N = %d, + "
+                        "refinement of the %d maxima + final solve + objective and %d-gradient; one AdjointStep.run()" % (
+                            n_eq, ns, na, nt0, n_eq * ns * na * nt0, len(th), n_eq * ns, n_eq - 1),
+               total_ms=float(np.median(times)), total_ms_runs=[float(t) for t in times],
+               phases_ms={k: float(v) for k, v in ph.items()}, phases_how="separate pass, HIP events between the phases "
+               "(one extra synchronisation); host_tables and gather_copy_objective are host wall times",
+               refine_evaluations=ev[0], refine_rounds=ev[2], coarse_solves=n_eq * ns * na * nt0,
+               fobj=out["fobj"], dfobj_norm=float(np.linalg.norm(out["dfobj"])),
+               gam_min=float(out["gam"].min()), gam_max=float(out["gam"].max()))
+    if n_oracle:
+        from oracle.pipeline import oracle_surface_pipeline
+        rng = np.random.default_rng(41)
+        errs = []
+        t0 = time.perf_counter()
+        for k in rng.choice(n_eq * ns, size=n_oracle, replace=False):
+            q, js = divmod(int(k), ns)
+            ref = oracle_surface_pipeline(wouts[q], float(svals[js]), th, na, nt0, step.del_alpha)
+            errs.append(abs(ref["gam"] - out["gam"][q, js]))
+        leg.update(max_abs_dgam_vs_oracle=float(max(errs)), oracle_pairs=int(n_oracle), parity_ok=bool(max(errs) < 1e-8),
+                   oracle_seconds=time.perf_counter() - t0)
+    return leg
+
+
+def c5_matrix(ctx, device, n_sys=1 << 20, budget_s=75.0):
+    """BASELINE configs[4] as stated: 10^6 (2^20) random (g, c, f) systems at N_zeta in {256, 512, 1024, 2048}, smooth and
+    rough families, as FP64, FP32 eigenvalues only (all-FP32 solver, every result certified by an FP64 count
+    pair) and FP32 with the growth rate (FP32 in HBM, FP64 in the solver).  Per row: solves/s, the HBM fraction on algorithmic
+    bytes (3 N + 1) w, the kernel that ran with its PMC fields, sweeps per solve, flagged systems; for the FP32 rows the
+    distance to the FP64 solve of the SAME (FP32-valued) systems in units of eps32 ||A||.  Rows are skipped (and say so)
+    once the leg's time budget is spent."""
+    import torch
+    rows = []
+    t_leg = time.perf_counter()
+    for nz in (256, 512, 1024, 2048):
+        N = nz + 1
+        for family in ("smooth", "rough"):
+            if time.perf_counter() - t_leg > budget_s:
+                rows.append(dict(n_zeta=nz, family=family, skipped="time budget of the leg spent"))
+                continue
+            h, g, c, f = c5_family(device, family, n_sys, N, seed=20240 + nz)           # SURVEY 8d C5: rng seed 20240 + N_zeta
+            g32, c32 = g.float(), c.float()
+            f32 = g32 if family == "smooth" else f.float()
+            g64w, c64w = g32.double(), c32.double()
+            f64w = g64w if family == "smooth" else f32.double()
+            r64 = ctx.solve_gcf(h, g64w, c64w, f64w)        # the FP32-valued systems solved in FP64: the FP32 rows' reference
+            nA = norm_a(h, g64w, c64w, f64w)
+            del g64w, c64w, f64w
+            for mode in ("f64", "f32_lam", "f32_gam"):
+                if mode == "f64":
+                    call = lambda want_info=False: ctx.solve_gcf(h, g, c, f, want_info=want_info)
+                    w = 8
+                elif mode == "f32_lam":
+                    call = lambda want_info=False: ctx.solve_gcf(h, g32, c32, f32, want_info=want_info, dtype=np.float32, want_gam=False)
+                    w = 4
+                else:
+                    call = lambda want_info=False: ctx.solve_gcf(h, g32, c32, f32, want_info=want_info, dtype=np.float32)
+                    w = 4
+                r = call(True)
+                kern, waves = ctx.last_launch()
+                torch.cuda.synchronize()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
+                for a, b in evs:
+                    a.record(); call(); b.record()
+                torch.cuda.synchronize()
+                ms = float(min(a.elapsed_time(b) for a, b in evs))
+                row = dict(n_zeta=nz, family=family, mode=mode, systems=n_sys, solves_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms,
+                           mean_sweeps=float((r["info"] & 0xffff).double().mean().item()),
+                           flagged=int(((r["info"] >> 16) != 0).sum().item()),
+                           roofline=hbm_roofline(n_sys * (3 * N + 1) * w, ms, "valu_issue", kern, waves, bytes_per_solve=(3 * N + 1) * w))
+                if mode != "f64":
+                    el = (r["lam"].double() - r64["lam"]).abs() / nA / 1.1920929e-07
+                    row["max_abs_dlam_over_eps32_normA"] = float(el.max().item())
+                    row["tolerance_n_eps32_normA"] = float(nz)
+                    row["within_tolerance"] = bool(el.max().item() <= nz)
+                    if mode == "f32_gam" and family == "smooth":
+                        row["max_abs_dgam_vs_f64"] = float((r["gam"].double() - r64["gam"]).abs().max().item())
+                rows.append(row)
+                del r
+            del g, c, f, g32, c32, f32, r64, nA
+            torch.cuda.empty_cache()
+    done = [r for r in rows if "mode" in r]
+    by = lambda nz, fam, mode: next((r["solves_per_s"] for r in done if (r["n_zeta"], r["family"], r["mode"]) == (nz, fam, mode)), None)
+    ratio = {"%d_%s" % (nz, fam): (by(nz, fam, "f32_gam") / by(nz, fam, "f64")) if by(nz, fam, "f32_gam") and by(nz, fam, "f64") else None
+             for nz in (256, 512, 1024, 2048) for fam in ("smooth", "rough")}
+    return dict(workload="configs[4]: %d random (g, c, f) systems per row, N_zeta x {f64, f32 eigenvalues only, f32 with growth rate} x "
+                         "{smooth, rough}" % n_sys, rows=rows, f32_gam_over_f64=ratio,
+                f32_results_outside_tolerance=int(sum(1 for r in done if r.get("within_tolerance") is False)),
+                seconds=time.perf_counter() - t_leg)
+
+
+def dropin_call(ctx, reps=200):
+    """the literal two-line integration of INTEGRATION.md 2: ONE `ibs_amd.gamma_ball_full(dPdrho, theta, B, gradpar, cvdrift,
+    gds2)` call on host numpy arrays (utils.py:1550-1552), N = 969 (the reference's NCSX grid): upload, one-wave solve with
+    eigenfunction output, download -- the per-call latency a ball_scan.py loop would see (reference: ~55 ms per call)."""
+    import ibs_amd
+    g3 = np.load(os.path.join(ROOT, "tests", "golden", "G3_ncsx_lines.npz"))
+    line = g3["geo_969"][5]
+    th = ibs_amd.theta_grid(969)
+    dP = float(-0.5 * np.mean((line[2] - line[7]) * line[0] ** 2))
+    cv = line[2] + 0.3 * line[3]; gd = line[4] + 2 * 0.3 * line[5] + 0.09 * line[6]       # ball_scan.py:267-268 at theta0 = 0.3
+    for _ in range(10):
+        out = ibs_amd.gamma_ball_full(dP, th, line[0], line[1], cv, gd, ctx=ctx)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = ibs_amd.gamma_ball_full(dP, th, line[0], line[1], cv, gd, ctx=ctx)
+    us = (time.perf_counter() - t0) / reps * 1e6
+    return dict(workload="one gamma_ball_full(...) call on host arrays, N = 969 (reference signature, 6-tuple back)",
+                us_per_call=us, calls_per_s=1e6 / us, gam=float(out[0]))
 
 
 def spawn_ranks(n, argv):
@@ -929,6 +1131,11 @@ def main():
             out["scan_large"] = scan_large(ctx, device, geo7, dP_d)
             out["batch_scaling"] = batch_scaling(ctx, device, h, geo7, dP_d, th0_d)
             out.update(ncsx_pipeline(ctx, device))
+            out["dropin_call_us"] = dropin_call(ctx)
+            out["c4_adjoint_step"] = c4_adjoint_step(ctx, device, n_oracle=0 if args.no_cpu else 4)
+            if out["c4_adjoint_step"].get("parity_ok") is False:
+                rc = 3
+            out["c5_matrix"] = c5_matrix(ctx, device)
         print(json.dumps(out), flush=True)
         if rc:
             print("bench.py: parity check FAILED: max |gam - oracle| = %g (bar 1e-8), flagged solves %d" % (

@@ -10,4 +10,4 @@ from .scan import BallooningScan, shard_surfaces, gather_surfaces, gather_rows_t
 from .geometry import SurfaceTables  # noqa: F401
 from .config import ScanConfig, load_params_dict, theta_grid_for, create_history_placeholders, PARAMS_KEYS  # noqa: F401
 from .lbfgsb import minimize2  # noqa: F401
-from .objective import ballooning_objective, dof_fd_gradient, dof_steps, shard_dofs, allreduce_dof_vector  # noqa: F401
+from .objective import ballooning_objective, dof_fd_gradient, dof_steps, shard_dofs, allreduce_dof_vector, AdjointStep  # noqa: F401

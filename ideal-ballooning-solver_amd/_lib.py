@@ -47,10 +47,13 @@ SYMBOLS = {
                                           _P, _P, _P, _P, _P, _P, _I32]),
     "ibs_gamma_scan_argmax_f64": (C.c_int, [_P, _I32, _I32, _I32, _D, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I32,
                                             _P, _P, _P, _P]),
+    "ibs_gamma_points_f64": (C.c_int, [_P, _I32, _I32, _D, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32]),
+    "ibs_scan_starts_f64": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "ibs_obj_w_grad_f64": (C.c_int, [_P, _I32, _I32, _D, _P, _I64, _P, _D, _P, _P, _P, _I32]),
     "ibs_hf_grad_f64": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I32]),
     "ibs_fieldline_geometry_f64": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _I32, _P,
                                              _I64, _P, _P, _I32, _P, _I32, _P, _D, _D, _I32]),
+    "ibs_surface_tables_f64": (C.c_int, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32]),
     "ibs_refine_f64": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _P, _D, _D, _I32, _P, _P,
                                  _I32, _P, _D, _I32, _D, _D, _P, _P, _P, _I32]),
     "ibs_refine_stats": (C.c_int, [_P, _P]),

@@ -244,6 +244,23 @@ __global__ void __launch_bounds__(256) k_hf_grad(long n_sys, int N, long ld, con
   if (lane == 0) jac[sys] = sc / y1 - sg / y1 - gam[sys] * sf / y1;
 }
 
+// start points of the refinement from the per-surface maxima of the coarse scan (ball_scan.py:279-295)
+__global__ void k_scan_starts(int n_surf, int n_alpha, int n_theta0, const double* alpha, const double* theta0,
+                              const double* pack, double* start, double* sigma0, int* n_bad) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_surf) return;
+  const double m = pack[2 * s], fi = pack[2 * s + 1];
+  double a = 0.0, t = 0.0, sg = 0.05;                                      // ball_scan.py:279-282: an all-zero table
+  const bool ok = (m == m) && fabs(m) <= 1.7976931348623157e308 && fi >= 0.0 && fi < (double)n_alpha * n_theta0;
+  if (!ok) atomicAdd(n_bad, 1);                                           // a NaN / flagged table: reported, start (0, 0)
+  else if (m != 0.0) {
+    const int idx = (int)fi, i = idx / n_theta0, j = idx - i * n_theta0;   // first maximum, row-major (ball_scan.py:283-288)
+    a = alpha[i]; t = theta0[j]; sg = 1.3 * fabs(m) + 0.05;               // ball_scan.py:289, 295
+  }
+  start[2 * s] = a; start[2 * s + 1] = t;
+  if (sigma0) sigma0[s] = sg;
+}
+
 template <typename T>
 int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, const T* c, const T* f, int64_t ld,
                    T* lam, T* gam, T* X, T* dX, int32_t* info, int32_t mem,
@@ -622,7 +639,8 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
                            const double* gds2, const double* gds21, const double* gds22, int64_t ld,
                            const double* dPdrho, const double* theta0, double* gam, double* lam, double* X,
                            double* dX, double* dth0, int32_t* info, int32_t mem, const double* lam_guess,
-                           double guess_width, int32_t n_surf = 0, double* pack = nullptr) {
+                           double guess_width, int32_t n_surf = 0, double* pack = nullptr, bool t0_per_line = false) {
+  // t0_per_line: n_theta0 = 1 and theta0[n_lines] holds one value per line (ibs_gamma_points_f64); one wave per system
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
   if (lam_guess && !(guess_width > 0)) return fail(IBS_ERR_ARG, "guess_width must be > 0");
   if (pack && (mem != IBS_MEM_DEVICE || n_surf <= 0 || n_lines % n_surf != 0 || !gam))
@@ -641,7 +659,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   int G = 1, cap = ibs::scan_max_threads(M) / 64;
   decltype(fn) fn_g_chain = nullptr;     // chained / warm-started sub-wave kernel of the same (P, M)
   {
-    const int P = pick_lanes(ctx, N, (long)n_lines * n_theta0);
+    const int P = t0_per_line ? 64 : pick_lanes(ctx, N, (long)n_lines * n_theta0);
     if (P != 64 && n_theta0 % (64 / P) == 0) {
       const int Mg = (N - 2 + P - 1) / P;
       auto fg = ibs::launch_table().scan_f64_g[P == 32 ? 0 : 1][Mg];
@@ -668,6 +686,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   wpb = (waves_per_line + nblk - 1) / nblk;
   ibs::ScanArgs<double> a{};
   a.n_lines = n_lines; a.n_theta0 = n_theta0; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
+  a.t0_stride = t0_per_line ? 1 : 0;
   // A chain shortens the blocks (a line's waves = theta0 slots / chain) while every block still stages the whole line:
   // the LDS then limits the waves per CU.  Shorten the chain until the blocks that fit a CU hold as many waves as the
   // registers allow (tools/batch_sweep.py, 8 theta0 per line, N = 513, 65,536 solves: chain 4 = one wave per block =
@@ -716,7 +735,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
       }
     }
   }
-  if (G == 1 && !lam_guess) {
+  if (G == 1 && !lam_guess && !t0_per_line) {
     const long waves = (long)n_lines * n_theta0, simds = 4L * ctx->n_cu;
     int chain = 1;
     if (n_theta0 >= 8 && waves >= 8 * simds) chain = 4;
@@ -742,7 +761,8 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   const size_t n_sys = (size_t)n_lines * n_theta0;
   if (mem == IBS_MEM_HOST) {
     const size_t in_elems = (size_t)n_lines * ld, out_elems = n_sys * N;
-    size_t need = 7 * pad256(in_elems * 8) + pad256(n_lines * 8) + pad256(n_theta0 * 8) + 4 * pad256(n_sys * 8) +
+    const size_t n_t0_vals = t0_per_line ? (size_t)n_lines : (size_t)n_theta0;
+    size_t need = 7 * pad256(in_elems * 8) + pad256(n_lines * 8) + pad256(n_t0_vals * 8) + 4 * pad256(n_sys * 8) +
                   2 * pad256(out_elems * 8) + pad256(n_sys * 4) + 8192;
     if (int r = ensure_ws(ctx, need)) return r;
     Arena ar(ctx);
@@ -752,9 +772,9 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
       dev[k] = ar.take<double>(in_elems);
       HIPCHK(hipMemcpyAsync(dev[k], src[k], in_elems * 8, hipMemcpyHostToDevice, ctx->stream));
     }
-    double* ddP = ar.take<double>(n_lines); double* dt0 = ar.take<double>(n_theta0);
+    double* ddP = ar.take<double>(n_lines); double* dt0 = ar.take<double>(n_t0_vals);
     HIPCHK(hipMemcpyAsync(ddP, dPdrho, (size_t)n_lines * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dt0, theta0, (size_t)n_theta0 * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dt0, theta0, n_t0_vals * 8, hipMemcpyHostToDevice, ctx->stream));
     double* dgam = ar.take<double>(n_sys); double* dlam = ar.take<double>(n_sys); double* dd = ar.take<double>(n_sys);
     double* dX_ = X ? ar.take<double>(out_elems) : nullptr; double* ddX = dX ? ar.take<double>(out_elems) : nullptr;
     int* d_info = ar.take<int>(n_sys); int* d_nbad = ar.take<int>(1);
@@ -839,6 +859,26 @@ int ibs_gamma_scan_argmax_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, i
   if (!pack) return fail(IBS_ERR_ARG, "pack is null");
   return gamma_scan_impl(ctx, n_lines, n_theta0, N, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, ld, dPdrho,
                          theta0, gam, lam, nullptr, nullptr, nullptr, info, IBS_MEM_DEVICE, nullptr, 0.0, n_surf, pack);
+}
+
+int ibs_gamma_points_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const double* bmag, const double* gradpar,
+                         const double* cvdrift, const double* cvdrift0, const double* gds2, const double* gds21,
+                         const double* gds22, int64_t ld, const double* dPdrho, const double* theta0, double* gam,
+                         double* lam, double* X, double* dX, double* dgam_dtheta0, int32_t* info, int32_t mem) {
+  return gamma_scan_impl(ctx, n_pts, 1, N, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, ld, dPdrho, theta0, gam,
+                         lam, X, dX, dgam_dtheta0, info, mem, nullptr, 0.0, 0, nullptr, true);
+}
+
+int ibs_scan_starts_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_alpha, int32_t n_theta0, const double* alpha,
+                        const double* theta0, const double* pack, double* start, double* sigma0, int32_t* n_bad) {
+  if (!ctx) return fail(IBS_ERR_ARG, "null context");
+  if (n_surf < 0 || n_alpha <= 0 || n_theta0 <= 0 || !alpha || !theta0 || !pack || !start || !n_bad) return fail(IBS_ERR_ARG, "bad arguments");
+  if (n_surf == 0) return 0;
+  ON_DEVICE(ctx);
+  hipLaunchKernelGGL(k_scan_starts, dim3((unsigned)((n_surf + 127) / 128)), dim3(128), 0, ctx->stream, n_surf, n_alpha, n_theta0,
+                     alpha, theta0, pack, start, sigma0, n_bad);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const double* geo, int64_t ld,

@@ -670,7 +670,9 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
                                                      const T* __restrict__ dPdrho, const T* __restrict__ theta0,
                                                      T* gam_out, T* lam_out, T* X_out, T* dX_out, T* dth0_out,
                                                      int* info_out, const T* __restrict__ lam_guess, T guess_width,
-                                                     int lines_per_surf, int* surf_counter, T* pack, int pack_mode) {
+                                                     int lines_per_surf, int* surf_counter, T* pack, int pack_mode,
+                                                     int t0_stride) {
+  // t0_stride: 0 = the theta0 grid is shared by all lines; 1 (with n_theta0 = 1) = one theta0 per line (ibs_gamma_points_f64)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -697,7 +699,7 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   const int it0 = part * wpb + wave;
   const bool valid = it0 < n_theta0;
   const int it0c = valid ? it0 : (n_theta0 - 1);
-  const T th0 = theta0[it0c];
+  const T th0 = theta0[(long)line * t0_stride + it0c];
   const long sys = (long)line * n_theta0 + it0c;
   const T guess = lam_guess ? lam_guess[sys] : T(0);
   {
@@ -1352,7 +1354,8 @@ static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   dim3 grid((unsigned)(((a.n_theta0 + wpb - 1) / wpb) * a.n_lines));
   hipLaunchKernelGGL(kern, grid, dim3(wpb * 64), lds, st, a.n_lines, a.n_theta0, a.N, a.h, a.bmag, a.gradpar,
                      a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.gam, a.lam, a.X,
-                     a.dX, a.dth0, a.info, a.lam_guess, a.guess_width, a.lines_per_surf, a.surf_counter, a.pack, a.pack_mode);
+                     a.dX, a.dth0, a.info, a.lam_guess, a.guess_width, a.lines_per_surf, a.surf_counter, a.pack, a.pack_mode,
+                     a.t0_stride);
   note_launch(grid.x, wpb * 64, "ibs::k_gamma_scan<%s, %d>", type_name<T>(), IBS_M);
   return hipGetLastError();
 }

@@ -28,6 +28,7 @@ struct ScanArgs {
   // surf_counter[n_surf]: zero between launches (the last arriver resets its word).  null pack = no fusion.
   int lines_per_surf; int* surf_counter; T* pack;
   int pack_mode;                         // 1 = write-through stores + sc1 loads (one block per CU), 2 = release / acquire fences
+  int t0_stride;                         // k_gamma_scan only: 0 = theta0[n_theta0] shared by all lines, 1 = theta0[n_lines] (n_theta0 = 1)
 };
 template <typename T>
 struct SturmArgs {

@@ -10,6 +10,8 @@ import numpy as np
 
 NAMES_MN = ("rmnc", "zmns", "lmns", "d_rmnc_d_s", "d_zmns_d_s", "d_lmns_d_s")
 NAMES_NYQ = ("gmnc", "bmnc", "d_bmnc_d_s", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc")
+# wout arrays the geometry needs, in the order ibs_surface_tables_f64 takes them (stored (modes, ns) as in simsopt's Vmec.wout)
+WOUT_ARRAYS = ("rmnc", "zmns", "lmns", "gmnc", "bmnc", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc")
 
 
 import functools
@@ -94,6 +96,59 @@ class SurfaceTables:
         out.tab_nyq = np.ascontiguousarray(np.concatenate([t.tab_nyq for t in tables]))
         out.scal = np.ascontiguousarray(np.concatenate([t.scal for t in tables]))
         out.rows_mn, out.dn_mn, out.rows_nyq, out.dn_nyq = t0.rows_mn, t0.dn_mn, t0.rows_nyq, t0.dn_nyq
+        return out
+
+    @classmethod
+    def from_wouts(cls, wouts, svals, n_threads=0):
+        """the surfaces `svals` of SEVERAL equilibria in one table set (the base equilibrium and its DOF-perturbed copies
+        of one optimizer step, sims_runner_NCSX.py:151-276; upstream every one of them runs its own vmec_splines,
+        utils.py:37-158): surface index = i_equilibrium * len(svals) + i_surface, like concat([from_wout(w, svals) ...]).
+        The radial splines are linear in the data and the meshes are shared: the four weight matrices (value / derivative
+        on the full / half mesh) are applied to the tables of ALL equilibria by the library's threaded host routine
+        (ibs_surface_tables_f64: every table is read once where it lies; 73 equilibria = 115 MB) instead of 13 small
+        matrix products per equilibrium."""
+        wouts = list(wouts)
+        w0 = wouts[0]
+        ns = int(w0["ns"])
+        svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))
+        n_eq, n_s = len(wouts), len(svals)
+        for w in wouts[1:]:
+            if int(w["ns"]) != ns or not all(w[k] is w0[k] or np.array_equal(w[k], w0[k]) for k in ("xm", "xn", "xm_nyq", "xn_nyq")):
+                raise ValueError("SurfaceTables.from_wouts: the equilibria must share the radial mesh and the mode tables")
+        Wf, Wfd, Wh, Whd = _radial_weights(ns, svals.tobytes())
+        # half-mesh data sit in columns 1..ns-1 of the (mn, ns) tables: a zero column in front of the weights lets the
+        # product run on the table as it lies in memory
+        z = np.zeros((n_s, 1))
+        Wh0, Whd0 = np.ascontiguousarray(np.hstack([z, Wh])), np.ascontiguousarray(np.hstack([z, Whd]))
+        mnmax, mnq = len(w0["xm"]), len(w0["xm_nyq"])
+        tab_mn = np.empty((n_eq * n_s, 6, mnmax)); tab_nyq = np.empty((n_eq * n_s, 7, mnq))
+        import ctypes as C
+        from . import _lib
+        keep, ptrs = [], (C.c_void_p * (9 * n_eq))()
+        for q, w in enumerate(wouts):
+            for k, name in enumerate(WOUT_ARRAYS):
+                a = np.ascontiguousarray(w[name], dtype=np.float64)          # (no copy for the arrays simsopt / numpy hand over)
+                if a.shape != ((mnmax if k < 3 else mnq), ns):
+                    raise ValueError("SurfaceTables.from_wouts: %s of equilibrium %d has shape %s" % (name, q, a.shape))
+                keep.append(a)
+                ptrs[9 * q + k] = a.ctypes.data
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        _lib.check(_lib.lib().ibs_surface_tables_f64(n_eq, ns, n_s, mnmax, mnq, ptrs, p(Wf), p(Wfd), p(Wh0), p(Whd0),
+                                                     p(tab_mn), p(tab_nyq), int(n_threads)), "ibs_surface_tables_f64")
+        pres = np.stack([np.asarray(w["pres"], dtype=np.float64)[1:] for w in wouts])        # utils.py:112
+        iota = np.stack([np.asarray(w["iotas"], dtype=np.float64)[1:] for w in wouts])       # utils.py:118
+        out = cls.__new__(cls)
+        out.s = np.tile(svals, n_eq)
+        out.xm, out.xn = (np.ascontiguousarray(w0[k], dtype=np.float64) for k in ("xm", "xn"))
+        out.xm_nyq, out.xn_nyq = (np.ascontiguousarray(w0[k], dtype=np.float64) for k in ("xm_nyq", "xn_nyq"))
+        out.tab_mn, out.tab_nyq = tab_mn, tab_nyq
+        phiedge = np.repeat([float(np.asarray(w["phi"])[-1]) for w in wouts], n_s)
+        aminor = np.repeat([float(w["Aminor_p"]) for w in wouts], n_s)
+        out.scal = np.ascontiguousarray(np.stack([out.s, (iota @ Wh.T).reshape(-1), (iota @ Whd.T).reshape(-1),
+                                                  (pres @ Whd.T).reshape(-1), phiedge, aminor], axis=1))
+        out.rows_mn, out.dn_mn = _mode_rows_cached(out.xm.tobytes(), out.xn.tobytes())
+        out.rows_nyq, out.dn_nyq = _mode_rows_cached(out.xm_nyq.tobytes(), out.xn_nyq.tobytes())
+        out.n_equilibria, out.n_surf_per_equilibrium = n_eq, n_s
         return out
 
     @classmethod

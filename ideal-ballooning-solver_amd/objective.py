@@ -3,9 +3,12 @@
 The optimizer drivers combine the per-surface growth rates of the base equilibrium (dof 0) and of the
 DOF-perturbed equilibria (dof 1..n) into the objective and its forward-difference gradient
 (sims_runner_NCSX.py:249-261, 300-313).  With one process per GPU the DOF-perturbed equilibria are sharded
-over ranks; the only exchange is one all-reduce (sum) of a (n_dof+1)-vector.
+over ranks; the only exchange is one gather of the per-surface rows (AdjointStep) or one all-reduce (sum) of a
+(n_dof+1)-vector (allreduce_dof_vector).
 """
 import numpy as np
+
+from ._lib import IbsError
 
 
 def ballooning_objective(f_other, gam, gamma_thresh=-2.0e-4, prefac=50.0):
@@ -49,3 +52,81 @@ def allreduce_dof_vector(local_values, owned, n_dof_plus_1, world, dist=None, de
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+class AdjointStep:
+    """The ballooning work of ONE optimizer iteration for all equilibria of the step at once: the base equilibrium and one
+    per boundary DOF (BASELINE configs[3]: 73 x 5 surfaces x 24 alpha x 15 theta0, N = 969).
+
+    Upstream this is ball_submit.py:64-95 (one `srun ball_scan.py iter dof ngroups` per DOF-perturbed equilibrium, each
+    running vmec_splines -> coarse scan -> argmax -> L-BFGS-B -> final solve, ball_scan.py:190-347) followed by
+    sims_runner_NCSX.py:249-261 (objective of every equilibrium, forward-difference gradient over the DOFs).  Here the
+    equilibria of a rank form ONE batch: the radial spline step for all of them (SurfaceTables.from_wouts), one geometry
+    launch, one scan + argmax call, one refinement call, one final solve, one copy of the rows (BallooningScan.device_rows).
+    With world > 1 the equilibria are dealt round-robin over the ranks (the reference's DP-1 level) and ONE
+    all-gather of [n_eq_local][n_surf * 3] doubles assembles the table everywhere.
+
+    SIMSOPT / VMEC stay outside: `wouts` are the wout tables of the (already converged) equilibria, `f_other` the
+    non-ballooning part of each equilibrium's objective (Simsopt_runner.py -> f{dof}.npy), `steps` the DOF steps
+    (dof_steps / ScanConfig.dof_step)."""
+
+    def __init__(self, ctx, theta, svals, device, nalpha=24, ntheta0=15, del_alpha=0.004, gamma_thresh=-2.0e-4, prefac=50.0,
+                 rank=0, world=1, dist=None, n_threads=0):
+        self.ctx, self.device = ctx, device
+        self.theta = np.asarray(theta, dtype=np.float64)
+        self.svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))       # ball_scan.py:197
+        self.nalpha, self.ntheta0, self.del_alpha = int(nalpha), int(ntheta0), float(del_alpha)
+        self.gamma_thresh, self.prefac = float(gamma_thresh), float(prefac)
+        self.rank, self.world, self.dist, self.n_threads = int(rank), int(world), dist, int(n_threads)
+        self._scan = None
+
+    def _scan_for(self, tables, n_eq_local):
+        from .scan import BallooningScan
+        n = n_eq_local * len(self.svals)
+        if self._scan is None or len(self._scan.rho_arr) != n:
+            self._scan = BallooningScan(self.ctx, None, self.theta, np.tile(self.svals, n_eq_local), nalpha=self.nalpha,
+                                        ntheta0=self.ntheta0, del_alpha=self.del_alpha, tables=tables, device=self.device,
+                                        surf_index=np.arange(n))
+        self._scan.tables = tables
+        return self._scan
+
+    def run(self, wouts, f_other, steps, refine=True, phases=None):
+        """wouts: the n_eq = n_dof + 1 equilibria (entry 0 = base); f_other (n_eq,); steps (n_eq,) with entry 0 unused.
+        Returns dict(gam, theta0, alpha: (n_eq, n_surf); f0: (n_eq,); fobj = sqrt(f0[0]) (sims_runner_NCSX.py:318);
+        dfobj: (n_dof,) (sims_runner_NCSX.py:258-261)), identical on every rank."""
+        import time
+        import torch
+        from .geometry import SurfaceTables
+        from .scan import gather_rows_tensor
+        n_eq, ns = len(wouts), len(self.svals)
+        own = shard_dofs(n_eq, self.rank, self.world)
+        err = None
+        try:                               # row of an equilibrium: n_surf x (theta0*, alpha*, gam) + the count of what went wrong
+            if own:
+                t0 = time.perf_counter()
+                tables = SurfaceTables.from_wouts([wouts[q] for q in own], self.svals, n_threads=self.n_threads)
+                if phases is not None:
+                    phases["host_tables_ms"] = (time.perf_counter() - t0) * 1e3
+                r, bad = self._scan_for(tables, len(own)).device_rows(refine, phases)
+                rows = torch.cat([r.reshape(len(own), 3 * ns), bad.reshape(1, 1).expand(len(own), 1)], dim=1)
+            else:
+                rows = torch.zeros((0, 3 * ns + 1), dtype=torch.float64, device=self.device)
+        except Exception as e:             # (carried through the gather as NaN rows and raised on every rank afterwards)
+            err = e
+            rows = torch.full((len(own), 3 * ns + 1), float("nan"), dtype=torch.float64, device=self.device)
+        t0 = time.perf_counter()
+        full = gather_rows_tensor(rows, n_eq, self.rank, self.world, self.dist, self.ctx if getattr(self.ctx, "_comm_world", 0) == self.world else None)
+        host = full.cpu().numpy()                                          # the one copy (and synchronisation)
+        if err is not None:
+            raise err
+        if not np.all(np.isfinite(host)) or np.any(host[:, -1] != 0):
+            raise IbsError("the scan of %d equilibria was flagged or produced non-finite growth rates" %
+                           int(np.sum(~np.isfinite(host).all(axis=1) | (host[:, -1] != 0))))
+        tab = host[:, :-1].reshape(n_eq, ns, 3)
+        gam = tab[:, :, 2]
+        f0 = ballooning_objective(f_other, gam, self.gamma_thresh, self.prefac)        # sims_runner_NCSX.py:254-257
+        out = dict(theta0=tab[:, :, 0], alpha=tab[:, :, 1], gam=gam, f0=f0, fobj=float(np.sqrt(f0[0])),
+                   dfobj=dof_fd_gradient(f0, steps))                                   # sims_runner_NCSX.py:258-261
+        if phases is not None:
+            phases["gather_copy_objective_ms"] = (time.perf_counter() - t0) * 1e3
+        return out

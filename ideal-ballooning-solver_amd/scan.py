@@ -77,13 +77,17 @@ class BallooningScan:
     """Coarse (alpha, theta0) scan -> argmax -> L-BFGS-B refinement -> final solve, per surface."""
 
     def __init__(self, ctx, fieldlines, theta, rho_arr, nalpha=24, ntheta0=15, del_alpha=0.004,
-                 rank=0, world=1, dist=None, gather_device=None, tables=None, device=None):
+                 rank=0, world=1, dist=None, gather_device=None, tables=None, device=None, surf_index=None):
         """fieldlines: host geometry callable (see module docstring), or None together with
-        tables=SurfaceTables (row F1): then rho_arr must equal tables.s and the geometry is produced on
-        `device` by the HIP geometry kernel and consumed there (nothing but scalars returns to the host)."""
+        tables=SurfaceTables (row F1): then the geometry is produced on `device` by the HIP geometry kernel and consumed
+        there -- coarse scan, per-surface maximum, start points, refinement and final solve all stay in HBM and ONE small
+        copy returns the rows.  surf_index[k] = index of surface k (of rho_arr) in `tables`; default: the surface of
+        tables.s nearest to rho_arr[k].  Table sets that hold several equilibria (SurfaceTables.from_wouts: s repeats
+        per equilibrium) need the explicit index."""
         self.ctx = ctx
         self.tables = tables
         self.device = device
+        self._resident = {}
         if tables is not None:
             fieldlines = self._device_fieldlines_host
         self.fieldlines = fieldlines
@@ -96,6 +100,17 @@ class BallooningScan:
         self.rank, self.world, self.dist, self.gather_device = rank, world, dist, gather_device
         self._native_gather = world > 1 and getattr(ctx, "_comm_world", 0) == world
         self.own = shard_surfaces(len(self.rho_arr), rank, world)
+        if tables is not None:
+            if surf_index is None:
+                surf_index = [int(np.argmin(np.abs(tables.s - r))) for r in self.rho_arr]
+            self.surf_index = np.asarray(surf_index, dtype=np.int32)
+            if self.surf_index.shape != self.rho_arr.shape or (len(self.surf_index) and (
+                    self.surf_index.min() < 0 or self.surf_index.max() >= len(tables.s))):
+                raise IbsError("surf_index must give one table index in [0, %d) per surface" % len(tables.s))
+
+    def _own_surf(self):
+        """table indices of the surfaces this rank owns"""
+        return self.surf_index[np.asarray(self.own, dtype=np.int64)] if len(self.own) else np.zeros(0, dtype=np.int32)
 
     def _device_fieldlines_host(self, s, alphas):
         """geometry kernel behind the host-callable interface (used by the final solve / tests)"""
@@ -109,7 +124,7 @@ class BallooningScan:
         if self.tables is not None and self.device is not None and self.own:
             import torch
             na = len(self.alpha_scan)
-            surf = np.repeat([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own], na)
+            surf = np.repeat(self._own_surf(), na)
             r = self.ctx.fieldline_geometry(self.tables, surf, np.tile(self.alpha_scan, len(self.own)), self.theta,
                                             device=self.device)
             t0 = torch.from_numpy(self.theta0_scan).to(self.device)
@@ -175,7 +190,7 @@ class BallooningScan:
         from . import _lib
         lib = _lib.lib()
         lo = np.array([0.0, 0.0]); hi = np.array([np.pi, 0.5 * np.pi])
-        surf = np.array([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own])
+        surf = self._own_surf()
         n = len(surf)
         p = lambda a: C.c_void_p(a.ctypes.data)
         x = np.clip(np.asarray(starts, dtype=np.float64).reshape(n, 2), lo, hi)
@@ -204,7 +219,7 @@ class BallooningScan:
         round trip per evaluation.  Returns (x_opt (n, 2), f_opt (n,) = -gam, evaluations per surface (n,)).
         f_opt is the objective at the optimizer's last accepted iterate (scipy's res.fun); run() re-evaluates gam at
         x_opt like ball_scan.py:322-339 does."""
-        surf = np.array([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own])
+        surf = self._own_surf()
         xo, fo, ne, _ = self.ctx.refine(self.tables, surf, np.asarray(starts, dtype=np.float64).reshape(len(surf), 2),
                                         self.theta, self.del_alpha, maxiter, ftol, gtol, device=self.device)
         return xo, fo, ne
@@ -212,26 +227,88 @@ class BallooningScan:
     def final_solve_device(self, xo):
         """gam at the refined (alpha, theta0) of every owned surface: the final geometry + solve of ball_scan.py:322-339
         (the value the reference stores; the optimizer's own f is the value at its last ACCEPTED iterate, which after a
-        collapsed line search is the same point, after a maxiter stop as well)."""
+        collapsed line search is the same point, after a maxiter stop as well).  ONE field line per point
+        (ibs_gamma_points_f64): no tangent lines, no gradient sums."""
         import torch
-        surf = np.array([int(np.argmin(np.abs(self.tables.s - self.rho_arr[k]))) for k in self.own])
-        r = self.ctx.fieldline_geometry(self.tables, surf, np.ascontiguousarray(xo[:, 0]), self.theta, device=self.device)
-        n = len(surf)
-        N = len(self.theta)
-        geo = r["geo"].reshape(8, n, 1, N).expand(8, n, 3, N).permute(1, 2, 0, 3).contiguous()   # only the centre line matters for val
+        xo = np.asarray(xo, dtype=np.float64).reshape(-1, 2)
+        r = self.ctx.fieldline_geometry(self.tables, self._own_surf(), np.ascontiguousarray(xo[:, 0]), self.theta, device=self.device)
         t0 = torch.from_numpy(np.ascontiguousarray(xo[:, 1])).to(self.device)
-        val, _ = self.ctx.obj_w_grad(self.h, geo, t0, self.del_alpha)
-        return -val.cpu().numpy()
+        out = self.ctx.gamma_points(self.h, *[r["geo"][k] for k in range(7)], r["dPdrho"], t0)
+        return out["gam"].cpu().numpy()
+
+    # -- the whole per-surface worker of ball_scan.py:248-339 for the owned surfaces, resident in HBM
+    def _resident_inputs(self):
+        """device copies of what does not change between optimizer iterations: line -> (surface, alpha) tables of the coarse
+        scan, the grids, the point -> surface map of the refinement"""
+        import torch
+        key = (tuple(self.own), str(self.device))
+        if self._resident.get("key") != key:
+            dev, na = self.device, len(self.alpha_scan)
+            own = self._own_surf()
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            self._resident = dict(key=key, surf=t(np.repeat(own, na).astype(np.int32)), al=t(np.tile(self.alpha_scan, len(own))),
+                                  th=t(self.theta), t0=t(self.theta0_scan), alpha=t(self.alpha_scan), pt_surf=t(own.astype(np.int32)),
+                                  n_bad=torch.zeros(1, dtype=torch.int32, device=dev))
+        return self._resident
+
+    def device_rows(self, refine=True, phases=None):
+        """(theta0*, alpha*, gam) of the owned surfaces as an (n_own, 3) DEVICE tensor + a device scalar counting what went
+        wrong (flagged solves, non-finite maxima): geometry -> coarse scan with the fused per-surface first maximum
+        (ibs_gamma_scan_argmax_f64) -> start points on the device (ibs_scan_starts_f64) -> L-BFGS-B per surface on the device
+        (ibs_refine_f64 on device pointers) -> final geometry + solve, one line per point (ibs_gamma_points_f64).  Nothing
+        returns to the host in between.  phases: optional dict filled with the per-phase milliseconds (HIP events; adds
+        one synchronisation at the end)."""
+        import torch
+        ctx, dev = self.ctx, self.device
+        n = len(self.own)
+        if n == 0:
+            return torch.empty((0, 3), dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float64, device=dev)
+        res = self._resident_inputs()
+        ev = []
+
+        def mark():
+            if phases is not None:
+                e = torch.cuda.Event(enable_timing=True); e.record(); ev.append(e)
+        res["n_bad"].zero_()
+        mark()
+        geo = ctx.fieldline_geometry(self.tables, res["surf"], res["al"], res["th"], device=dev)
+        mark()
+        sc = ctx.gamma_scan_argmax(self.h, [geo["geo"][k] for k in range(7)], geo["dPdrho"], res["t0"], n)
+        start = ctx.scan_starts(res["alpha"], res["t0"], sc["pack"], res["n_bad"])
+        mark()
+        bad = ((sc["info"] >> 16) != 0).sum() + res["n_bad"][0]
+        if refine:
+            xo, fo, ne, rounds = ctx.refine_device(self.tables, res["pt_surf"], start, res["th"], self.del_alpha)
+            mark()
+            xa, xt = xo[:, 0].contiguous(), xo[:, 1].contiguous()
+            gf = ctx.fieldline_geometry(self.tables, res["pt_surf"], xa, res["th"], device=dev)
+            fin = ctx.gamma_points(self.h, *[gf["geo"][k] for k in range(7)], gf["dPdrho"], xt, want_info=True)
+            rows = torch.stack([xt, xa, fin["gam"]], dim=1)
+            bad = bad + ((fin["info"] >> 16) != 0).sum()
+            self.last_refine = dict(n_evals=ne, rounds=rounds)
+        else:
+            mark()
+            rows = torch.stack([start[:, 1], start[:, 0], sc["pack"][:, 0]], dim=1)
+        mark()
+        if phases is not None:
+            torch.cuda.synchronize()
+            names = ("geometry_ms", "scan_argmax_ms", "refine_ms", "final_solve_ms")
+            for k, nm in enumerate(names):
+                phases[nm] = ev[k].elapsed_time(ev[k + 1])
+        return rows, bad.to(torch.float64)
 
     def local_rows(self, refine=True):
         """(theta0*, alpha*, gam) of the surfaces this rank owns, (n_own, 3): coarse scan -> argmax -> refinement -> final
         solve (ball_scan.py:248-339), no collective"""
+        if self.tables is not None and self.device is not None:
+            import torch
+            rows, bad = self.device_rows(refine)
+            host = torch.cat([rows.reshape(-1), bad.reshape(1)]).cpu().numpy()          # the one copy (and synchronisation)
+            if host[-1] != 0 or not np.all(np.isfinite(host[:-1])):
+                raise IbsError("%d solves of this rank's scan were flagged or produced non-finite growth rates (status word != 0: "
+                               "invalid data or iteration cap)" % int(host[-1]))
+            return host[:-1].reshape(len(self.own), 3)
         tabs = self.coarse()
-        if refine and self.tables is not None and self.device is not None and self.own:
-            starts = np.array([pick_start(tab, self.alpha_scan, self.theta0_scan)[:2] for tab in tabs])
-            xo, fo, _ = self.refine_device(starts)
-            gam = self.final_solve_device(xo)                      # ball_scan.py:322-339: one more solve at the optimum
-            return np.stack([xo[:, 1], xo[:, 0], gam], axis=1)
         rows = []
         for k, tab in zip(self.own, tabs):
             a0, t0, sigma0, ij = pick_start(tab, self.alpha_scan, self.theta0_scan)

@@ -227,6 +227,69 @@ class Context:
             out.update(info=info)
         return out
 
+    def gamma_scan_argmax(self, h, geo7, dPdrho, theta0, n_surf):
+        """coarse scan + per-surface first maximum in ONE C call on device tensors (ibs_gamma_scan_argmax_f64; replaces
+        ball_scan.py:248-295 for all surfaces at once).  geo7: seven (n_lines, N) tensors, lines surface-major.
+        Returns dict(gam, lam (n_lines, n_theta0), pack (n_surf, 2) = (max, first row-major index), info)."""
+        import torch
+        ar = _Args()
+        n_lines, N = geo7[0].shape
+        n_t0 = int(theta0.shape[0])
+        ptrs = [ar.inp(a) for a in geo7]
+        pdP, pt0 = ar.inp(dPdrho), ar.inp(theta0)
+        if ar.mem != MEM_DEVICE:
+            raise IbsError("gamma_scan_argmax takes device tensors")
+        ref = geo7[0]
+        self._stream_from_torch(ref)
+        gam, pgam = ar.out((n_lines, n_t0), ref)
+        lam, plam = ar.out((n_lines, n_t0), ref)
+        pack, ppack = ar.out((n_surf, 2), ref)
+        info, pinfo = ar.out((n_lines, n_t0), ref, dtype=np.int32)
+        check(self._lib.ibs_gamma_scan_argmax_f64(self._h, n_lines, n_t0, N, float(h), *ptrs, N, pdP, pt0, int(n_surf),
+                                                  pgam, plam, ppack, pinfo), "ibs_gamma_scan_argmax_f64")
+        return dict(gam=gam, lam=lam, pack=pack, info=info)
+
+    def gamma_points(self, h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, dPdrho, theta0,
+                     want_X=False, want_dtheta0=False, want_info=False):
+        """one (line, theta0) pair per point (ibs_gamma_points_f64: the final solve of ball_scan.py:322-339 for many
+        surfaces at once).  geometry arrays (n_pts, N); dPdrho, theta0 (n_pts,).  Returns dict(gam, lam[, X, dX][, ...])."""
+        ar = _Args()
+        n_pts, N = bmag.shape
+        ptrs = [ar.inp(a) for a in (bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22)]
+        pdP, pt0 = ar.inp(dPdrho), ar.inp(theta0)
+        ref = bmag if ar.mem == MEM_DEVICE else None
+        if ref is not None:
+            self._stream_from_torch(ref)
+        gam, pgam = ar.out((n_pts,), ref)
+        lam, plam = ar.out((n_pts,), ref)
+        X, pX = ar.out((n_pts, N), ref, want=want_X)
+        dX, pdX = ar.out((n_pts, N), ref, want=want_X)
+        dth, pdth = ar.out((n_pts,), ref, want=want_dtheta0)
+        info, pinfo = ar.out((n_pts,), ref, dtype=np.int32, want=want_info)
+        rc = check(self._lib.ibs_gamma_points_f64(self._h, n_pts, N, float(h), *ptrs, N, pdP, pt0, pgam, plam, pX, pdX,
+                                                  pdth, pinfo, ar.mem), "ibs_gamma_points_f64")
+        out = dict(gam=gam, lam=lam, nbad=rc)
+        if want_X:
+            out.update(X=X, dX=dX)
+        if want_dtheta0:
+            out.update(dgam_dtheta0=dth)
+        if want_info:
+            out.update(info=info)
+        return out
+
+    def scan_starts(self, alpha_scan, theta0_scan, pack, n_bad):
+        """start points (n_surf, 2) = (alpha, theta0) of the refinement from the per-surface maxima `pack`, on the device
+        (ibs_scan_starts_f64; ball_scan.py:279-295).  All arguments device tensors; n_bad: int32 tensor of one element that
+        accumulates the number of surfaces whose maximum is not finite."""
+        import torch
+        n_surf = pack.shape[0]
+        start = torch.empty((n_surf, 2), dtype=torch.float64, device=pack.device)
+        self._stream_from_torch(pack)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.ibs_scan_starts_f64(self._h, n_surf, alpha_scan.shape[0], theta0_scan.shape[0], p(alpha_scan),
+                                            p(theta0_scan), p(pack), p(start), C.c_void_p(None), p(n_bad)), "ibs_scan_starts_f64")
+        return start
+
     def obj_w_grad(self, h, geo, theta0, del_alpha=0.004, want_info=False):
         """geo: (n_pts, 3, 8, N) -- lines (alpha-d/2, alpha, alpha+d/2) x (bmag, gradpar, cvdrift, cvdrift0,
         gds2, gds21, gds22, gbdrift); theta0: (n_pts,).  Returns (val (n_pts,), jac (n_pts, 2)) with the
@@ -348,6 +411,28 @@ class Context:
                                                 p(d_th), *tail, p(xo), p(fo), p(ne), MEM_DEVICE), "ibs_refine_f64")
         h = out.cpu()
         return (h[:2 * n].view(n, 2).numpy(), h[2 * n:3 * n].numpy(), h[3 * n:].view(torch.int32)[:n].numpy().copy(), rounds)
+
+    def refine_device(self, tables, d_pt_surf, d_start, d_theta, del_alpha=0.004, maxiter=30, ftol=5.0e-11, gtol=2.0e-8):
+        """refine() on device tensors, results left in HBM: d_pt_surf (n,) int32, d_start (n, 2), d_theta (N,) float64.
+        Returns (x_opt (n, 2), f_opt (n,) = -gam, n_evals (n,) int32, rounds); the tensors are stream-ordered on the
+        current torch stream (include/ibs.h: ibs_refine_f64 with device pointers)."""
+        import torch
+        device = d_start.device
+        n = int(d_pt_surf.shape[0])
+        dev = self._device_tables(tables, device)
+        nr = (len(tables.rows_mn), len(tables.rows_nyq))
+        out = torch.empty((4 * n,), dtype=torch.float64, device=device)     # x_opt (2n) | f_opt (n) | n_evals (n int32 in n/2.. words)
+        xo, fo = out[:2 * n].view(n, 2), out[2 * n:3 * n]
+        ne = out[3 * n:].view(torch.int32)[:n]
+        self._stream_from_torch(out)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rounds = check(self._lib.ibs_refine_f64(self._h, len(tables.s), len(tables.xm), len(tables.xm_nyq),
+                                                *[p(t) for t in dev[:7]], nr[0], p(dev[7]), nr[1], p(dev[8]),
+                                                float(tables.dn_mn), float(tables.dn_nyq), n, p(d_pt_surf), p(d_start),
+                                                int(d_theta.shape[0]), p(d_theta), float(del_alpha), int(maxiter), float(ftol),
+                                                float(gtol), p(xo), p(fo), p(ne), MEM_DEVICE), "ibs_refine_f64")
+        self._keep_refine = (d_pt_surf, d_start, d_theta, out)
+        return xo, fo, ne, rounds
 
     def refine_stats(self):
         """(evaluations, forward sweeps, rounds needed, rounds enqueued) of the last refine() call of this context"""

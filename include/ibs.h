@@ -167,6 +167,26 @@ int ibs_gamma_scan_argmax_f64(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, i
                               const double* dPdrho, const double* theta0, int32_t n_surf, double* gam, double* lam,
                               double* pack, int32_t* info);
 
+/* One (field line, theta0) PAIR per point: growth rates of n_pts lines, line i at its own theta0[i].
+ * Replaces: the final solve of ball_scan.py:322-339 (one more vmec_fieldlines + gamma_ball_full at the refined
+ * (alpha*, theta0*) of every surface) for all surfaces of a rank -- or of all equilibria of an optimizer step -- at once.
+ * Arrays as in ibs_gamma_scan_f64 with n_lines = n_pts ([n_pts][ld]); theta0[n_pts]; outputs [n_pts] (X, dX: [n_pts][N]). */
+int ibs_gamma_points_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const double* bmag, const double* gradpar,
+                         const double* cvdrift, const double* cvdrift0, const double* gds2, const double* gds21,
+                         const double* gds22, int64_t ld, const double* dPdrho, const double* theta0, double* gam,
+                         double* lam, double* X, double* dX, double* dgam_dtheta0, int32_t* info, int32_t mem);
+
+/* Start points of the refinement from the coarse scan's per-surface maxima, on the device (device pointers only).
+ * Replaces: ball_scan.py:279-295 -- the first maximum of the surface's (alpha, theta0) table gives x0 = (alpha_scan[i],
+ * theta0_scan[j]) and sigma0 = 1.3 |gam| + 0.05 (:283-295); an all-zero table starts from (0, 0) with sigma0 = 0.05 (:279-282).
+ *   pack[n_surf][2] = (max, first row-major index as a double): the output of ibs_gamma_scan_argmax_f64 /
+ *   ibs_surface_argmax_pack_f64;  alpha[n_alpha], theta0[n_theta0]: the scan grids (ball_scan.py:225-226);
+ *   start[n_surf][2] = (alpha, theta0): the `start` input of ibs_refine_f64;  sigma0[n_surf] (optional; the deterministic
+ *   solver ignores it);  *n_bad (device int, NOT cleared here) += the number of surfaces whose maximum is not finite (a
+ *   flagged or NaN table: ball_scan.py would have crashed in eigs; their start is (0, 0)). */
+int ibs_scan_starts_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_alpha, int32_t n_theta0, const double* alpha,
+                        const double* theta0, const double* pack, double* start, double* sigma0, int32_t* n_bad);
+
 /* Objective and Hellmann-Feynman ("adjoint") gradient at n_pts points (alpha, theta0).
  * Replaces: utils.py:1632-1728 obj_w_grad, given the geometry of the three field lines
  * (alpha - del_alpha/2, alpha, alpha + del_alpha/2) that utils.py:1641-1646 obtains from vmec_fieldlines.
@@ -207,6 +227,21 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
                                const double* line_alpha, int32_t N, const double* theta, int64_t ld, double* geo,
                                double* dPdrho, int32_t nrows_mn, const int32_t* rows_mn, int32_t nrows_nyq,
                                const int32_t* rows_nyq, double dn_mn, double dn_nyq, int32_t mem);
+
+/* Host part of the geometry producer: the per-surface Fourier coefficient vectors of n_eq equilibria at n_s surfaces.
+ * Replaces: vmec_splines (utils.py:58-119: one InterpolatedUnivariateSpline per mode and array) + their evaluation at the
+ * surface (utils.py:311-357) for all equilibria of an optimizer step (sims_runner_NCSX.py:151-276) at once.  Cubic
+ * interpolating splines are linear in the data and all modes share the radial meshes, so the caller supplies four weight
+ * matrices [n_s][ns] -- value / derivative on VMEC's full mesh, value / derivative on the half mesh with a zero first
+ * column (half-mesh data live in columns 1..ns-1) -- built once per (ns, surfaces) by splining the identity.
+ *   tabs[n_eq][9]: pointers to the (modes, ns) row-major wout arrays rmnc zmns lmns (mnmax rows) gmnc bmnc bsupvmnc
+ *   bsubsmns bsubumnc bsubvmnc (mnmax_nyq rows);  tab_mn [n_eq * n_s][6][mnmax], tab_nyq [n_eq * n_s][7][mnmax_nyq]: the
+ *   inputs of ibs_fieldline_geometry_f64 (surface index = i_eq * n_s + i_s).  Host pointers only; n_threads <= 0: all cores.
+ * No GPU is involved; results do not depend on the thread count. */
+int ibs_surface_tables_f64(int32_t n_eq, int32_t ns, int32_t n_s, int32_t mnmax, int32_t mnmax_nyq,
+                           const double* const* tabs, const double* w_full, const double* w_full_d,
+                           const double* w_half, const double* w_half_d, double* tab_mn, double* tab_nyq,
+                           int32_t n_threads);
 
 /* Refinement of the per-surface maximum: maximise gam over (alpha, theta0) in
  * [0, pi] x [0, pi/2] from n_pts start points at once, entirely on the device.

@@ -3,6 +3,7 @@ oracle standing in for the GPU, including a world_size-2 gloo run."""
 import json
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -398,3 +399,112 @@ def test_bench_watchdog_prints_the_headline_once_and_leaves_with_its_own_status(
             d = json.loads(lines[0])
             assert d["value"] == 1.0 and "test phase" in d["aborted"]
         assert "overran" in r.stderr
+
+
+def test_surface_tables_of_many_equilibria_native_host_routine():
+    """SurfaceTables.from_wouts (ibs_surface_tables_f64: the radial spline step of ALL equilibria of an optimizer step,
+    threaded, on the host): (a) against the values the reference's own splines produced (G8, 1e-12); (b) against
+    concat(from_wout) on the 73 emulated equilibria of configs[3] (surface index = i_eq * n_s + i_s); (c) the same bits
+    whatever the thread count."""
+    import ibs_amd
+    from ibs_amd.geometry import NAMES_MN, NAMES_NYQ
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import emulated_equilibria
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    ref = np.load(os.path.join(G, "G8_surface_tables.npz"))
+    tab = ibs_amd.SurfaceTables.from_wouts([wout], ref["s"])
+    for q, k in enumerate(NAMES_MN):
+        assert np.abs(tab.tab_mn[:, q] - ref[k]).max() <= 1e-12 * max(1.0, np.abs(ref[k]).max()), k
+    for q, k in enumerate(NAMES_NYQ):
+        assert np.abs(tab.tab_nyq[:, q] - ref[k]).max() <= 1e-12 * max(1.0, np.abs(ref[k]).max()), k
+    for col, k in ((1, "iota"), (2, "d_iota_d_s"), (3, "d_pressure_d_s")):
+        assert np.abs(tab.scal[:, col] - ref[k]).max() <= 1e-12 * max(1.0, np.abs(ref[k]).max()), k
+    wouts, steps, x0 = emulated_equilibria(wout)
+    sv = np.linspace(0.5, 0.95, 5)
+    one = ibs_amd.SurfaceTables.concat([ibs_amd.SurfaceTables.from_wout(w, sv) for w in wouts[:9]])
+    many = ibs_amd.SurfaceTables.from_wouts(wouts[:9], sv)
+    for k in ("s", "tab_mn", "tab_nyq", "scal"):
+        a, b = getattr(one, k), getattr(many, k)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-13 * np.abs(a).max(), k
+    assert np.array_equal(one.rows_mn, many.rows_mn) and one.dn_nyq == many.dn_nyq
+    for nt in (1, 3):
+        again = ibs_amd.SurfaceTables.from_wouts(wouts[:9], sv, n_threads=nt)
+        assert np.array_equal(again.tab_mn, many.tab_mn) and np.array_equal(again.tab_nyq, many.tab_nyq)
+    bad = dict(wouts[1]); bad["xm"] = wouts[1]["xm"][::-1].copy()
+    with pytest.raises(ValueError):
+        ibs_amd.SurfaceTables.from_wouts([wouts[0], bad], sv)
+
+
+class _FakeScan:
+    """stands in for BallooningScan.device_rows in the CPU test of AdjointStep: rows are a function of the tables alone"""
+
+    def __init__(self, tables, fail):
+        self.tables, self.fail = tables, fail
+
+    def device_rows(self, refine=True, phases=None):
+        import torch
+        if self.fail:
+            raise ValueError("injected failure")
+        t = self.tables
+        gam = 1e-3 * (t.tab_mn[:, 0, :].sum(axis=1) - 1.6) + 2e-4 * t.s            # depends on the (perturbed) rmnc row sums
+        rows = np.stack([0.5 * t.s, 1.0 + t.s, gam], axis=1)
+        return torch.from_numpy(rows), torch.zeros((), dtype=torch.float64)
+
+
+def _worker_adjoint(rank, world, port, q, fail_rank):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import emulated_equilibria
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    wout = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "G8_wout_ncsx_op.npz")))
+    wouts, steps, x0 = emulated_equilibria(wout)
+    wouts, steps = wouts[:7], steps[:7]
+    step = ibs_amd.AdjointStep(None, bo.theta_grid(129), np.linspace(0.5, 0.95, 5), torch.device("cpu"), rank=rank, world=world,
+                               dist=dist if world > 1 else None, n_threads=2)
+    step._scan_for = lambda tables, n: _FakeScan(tables, rank == fail_rank)
+    try:
+        r = step.run(wouts, 0.8 + 0.01 * np.arange(7), steps)
+        out = ("ok", {k: np.asarray(v).tolist() for k, v in r.items()})
+    except (ibs_amd.IbsError, ValueError) as e:
+        out = ("raised", str(e))
+    q.put((rank, out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_two_rank_gloo_adjoint_step_equals_single_rank(fail_rank):
+    """AdjointStep: the equilibria of an optimizer step dealt round-robin over two ranks (the reference's one-srun-per-DOF
+    level, ball_submit.py:64-95), ONE gather of the rows, objective and forward-difference gradient
+    (sims_runner_NCSX.py:249-261) identical on both ranks and equal to the one-rank result; a failing rank is raised
+    everywhere after the collective."""
+    import queue
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_adjoint, args=(r, 2, port, q, fail_rank)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    if fail_rank >= 0:
+        assert res[0][0] == "raised" and res[1][0] == "raised" and "injected failure" in res[fail_rank][1]
+        return
+    q1 = queue.Queue()
+    _worker_adjoint(0, 1, 0, q1, -1)
+    single = q1.get()[1]
+    assert res[0][0] == "ok" and res[1][0] == "ok" and single[0] == "ok"
+    for k in ("gam", "theta0", "alpha", "f0", "dfobj", "fobj"):
+        assert np.array_equal(np.asarray(res[0][1][k]), np.asarray(res[1][1][k])), k
+        assert np.array_equal(np.asarray(res[0][1][k]), np.asarray(single[1][k])), k
+    f0 = np.asarray(single[1]["f0"]); gam = np.asarray(single[1]["gam"])
+    assert gam.shape == (7, 5) and abs(f0[2] - (0.82 + 50.0 * np.maximum(gam[2] + 2e-4, 0).sum())) < 1e-14

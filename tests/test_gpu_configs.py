@@ -6,6 +6,7 @@
 Checked against the C oracle / numpy oracles where they finish in seconds, otherwise through size-independent
 properties (Sturm-count certificates, covariance under scaling and shifts)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -21,37 +22,9 @@ def ctx():
     return ibs_amd.Context(0)
 
 
-def c5_family(dev, family, n, N, seed):
-    """'smooth' = s-alpha coefficients (bishop_ball_s-alpha.py:30-45, f = g), shat ~ U(0.1, 2), alpha ~ U(0, 1.2),
-    theta0 ~ U(0, pi/2); 'rough' = iid per point inside the measured NCSX_op envelopes."""
-    import torch
-    gen = torch.Generator(device=dev); gen.manual_seed(seed)
-    u = lambda lo, hi, shape: lo + (hi - lo) * torch.rand(shape, dtype=torch.float64, device=dev, generator=gen)
-    h = 8 * np.pi / (N - 1)
-    if family == "smooth":
-        th = torch.linspace(-4 * np.pi, 4 * np.pi, N, dtype=torch.float64, device=dev)
-        sh, al, t0 = u(0.1, 2.0, (n, 1)), u(0.0, 1.2, (n, 1)), u(0.0, np.pi / 2, (n, 1))
-        lam = sh * (th[None] - t0) - al * (torch.sin(th)[None] - torch.sin(t0))
-        g = 1 + lam ** 2
-        c = al * (torch.cos(th)[None] + torch.sin(th)[None] * lam)
-        del lam
-        return h, g, c, g
-    g = torch.exp(u(np.log(0.01), np.log(50.0), (n, N)))
-    c = u(-2.5, 3.5, (n, N))
-    f = torch.exp(u(np.log(0.2), np.log(3e3), (n, N)))
-    return h, g, c, f
-
-
-def norm_a(h, g, c, f, chunk=65536):
-    """the solver's ||A|| bound per system: max_r (|d_r| + e_r + e_{r+1}) / f_r   (utils.py:1584-1592 rows)"""
-    import torch
-    out = torch.empty(g.shape[0], dtype=torch.float64, device=g.device)
-    for a in range(0, g.shape[0], chunk):
-        gg, cc, ff = g[a:a + chunk], c[a:a + chunk], f[a:a + chunk]
-        e = 0.5 * (gg[:, :-1] + gg[:, 1:]) / h ** 2
-        d = cc[:, 1:-1] - (e[:, :-1] + e[:, 1:])
-        out[a:a + chunk] = ((d.abs() + e[:, :-1] + e[:, 1:]) / ff[:, 1:-1]).amax(dim=1)
-    return out
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the synthetic inputs of configs[3] and configs[4] live with the bench
+from bench import c5_family, norm_a, emulated_equilibria, ncsx_boundary_dofs  # noqa: E402,F401
 
 
 @pytest.mark.parametrize("nz", [256, 1024, 2048])
@@ -146,39 +119,6 @@ def test_config5_fp32_stated_tolerances(ctx, nz):
 
 
 # ---------------------------------------------------------------------------------------------- configs[3]
-def ncsx_boundary_dofs(xm, xn, nfp):
-    """the 72 boundary DOFs of the NCSX / HBERG set-up (create_dict.py:29-34, 47-55): RBC(m, n) and ZBS(m, n) for
-    m = 0..6 with |n| <= (4, 3, 3, 2, 2, 2, 1)[m] (m = 0: n = 1..tor only) -> list of (table name, row in the wout mode list)"""
-    pol = [0, 1, 2, 3, 4, 5, 6]; tor = [4, 3, 3, 2, 2, 2, 1]
-    dofs = []
-    for name in ("rmnc", "zmns"):
-        for m, t in zip(pol, tor):
-            for n in (range(1, t + 1) if m == 0 else range(-t, t + 1)):
-                row = np.nonzero((xm == m) & (xn == n * nfp))[0]
-                assert len(row) == 1, (m, n)
-                dofs.append((name, int(row[0])))
-    return dofs
-
-
-def emulated_equilibria(wout0):
-    """without VMEC the 72 DOF-perturbed equilibria are emulated on the shipped NCSX_op tables: the boundary
-    value x of DOF k is stepped by abs 1e-3 if |x| <= 1e-2 else rel 2e-3 (create_dict.py:67, 70; ball_scan.py:129-139)
-    and the change carried inward with an s^2 profile.  Identical arithmetic, not a consistent equilibrium."""
-    nfp = int(wout0["nfp"])
-    dofs = ncsx_boundary_dofs(np.asarray(wout0["xm"]), np.asarray(wout0["xn"]), nfp)
-    assert len(dofs) == 72
-    prof = np.linspace(0, 1, wout0["rmnc"].shape[1]) ** 2
-    wouts, steps, x0 = [wout0], [1.0], []
-    for name, row in dofs:
-        w = dict(wout0)
-        w[name] = wout0[name].copy()
-        x = w[name][row, -1]
-        step = 1.0e-3 if abs(x) <= 1.0e-2 else 2.0e-3 * x
-        w[name][row, :] += step * prof
-        wouts.append(w); steps.append(step); x0.append(x)
-    return wouts, np.array(steps), np.array(x0)
-
-
 def test_config4_full_adjoint_step_73_equilibria(ctx):
     """BASELINE configs[3] at its shape: 73 equilibria x 5 surfaces x 24 alpha x 15 theta0 = 131,400 solves on the
     reference's N = 969 grid, ONE geometry launch + ONE scan launch + ONE argmax launch, then the objective and its

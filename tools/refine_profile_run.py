@@ -35,13 +35,12 @@ if which in ("small", "both"):
     tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
     run("reference batch", ibs_amd.BallooningScan(ctx, None, th, svals, tables=tabs, device=dev))
 if which in ("big", "both"):
-    n_eq = 73
-    tabs_all = []
-    for q in range(n_eq):
-        w = dict(wout)
-        if q:
-            w["rmnc"] = wout["rmnc"].copy(); w["rmnc"][q % 200, :] *= (1 + 2e-3 * np.linspace(0, 1, wout["rmnc"].shape[1]) ** 2)
-        tabs_all.append(ibs_amd.SurfaceTables.from_wout(w, svals))
-    big = ibs_amd.SurfaceTables.concat(tabs_all) if hasattr(ibs_amd.SurfaceTables, "concat") else None
-    run("config-4 shape", ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), nalpha=na, ntheta0=nt0, tables=big, device=dev))
+    import bench
+    wouts, _, _ = bench.emulated_equilibria(wout)          # base + the 72 DOF-stepped equilibria of configs[3]
+    n_eq = len(wouts)
+    big = ibs_amd.SurfaceTables.from_wouts(wouts, svals)
+    # (surface k of the scan = table index k: tables.s repeats per equilibrium, the nearest-s default would map every
+    #  equilibrium onto the first one -- which is what this tool measured until round 3)
+    run("config-4 shape", ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), nalpha=na, ntheta0=nt0, tables=big, device=dev,
+                                                 surf_index=np.arange(n_eq * ns)))
 print("refine stats of the last call (evaluations, sweeps, rounds, rounds enqueued):", ctx.refine_stats())
