@@ -575,7 +575,7 @@ def dropin_call(ctx, reps=200):
     eigenfunction output, download -- the per-call latency a ball_scan.py loop would see (reference: ~55 ms per call)."""
     import ibs_amd
     g3 = np.load(os.path.join(ROOT, "tests", "golden", "G3_ncsx_lines.npz"))
-    line = g3["geo_969"][5]
+    line = g3["geo_969"][1]
     th = ibs_amd.theta_grid(969)
     dP = float(-0.5 * np.mean((line[2] - line[7]) * line[0] ** 2))
     cv = line[2] + 0.3 * line[3]; gd = line[4] + 2 * 0.3 * line[5] + 0.09 * line[6]       # ball_scan.py:267-268 at theta0 = 0.3

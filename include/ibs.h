@@ -236,7 +236,7 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
  * column (half-mesh data live in columns 1..ns-1) -- built once per (ns, surfaces) by splining the identity.
  *   tabs[n_eq][9]: pointers to the (modes, ns) row-major wout arrays rmnc zmns lmns (mnmax rows) gmnc bmnc bsupvmnc
  *   bsubsmns bsubumnc bsubvmnc (mnmax_nyq rows);  tab_mn [n_eq * n_s][6][mnmax], tab_nyq [n_eq * n_s][7][mnmax_nyq]: the
- *   inputs of ibs_fieldline_geometry_f64 (surface index = i_eq * n_s + i_s).  Host pointers only; n_threads <= 0: all cores.
+ *   inputs of ibs_fieldline_geometry_f64 (surface index = i_eq * n_s + i_s).  Host pointers only; n_threads <= 0: up to 16.
  * No GPU is involved; results do not depend on the thread count. */
 int ibs_surface_tables_f64(int32_t n_eq, int32_t ns, int32_t n_s, int32_t mnmax, int32_t mnmax_nyq,
                            const double* const* tabs, const double* w_full, const double* w_full_d,

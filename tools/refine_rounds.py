@@ -7,15 +7,11 @@ ctx = ibs_amd.Context(0); dev = torch.device("cuda", 0)
 wout = dict(np.load(os.path.join(ROOT, "tests/golden/G8_wout_ncsx_op.npz")))
 N, ns = 969, 5
 svals = np.linspace(0.5, 0.95, ns); th = ibs_amd.theta_grid(N)
-n_eq = 73
-tabs_all = []
-for q in range(n_eq):
-    w = dict(wout)
-    if q:
-        w["rmnc"] = wout["rmnc"].copy(); w["rmnc"][q % 200, :] *= (1 + 2e-3 * np.linspace(0, 1, wout["rmnc"].shape[1]) ** 2)
-    tabs_all.append(ibs_amd.SurfaceTables.from_wout(w, svals))
-big = ibs_amd.SurfaceTables.concat(tabs_all)
-scan = ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), tables=big, device=dev)
+import bench
+wouts, _, _ = bench.emulated_equilibria(wout)          # base + the 72 DOF-stepped equilibria of configs[3]
+n_eq = len(wouts)
+big = ibs_amd.SurfaceTables.from_wouts(wouts, svals)
+scan = ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), tables=big, device=dev, surf_index=np.arange(n_eq * ns))
 st = np.array([ibs_amd.pick_start(t, scan.alpha_scan, scan.theta0_scan)[:2] for t in scan.coarse()])
 xo, fo, ne = scan.refine_device(st)
 nc = [int((ne > r).sum()) for r in range(ne.max())]
