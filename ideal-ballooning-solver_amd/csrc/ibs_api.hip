@@ -63,6 +63,7 @@ struct ibs_options {
   int geo_lpp = 0;        // lanes per grid point of the geometry kernel: 1 | 2 | 4
   int gcf_rows = -1;      // raw systems on long grids: -1 / 1 = row-streamed kernel, 0 = the 3-row staging of k_solve_gcf
   int pack_mode = 0;      // hand-off of the fused scan + argmax: 1 = write-through + sc1 loads, 2 = release / acquire fences
+  int f32_lam = 0;        // FP32 eigenvalue-only requests: 0 = by grid size, 1 = all-FP32 iteration + FP64 certificate, 2 = FP32 in HBM + FP64 solver
   int refine_tangent = -1; // refinement: alpha-tangent of a point staged in LDS (1) or read from global memory in the sums (0); -1 = by batch size
   double chain_w1 = 0.25, chain_w2 = 1.0;   // relative widths of the chain's warm starts
 };
@@ -185,7 +186,7 @@ int pick_lanes(const ibs_ctx* ctx, int N, long n_sys) {
 
 __global__ void k_count_status(long n, const int* info, int* out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int bad = (i < n) && ((info[i] >> 16) != 0);
+  int bad = (i < n) && (((info[i] >> 16) & 3) != 0);      // (status bit 2 is informational: an FP32 result re-solved in FP64)
   unsigned long long m = __ballot(bad);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
 }
@@ -283,10 +284,26 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     }
   }
   if constexpr (sizeof(T) == 4) {
-    // FP32 systems whose growth rate or eigenfunction is wanted: widened to FP64 while they are staged (k_solve_gcf_wide);
-    // lam alone stays with the all-FP32 kernel
-    auto fw = ibs::launch_table().gcf_f32_wide[M];
-    if ((gam || X || dX) && fw) { launch = fw; per_wave = (size_t)3 * ibs::lds_pitch(N) * sizeof(double); }
+    // FP32 systems whose growth rate or eigenfunction is wanted: FP32 in HBM, widened to FP64 as they are read, solved by the
+    // FP64 solver -- in the same three forms as the FP64 entry point (sub-wave for large batches of short grids, row-streamed
+    // for long grids, else one wave per system with the three rows staged).  lam alone stays with the all-FP32 kernel, whose
+    // result is certified by an FP64 count pair (k_solve_gcf<float, M>).
+    // lam alone: the all-FP32 iteration with its FP64 certificate pays on long grids; where the sub-wave forms exist
+    // (N <= 642) the FP64 solver on FP32 bytes, without the growth-rate stage, is faster (option f32_lam overrides)
+    const bool wide_lam = ctx->opt.f32_lam == 2 || (ctx->opt.f32_lam == 0 && pick_lanes(ctx, N, (long)n_sys) != 64);
+    if (gam || X || dX || wide_lam) {
+      auto fw = ibs::launch_table().gcf_f32_wide[M];
+      if (fw) { launch = fw; per_wave = (size_t)3 * ibs::lds_pitch(N) * sizeof(double); }
+      const int P = pick_lanes(ctx, N, (long)n_sys);
+      if (P != 64) {
+        const int Mg = (N - 2 + P - 1) / P;
+        auto fg = ibs::launch_table().gcf_f32w_g[P == 32 ? 0 : 1][Mg];
+        if (fg) { launch = fg; M = Mg; per_wave = (size_t)(64 / P) * ibs::lds_pitch(N) * sizeof(double); }
+      } else {
+        auto fr = ibs::launch_table().gcf_f32w_rows[M];
+        if (fr && ctx->opt.gcf_rows != 0) { launch = fr; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(double); }
+      }
+    }
   }
   if constexpr (sizeof(T) == 8) {
     // long grids, one wave per system: stream the three rows through ONE LDS row per wave (k_solve_gcf_rows) -- the
@@ -446,6 +463,7 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   else if (n == "geo_lpp") c->opt.geo_lpp = reset ? c->opt_created.geo_lpp : (int)value;
   else if (n == "gcf_rows") c->opt.gcf_rows = reset ? c->opt_created.gcf_rows : (int)value;
   else if (n == "pack_mode") c->opt.pack_mode = reset ? c->opt_created.pack_mode : (int)value;
+  else if (n == "f32_lam") c->opt.f32_lam = reset ? c->opt_created.f32_lam : (int)value;
   else if (n == "refine_tangent") c->opt.refine_tangent = reset ? c->opt_created.refine_tangent : (int)value;
   else if (n == "chain_w1") c->opt.chain_w1 = reset ? c->opt_created.chain_w1 : value;
   else if (n == "chain_w2") c->opt.chain_w2 = reset ? c->opt_created.chain_w2 : value;

@@ -56,6 +56,16 @@ struct SrcGCFH {
   __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { const int q = lpos(j); g_ = gs[q]; c_ = cs[q]; f_ = fs[q]; }
 };
 
+// FP32 rows staged in LDS read as FP64 (the certificate of the all-FP32 kernel k_solve_gcf<float, M>)
+template <typename TS>
+struct SrcGCFF {
+  static constexpr bool kHasGh = false;
+  const TS* gs; const TS* cs; const TS* fs;
+  __device__ __forceinline__ double g(int j) const { return (double)gs[lpos(j)]; }
+  __device__ __forceinline__ double c(int j) const { return (double)cs[lpos(j)]; }
+  __device__ __forceinline__ double f(int j) const { return (double)fs[lpos(j)]; }
+};
+
 template <typename T, bool SCALED = false>
 struct SrcGeo {
   static constexpr bool kHasGh = false;
@@ -368,6 +378,35 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
     if constexpr (kTrial) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
     else lam = ws.solve(inf);
   } else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  if constexpr (sizeof(T) == 4) {
+    // FP64 CERTIFICATE of the all-FP32 result.  FP32 Sturm counts are good to ~eps32 ||A||; between two close eigenvalues a
+    // count off by one lets the bracket close on lam_2 (1e-4 of the smooth config-5 systems at N_zeta <= 512, round 3).  The
+    // rows are still staged: the FP64 solver is set up on them (every float is a double) and ONE count pair at
+    // lam32 +- n eps32 ||A|| says whether lam_max lies within that distance (count 0 above, >= 1 below: backward-stable).  A
+    // system that fails is solved in FP64 from the trial bracket; its info word carries status bit 2 (informational).
+    if (!bad) {
+      WaveSolver<double, M> wd;
+      const SrcGCFF<T> srcw{gs, cs, fs};
+      const bool bad2 = wd.template setup<SrcGCFF<T>, true>(srcw, N, (double)h);
+      const double tolc = (double)(N - 2) * (double)Eps<float>::v * wd.normA;
+      bool ok = !bad2 && wd.sweep_fwd((double)lam + tolc) == 0;
+      if (ok) ok = wd.sweep_fwd((double)lam - tolc) >= 1;
+      if (!ok && !bad2) {                                  // (wave-uniform)
+        SolveInfo inf2{0, 0};
+        double g_, w_;
+        wd.trial_guess(g_, w_);
+        lam = (T)wd.solve(inf2, true, g_, w_);
+        inf.iters += inf2.iters + 2; inf.status |= inf2.status | 4;
+      } else inf.iters += 2;
+    }
+  }
+  if (!gam_out && !X_out && !dX_out) {     // (kernel-uniform) eigenvalues only: no eigenvector, no Simpson sums
+    if (lane == 0 && valid) {
+      if (lam_out) lam_out[sysc] = lam;
+      if (info_out) info_out[sysc] = inf.iters | (inf.status << 16);
+    }
+    return;
+  }
   if constexpr (M >= 3) {                  // f is read from its LDS slot, which X / dX reuse afterwards
     finish_chunk<T, M, SrcGCF<T>, false>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                          valid ? gam_out : nullptr, valid ? X_out : nullptr,
@@ -422,6 +461,13 @@ __global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float
   T lam = T(0);
   if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
   else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  if (!gam_out && !X_out && !dX_out) {     // (kernel-uniform) eigenvalues only
+    if (lane == 0 && valid) {
+      if (lam_out) lam_out[sysc] = (float)lam;
+      if (info_out) info_out[sysc] = inf.iters | (inf.status << 16);
+    }
+    return;
+  }
   if constexpr (M >= 3) {
     finish_chunk<T, M, SrcGCF<T>, false, 1, float>(ws, src, N, (T)h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                                     valid ? gam_out : nullptr, valid ? X_out : nullptr,
@@ -440,8 +486,8 @@ __global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float
 // CU, 28 KB at 1024 -> five).  Here the three rows pass through ONE row, one after the other, the way k_sturm_count moves
 // them: set-up is split into a g pass (half-grid e, diagonal scaling), an f pass and a c pass; after the solve the growth
 // rate re-stages g (scaling of the eigenvector + the g dX^2 sum), then c, then f.  LDS per wave: N doubles.
-template <typename T, int M>
-__device__ __forceinline__ void stage_row(T* row, const T* __restrict__ src, int N, int lane) {
+template <typename T, int M, typename TI = T>
+__device__ __forceinline__ void stage_row(T* row, const TI* __restrict__ src, int N, int lane) {
   // batches of up to 17 coalesced loads in flight (34 VGPRs), then their LDS writes.  (The whole row in one batch -- 33 loads at
   // N_zeta = 2048, one exposed memory latency per row instead of two -- spills more than it hides: 1.72e7 against 1.83e7 solves/s.)
   constexpr int B = 17;
@@ -449,16 +495,16 @@ __device__ __forceinline__ void stage_row(T* row, const T* __restrict__ src, int
   for (int k0 = 0; k0 <= M; k0 += B) {
     T v[B];
 #pragma unroll
-    for (int k = 0; k < B; ++k) { const int j = lane + (k0 + k) * kWave; v[k] = (k0 + k <= M && j < N) ? src[j] : T(0); }
+    for (int k = 0; k < B; ++k) { const int j = lane + (k0 + k) * kWave; v[k] = (k0 + k <= M && j < N) ? (T)src[j] : T(0); }
 #pragma unroll
     for (int k = 0; k < B; ++k) { const int j = lane + (k0 + k) * kWave; if (k0 + k <= M && j < N) row[lpos(j)] = v[k]; }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-template <typename T, int M>
+template <typename T, int M, typename TI = T>
 struct SrcRows {
   static constexpr bool kHasGh = false;
-  T* row; const T* gg; const T* cg; const T* fg; int N, lane, which;     // which: the array the row holds now (0 g, 1 c, 2 f)
+  T* row; const TI* gg; const TI* cg; const TI* fg; int N, lane, which;     // which: the array the row holds now (0 g, 1 c, 2 f)
   __device__ __forceinline__ T g(int j) const { return row[lpos(j)]; }
   __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const {
     const T v = row[lpos(j)];
@@ -466,7 +512,7 @@ struct SrcRows {
   }
   __device__ __forceinline__ void hold(int w) {
     wave_lds_sync();
-    stage_row<T, M>(row, w == 0 ? gg : (w == 1 ? cg : fg), N, lane);
+    stage_row<T, M, TI>(row, w == 0 ? gg : (w == 1 ? cg : fg), N, lane);
     wave_lds_sync();
     which = w;
   }
@@ -478,8 +524,8 @@ struct SrcRows {
 // are SEPARABLE in (g, c, f), so they fit the three passes:  x'Tx = sum_j c_j x_j^2 - sum_edges e_{j+1/2} (x_{j+1} - x_j)^2
 // (summation by parts, x_0 = x_{N-1} = 0),  x'Fx = sum_j f_j x_j^2.  (The residual bound del is not separable: the kernel
 // estimates it from a sample of rows, see k_solve_gcf_rows.)
-template <typename T, int M>
-__device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& s, int N, T h) {
+template <typename T, int M, typename TI = T>
+__device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M, TI>& s, int N, T h) {
   const int lane = s.lane;
   ws.lane = lane;
   const int n = N - 2;
@@ -585,8 +631,8 @@ __device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M>& 
 // Estimate of the trial vector's residual bound del (WaveSolver::setup<Src, true>) from every fourth row, straight from global
 // memory before anything else is live: (T x)_j needs g, c and f of a row at once.  8 rows per lane at N_zeta = 2048, all 40 loads in
 // flight together.  del only sets the width of the first bracket (rho + del / 4 and up): an estimate will do.
-template <typename T>
-__device__ __forceinline__ T trial_del_sampled(const T* gq, const T* cq, const T* fq, int N, T h, int lane) {
+template <typename T, typename TI = T>
+__device__ __forceinline__ T trial_del_sampled(const TI* gq, const TI* cq, const TI* fq, int N, T h, int lane) {
   constexpr int kS = 8, kStep = 4;
   const T ih2 = T(1) / (h * h);
   const T dl = T(3.14159265358979323846) / T(N - 1);
@@ -595,7 +641,7 @@ __device__ __forceinline__ T trial_del_sampled(const T* gq, const T* cq, const T
   for (int k = 0; k < kS; ++k) {
     const int j = 2 + kStep * (lane + kWave * k);
     const int jc = j <= N - 2 ? j : 2;
-    gm[k] = gq[jc - 1]; g0[k] = gq[jc]; gp[k] = gq[jc + 1]; cc[k] = cq[jc]; ff[k] = fq[jc];
+    gm[k] = (T)gq[jc - 1]; g0[k] = (T)gq[jc]; gp[k] = (T)gq[jc + 1]; cc[k] = (T)cq[jc]; ff[k] = (T)fq[jc];
   }
   T sj, cj, s1, c1, sW, cW;
   trial_sincos(T(2 + kStep * lane) * dl, sj, cj);
@@ -620,10 +666,11 @@ __device__ __forceinline__ T trial_del_sampled(const T* gq, const T* cq, const T
   return approx_sqrt(xmax(xfma(-rho_s, A, C), T(0)) / B);
 }
 
-template <typename T, int M>
-__global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, const T* __restrict__ g,
-                                                        const T* __restrict__ c, const T* __restrict__ f, long ld,
-                                                        T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out) {
+// TI = the element type in memory (float: FP32 systems widened as they are staged and solved in FP64, like k_solve_gcf_wide)
+template <typename T, int M, typename TI = T>
+__global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, const TI* __restrict__ g,
+                                                        const TI* __restrict__ c, const TI* __restrict__ f, long ld,
+                                                        TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
   static_assert(M >= 3, "long grids only");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -633,15 +680,15 @@ __global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, 
   const bool valid = sys < n_sys;
   const long sysc = valid ? sys : (n_sys - 1);
   T* row = smem + (size_t)wave * lds_pitch(N);
-  SrcRows<T, M> src{row, g + sysc * ld, c + sysc * ld, f + sysc * ld, N, lane, -1};
+  SrcRows<T, M, TI> src{row, g + sysc * ld, c + sysc * ld, f + sysc * ld, N, lane, -1};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
   // trial-vector bracket (WaveSolver::trial_guess): rho from set-up's separable sums, del from a sample of rows (a full pass over
   // global memory for del cost what the bracket saved: 10.0 instead of 16.2 sweeps, 1.73e7 solves/s either way)
   IBS_PROBE_AT(0);                                       // (phase stamps: tools/rows_probe.py, debug builds only)
-  const T t_del = trial_del_sampled<T>(src.gg, src.cg, src.fg, N, h, lane);
+  const T t_del = trial_del_sampled<T, TI>(src.gg, src.cg, src.fg, N, h, lane);
   IBS_PROBE_AT(1);
-  const bool bad = setup_rows<T, M>(ws, src, N, h);
+  const bool bad = setup_rows<T, M, TI>(ws, src, N, h);
   ws.trial_del = t_del;
   IBS_PROBE_AT(2);
   T lam = T(0);
@@ -651,10 +698,17 @@ __global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, 
   // (the first batch of the next row requested while the current row is worked on -- to hide one of the two exposed memory
   //  latencies per staged row, 33 of this kernel's 63 us -- was built and measured: the 34 registers it keeps live cost more in
   //  AGPR traffic than the latency it hides, 1.71e7 against 1.83e7 solves/s)
+  if (!gam_out && !X_out && !dX_out) {                   // (kernel-uniform) eigenvalues only
+    if (lane == 0 && valid) {
+      if (lam_out) lam_out[sysc] = (TI)lam;
+      if (info_out) info_out[sysc] = inf.iters | (inf.status << 16);
+    }
+    return;
+  }
   src.hold(0);                                           // g: the eigenvector's scaling is rebuilt from it, then the g dX^2 sum
-  finish_chunk<T, M, SrcRows<T, M>, false, 3>(ws, src, N, h, row, lam, inf, sysc, valid ? lam_out : nullptr,
-                                              valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
-                                              nullptr, valid ? info_out : nullptr);
+  finish_chunk<T, M, SrcRows<T, M, TI>, false, 3, TI>(ws, src, N, h, row, lam, inf, sysc, valid ? lam_out : nullptr,
+                                                      valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                                      nullptr, valid ? info_out : nullptr);
   IBS_PROBE_AT(4);
 }
 
@@ -1344,6 +1398,24 @@ static hipError_t launch_gcf_rows(const GcfArgs<T>& a, hipStream_t st) {
     return hipErrorInvalidValue;
   }
 }
+#ifdef IBS_WITH_F32
+static hipError_t launch_gcf_rows_wide(const GcfArgs<float>& a, hipStream_t st) {
+  if constexpr (IBS_M >= 3) {
+    const int wpb = a.wpb;
+    const size_t lds = (size_t)wpb * lds_pitch(a.N) * sizeof(double);
+    const long nblk = (a.n_sys + wpb - 1) / wpb;
+    auto kern = k_solve_gcf_rows<double, IBS_M, float>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, (double)a.h, a.g, a.c, a.f, a.ld,
+                       a.lam, a.gam, a.X, a.dX, a.info);
+    note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_rows<double, %d, float>", IBS_M);
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+#endif
 template <typename T>
 static hipError_t launch_scan(const ScanArgs<T>& a, hipStream_t st) {
   const int wpb = a.wpb;
@@ -1424,6 +1496,9 @@ struct IBS_CAT(Registrar, IBS_M) {
     // the three-row staging admits three (M = 24..28) or two (M = 29..32).  Below, the three-row kernel holds as many or
     // more waves and is faster (N_zeta = 1024, M = 16: 198 VGPRs, two waves per SIMD, 3.7e7 against 3.0e7 solves/s)
     t.gcf_rows_f64[IBS_M] = &launch_gcf_rows<double>;
+#ifdef IBS_WITH_F32
+    t.gcf_f32w_rows[IBS_M] = &launch_gcf_rows_wide;
+#endif
 #endif
     t.scan_f64[IBS_M] = &launch_scan<double>;
     t.scan_chain_f64[IBS_M] = &launch_scan_chain<double>;

@@ -11,13 +11,15 @@
 
 namespace ibs {
 
-template <typename T>
+// TI = the element type in memory: FP32 systems whose growth rate is wanted are widened (exactly) as they are read and solved
+// by the FP64 solver (T = double, TI = float: half the bytes, the same arithmetic; see k_solve_gcf_wide in ibs_kernels.hip)
+template <typename T, typename TI = T>
 struct SrcGlobal {   // raw (g, c, f) straight from global memory: a lane's chunk is M contiguous values
   static constexpr bool kHasGh = false;
-  const T* gs; const T* cs; const T* fs;
-  __device__ __forceinline__ T g(int j) const { return gs[j]; }
-  __device__ __forceinline__ T c(int j) const { return cs[j]; }
-  __device__ __forceinline__ T f(int j) const { return fs[j]; }
+  const TI* gs; const TI* cs; const TI* fs;
+  __device__ __forceinline__ T g(int j) const { return (T)gs[j]; }
+  __device__ __forceinline__ T c(int j) const { return (T)cs[j]; }
+  __device__ __forceinline__ T f(int j) const { return (T)fs[j]; }
 };
 
 template <typename T>
@@ -50,15 +52,16 @@ __device__ __forceinline__ void simpson_point_g(const Src& src, int j, T w, T X,
 // stencil neighbours beyond a chunk come from the adjacent lanes of the group, every lane sums its own rows, the
 // first and last lane of the group add the end points j = 0, N-1.  X / dX, when requested, go through the group's
 // LDS row afterwards.
-template <typename T, int M, int P, class Src, bool HF>
+template <typename T, int M, int P, class Src, bool HF, typename TO = T>
 __device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const Src& src, int N, T h, T* Xs, T lam,
-                                               int iters, int status, long sys, bool valid, T* lam_out, T* gam_out,
-                                               T* X_out, T* dX_out, T* dth0_out, int* info_out) {
+                                               int iters, int status, long sys, bool valid, TO* lam_out, TO* gam_out,
+                                               TO* X_out, TO* dX_out, TO* dth0_out, int* info_out) {
   static_assert(M >= 3, "the halo exchange takes two rows from each neighbour lane");
   using GP = Grp<P>;
   const int lane = ws.lane, lg = ws.lg;
   const int n = N - 2;
   const bool hl = ws.has_last, first = lg == 0, last = lg == P - 1;
+
   T x[M];
   ws.assemble(src, N, h, x);
   T m = T(0);
@@ -116,17 +119,17 @@ __device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const S
     if (do_hf) {
       hc = GP::sum(hc, lane); hg = GP::sum(hg, lane); hf = GP::sum(hf, lane);
       const T jac = hc / y1 - hg / y1 - gam * hf / y1;                 // utils.py:1676-1680
-      if (first && valid) dth0_out[sys] = jac;
+      if (first && valid) dth0_out[sys] = (TO)jac;
     }
   }
   if (first && valid) {
-    if (lam_out) lam_out[sys] = lam;
-    if (gam_out) gam_out[sys] = gam;
+    if (lam_out) lam_out[sys] = (TO)lam;
+    if (gam_out) gam_out[sys] = (TO)gam;
     if (info_out) info_out[sys] = iters | (status << 16);
   }
   if (X_out || dX_out) {                   // kernel-uniform
     for (int pass = 0; pass < 2; ++pass) {
-      T* out = pass ? dX_out : X_out;
+      TO* out = pass ? dX_out : X_out;
       if (!out) continue;
       wave_lds_sync();
 #pragma unroll
@@ -139,7 +142,7 @@ __device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const S
       if (first) Xs[lpos(0)] = pass ? dX_end : T(0);
       if (last) Xs[lpos(N - 1)] = pass ? dX_end : T(0);
       wave_lds_sync();
-      if (valid) for (int j = lg; j < N; j += P) out[sys * N + j] = Xs[lpos(j)];
+      if (valid) for (int j = lg; j < N; j += P) out[sys * N + j] = (TO)Xs[lpos(j)];
     }
   }
 }
@@ -148,10 +151,10 @@ __device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const S
 // (2 waves per SIMD: the shift iteration keeps ~210 VGPRs live.  Forcing 3 waves (168 VGPRs) spills 45 of them:
 //  6 % faster (9.6e7 vs 9.0e7 solves/s) but the scratch traffic doubles the HBM bytes per launch (8.1 vs 4.3 GB
 //  PMC), so it is not used; 4 waves per SIMD halve the rate.)
-template <typename T, int M, int P>
-__global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, const T* __restrict__ g,
-                                                     const T* __restrict__ c, const T* __restrict__ f, long ld,
-                                                     T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out) {
+template <typename T, int M, int P, typename TI = T>
+__global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, const TI* __restrict__ g,
+                                                     const TI* __restrict__ c, const TI* __restrict__ f, long ld,
+                                                     TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   constexpr int G = 64 / P;
@@ -162,16 +165,23 @@ __global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, 
   const bool valid = sys < n_sys;
   const long sysc = valid ? sys : (n_sys - 1);
   T* Xs = smem + ((size_t)wave * G + gid) * lds_pitch(N);
-  SrcGlobal<T> src{g + sysc * ld, c + sysc * ld, f + sysc * ld};
+  SrcGlobal<T, TI> src{g + sysc * ld, c + sysc * ld, f + sysc * ld};
   GroupSolver<T, M, P> ws;
-  const bool bad = ws.template setup<SrcGlobal<T>, true>(src, N, h);
+  const bool bad = ws.template setup<SrcGlobal<T, TI>, true>(src, N, h);
   int iters = 0, status = 0;
   T g_ = T(0), w_ = T(0);
   bool warm_ = false;
   ws.trial_guess(true, g_, w_, warm_);                 // cold solves start from the trial vector's bracket
   const T lam = ws.solve(bad, iters, status, warm_, g_, w_);
-  finish_chunk_g<T, M, P, SrcGlobal<T>, false>(ws, src, N, h, Xs, lam, iters, status, sysc, valid, lam_out, gam_out, X_out,
-                                         dX_out, nullptr, info_out);
+  if (!gam_out && !X_out && !dX_out) {     // (kernel-uniform) eigenvalues only: no eigenvector, no Simpson sums
+    if (ws.lg == 0 && valid) {
+      if (lam_out) lam_out[sysc] = (TI)lam;
+      if (info_out) info_out[sysc] = iters | (status << 16);
+    }
+    return;
+  }
+  finish_chunk_g<T, M, P, SrcGlobal<T, TI>, false, TI>(ws, src, N, h, Xs, lam, iters, status, sysc, valid, lam_out, gam_out, X_out,
+                                                       dX_out, static_cast<TI*>(nullptr), info_out);
 }
 
 // geometry-fed scan: block = wpb waves of one line part; wave w solves theta0 indices (part*wpb + w)*G .. +G-1
@@ -318,6 +328,23 @@ static hipError_t launch_gcf_g(const GcfArgs<T>& a, hipStream_t st) {
   note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_g<%s, %d, %d>", type_name<T>(), IBS_M, IBS_P);
   return hipGetLastError();
 }
+#ifdef IBS_WITH_F32
+// FP32 in HBM, FP64 in the solver (the sub-wave sibling of k_solve_gcf_wide)
+static hipError_t launch_gcf_g_wide(const GcfArgs<float>& a, hipStream_t st) {
+  constexpr int G = 64 / IBS_P;
+  const int wpb = a.wpb;
+  const size_t lds = (size_t)wpb * G * lds_pitch(a.N) * sizeof(double);
+  const long nwaves = (a.n_sys + G - 1) / G;
+  const long nblk = (nwaves + wpb - 1) / wpb;
+  auto kern = k_solve_gcf_g<double, IBS_M, IBS_P, float>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, (double)a.h, a.g, a.c, a.f, a.ld,
+                     a.lam, a.gam, a.X, a.dX, a.info);
+  note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_g<double, %d, %d, float>", IBS_M, IBS_P);
+  return hipGetLastError();
+}
+#endif
 template <typename T>
 static hipError_t launch_scan_g(const ScanArgs<T>& a, hipStream_t st) {
   constexpr int G = 64 / IBS_P;
@@ -360,6 +387,9 @@ struct IBS_CAT3(RegistrarG, IBS_P, IBS_M) {
     LaunchTable& t = launch_table();
     constexpr int pi = (IBS_P == 32) ? 0 : 1;
     t.gcf_f64_g[pi][IBS_M] = &launch_gcf_g<double>;
+#ifdef IBS_WITH_F32
+    t.gcf_f32w_g[pi][IBS_M] = &launch_gcf_g_wide;
+#endif
     t.scan_f64_g[pi][IBS_M] = &launch_scan_g<double>;
     t.scan_chain_f64_g[pi][IBS_M] = &launch_scan_g_chain<double>;
   }

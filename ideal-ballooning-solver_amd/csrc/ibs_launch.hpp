@@ -84,6 +84,8 @@ struct LaunchTable {
   hipError_t (*gcf_rows_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);   // row-streamed form (k_solve_gcf_rows)
   hipError_t (*gcf_f32[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);
   hipError_t (*gcf_f32_wide[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);   // FP32 in HBM, FP64 in the solver (gam / X wanted)
+  hipError_t (*gcf_f32w_rows[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);  // the same, row-streamed (long grids)
+  hipError_t (*gcf_f32w_g[2][kMaxM + 1])(const GcfArgs<float>&, hipStream_t);  // the same, 32 / 16 lanes per system
   hipError_t (*scan_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
   hipError_t (*scan_chain_f64[kMaxM + 1])(const ScanArgs<double>&, hipStream_t);
   hipError_t (*sturm_f64[kMaxM + 1])(const SturmArgs<double>&, hipStream_t);

@@ -15,8 +15,10 @@
  *   - grids are uniform in theta with N points (N odd, 66 <= N <= 2050) and spacing h;
  *     arrays of one system/line are contiguous, consecutive systems are `ld` elements apart.
  *   - optional outputs may be NULL.
- *   - info word per system: bits 0..15 = fused sweeps used, bits 16.. = status
- *     (1 = iteration cap hit, 2 = invalid data: non-finite, g <= 0 or f <= 0).
+ *   - info word per system: bits 0..15 = sweeps used, bits 16.. = status
+ *     (bit 0 = iteration cap hit, bit 1 = invalid data: non-finite, g <= 0 or f <= 0; bit 2 is informational and only set by
+ *     the FP32 eigenvalue-only path: the all-FP32 result failed its FP64 certificate and the system was solved in FP64 --
+ *     the returned value is good; return values > 0 and the host-side counts look at bits 0 and 1 only).
  */
 #ifndef IBS_H
 #define IBS_H
@@ -98,7 +100,8 @@ int ibs_comm_destroy(ibs_ctx* ctx);
  * name: "force_p" (lanes per system 64|32|16), "scan_chain" (theta0 values chained through one wave),
  * "chain_w1" / "chain_w2" (relative widths of the chain's warm starts), "geo_lpp" (lanes per grid point of the
  * geometry kernel 1|2|4|8, or -2 = two grid points per lane), "gcf_rows" (0: three-row staging instead of the row-streamed raw
- * kernel on long grids), "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
+ * kernel on long grids), "f32_lam" (FP32 eigenvalue-only requests: 1 = all-FP32 iteration + FP64 certificate, 2 = FP64 solver on
+ * the FP32 arrays; 0 = by grid size), "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
  * staged in LDS, 1, or read from global memory by the sums, 0: two blocks per CU instead of one at N = 969; -1 = by batch size);
  * value 0 = automatic (refine_tangent: -1); value NaN = back to what ibs_create() read from the environment
  * (IBS_FORCE_P, IBS_SCAN_CHAIN, IBS_CHAIN_W1, IBS_CHAIN_W2, IBS_GEO_LPP are read once, there); name "all" with NaN
@@ -120,11 +123,14 @@ int ibs_solve_gcf_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const do
 int ibs_solve_gcfh_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* gh,
                        const double* c, const double* f, int64_t ld, double* lam, double* gam, double* X, double* dX,
                        int32_t* info, int32_t mem);
-/* FP32 form (BASELINE configs[4], the stress leg).  With lam alone (gam, X, dX all null) the whole solve is FP32 -- the
- * throughput form; |lam - lam64| <= 16 eps32 ||A|| (median), <= N_zeta eps32 ||A|| (99.9 %).  When gam, X or dX is asked
- * for the arrays are widened to FP64 as they are staged and the FP64 solver runs on them (FP32 in HBM only; results
- * rounded to FP32): an FP32 eigenvector's noise is multiplied by ~N^2 in the FD4 / Simpson quotient, so an all-FP32
- * growth rate is noise above N_zeta = 512.  |gam - gam64| <= 1e-6 at every N_zeta on smooth systems. */
+/* FP32 form (BASELINE configs[4], the stress leg).  With lam alone (gam, X, dX all null) the shift iteration runs in FP32 --
+ * the throughput form -- and EVERY result is then certified in FP64 on the staged rows: one Sturm-count pair at
+ * lam32 +- n eps32 ||A|| (n = N - 2) must read (0 above, >= 1 below); a system that fails (an FP32 count off by one between
+ * two close eigenvalues would otherwise return lam_2) is solved in FP64 and carries status bit 2.  Hence
+ * |lam - lam64| <= n eps32 ||A|| + the rounding of lam to FP32 for every system.  When gam, X or dX is asked for the arrays
+ * are widened to FP64 as they are read and the FP64 solver runs on them (FP32 in HBM only; results rounded to FP32; the same
+ * kernel forms as the FP64 entry point): an FP32 eigenvector's noise is multiplied by ~N^2 in the FD4 / Simpson quotient, so
+ * an all-FP32 growth rate would be noise above N_zeta = 512.  |gam - gam64| <= 1e-6 at every N_zeta on smooth systems. */
 int ibs_solve_gcf_f32(ibs_ctx* ctx, int64_t n_sys, int32_t N, float h, const float* g, const float* c,
                       const float* f, int64_t ld, float* lam, float* gam, float* X, float* dX,
                       int32_t* info, int32_t mem);

@@ -72,15 +72,15 @@ def test_config5_fp64_one_million_systems(ctx, nz, family):
     assert float(((r2["lam"] - (lam[:m] + 0.25)).abs() / nA[:m]).max()) < (3e-13 if family == "smooth" else max(3e-13, tol))
 
 
-# FP32 entry point of config 5 (ibs_solve_gcf_f32), measured with tests/tools/fp32_wide_probe.py and stated with margin.
-#   lam-only requests run the all-FP32 kernel (the throughput / stress form): the scan-form Sturm counts certify eigenvalues
-#        of a matrix perturbed by ~n eps, n = N_zeta rows:
-#        median <= 16 eps32 ||A||,  99.9 % <= n eps32 ||A||,  every system <= 16 n eps32 ||A||
-#        (the outliers beyond n eps32 ||A|| -- 1e-4 of the smooth family at N_zeta <= 512 -- sit on lam_2: an FP32 count
-#        off by one between lam_2 and lam_1; FP64 is the parity path)
-#   requests for gam (or X) are WIDENED: FP32 in HBM, FP64 in the solver (k_solve_gcf_wide) -- an FP32 eigenvector's noise is
-#        multiplied by ~N_zeta^2 in the FD4 / Simpson quotient (round 2: noise above N_zeta = 512).  What is left is the
-#        rounding of the inputs and of the result to FP32:  |lam - lam64| <= 2 eps32 ||A|| on every system (measured 0.2),
+# FP32 entry point of config 5 (ibs_solve_gcf_f32).
+#   lam-only requests: either the all-FP32 shift iteration followed by an FP64 CERTIFICATE on the staged rows (one Sturm-count
+#        pair at lam32 +- n eps32 ||A||, n = N_zeta rows; a system that fails it -- an FP32 count off by one between two close
+#        eigenvalues used to return lam_2 for 1e-4 of the smooth family -- is solved in FP64 and carries the informational
+#        status bit 2), or the FP64 solver on the FP32 arrays (where the sub-wave kernels exist); `f32_lam` picks the form.
+#        EVERY system: |lam - lam64| <= n eps32 ||A|| (+ the rounding of the inputs and of lam to FP32).
+#   requests for gam (or X) are WIDENED: FP32 in HBM, FP64 in the solver (wave / sub-wave / row-streamed forms like FP64) -- an FP32
+#        eigenvector's noise is multiplied by ~N_zeta^2 in the FD4 / Simpson quotient.  What is left is the rounding of the
+#        inputs and of the result to FP32:  |lam - lam64| <= 2 eps32 ||A|| on every system (measured 0.2),
 #        |gam - gam64| <= 1e-6 on every system of the smooth family (measured 6e-8 = gam eps32) at EVERY N_zeta;
 #        SURVEY 8d C5-ii pins lam alone on the rough family (near-degenerate pairs: gam is first order in the inputs there).
 EPS32 = 1.1920929e-07
@@ -89,23 +89,31 @@ GAM32_WIDE_TOL = 1.0e-6
 
 @pytest.mark.parametrize("nz", [256, 512, 1024, 2048])
 def test_config5_fp32_stated_tolerances(ctx, nz):
-    """FP32 legs of config 5 against FP64 on the same systems, 2 families x 10^6 systems per N_zeta (BASELINE's size)"""
+    """FP32 legs of config 5 against FP64 on the same systems, 2 families x 10^6 systems per N_zeta (BASELINE's size): no
+    result may sit on lam_2 -- every eigenvalue within n eps32 ||A|| of the FP64 one, in both eigenvalue-only forms."""
     import torch
     dev = torch.device("cuda:0")
     n, N = 1000000, nz + 1
-    q = lambda t, pr: float(torch.quantile(t, pr))
+    resolved = {}
     for family in ("smooth", "rough"):
         h, g, c, f = c5_family(dev, family, n, N, seed=20240 + nz)
         r64 = ctx.solve_gcf(h, g, c, f)
         nA = norm_a(h, g, c, f)
         g32, c32, f32 = g.float(), c.float(), f.float()
         del g, c, f
-        # (a) eigenvalues only: the all-FP32 kernel
-        r32 = ctx.solve_gcf(h, g32, c32, f32, want_info=True, dtype=np.float32, want_gam=False)
-        assert r32["lam"].dtype == torch.float32 and r32["gam"] is None and int(((r32["info"] >> 16) != 0).sum()) == 0
-        el = (r32["lam"].double() - r64["lam"]).abs() / nA
-        assert float(el.median()) < 16 * EPS32 and q(el, 0.999) < nz * EPS32 and float(el.max()) < 16 * nz * EPS32, \
-            (float(el.median()), q(el, 0.999), float(el.max()))
+        # (a) eigenvalues only: all-FP32 iteration + FP64 certificate (1), FP64 solver on the FP32 arrays (2), library's choice (0)
+        for mode in (1, 2, 0):
+            ctx.set_option("f32_lam", mode)
+            r32 = ctx.solve_gcf(h, g32, c32, f32, want_info=True, dtype=np.float32, want_gam=False)
+            st = r32["info"] >> 16
+            assert r32["lam"].dtype == torch.float32 and r32["gam"] is None and int(((st & 3) != 0).sum()) == 0
+            el = (r32["lam"].double() - r64["lam"]).abs() / nA
+            assert float(el.max()) <= (nz + 4) * EPS32, (family, mode, float(el.median()), float(el.max()) / EPS32)
+            if mode == 1:
+                resolved[family] = int(((st & 4) != 0).sum())
+            else:
+                assert int((st != 0).sum()) == 0
+        ctx.set_option("f32_lam", None)
         # (b) growth rate wanted: widened to FP64 inside the solver
         rw = ctx.solve_gcf(h, g32, c32, f32, want_info=True, dtype=np.float32)
         assert rw["gam"].dtype == torch.float32 and int(((rw["info"] >> 16) != 0).sum()) == 0
@@ -116,6 +124,7 @@ def test_config5_fp32_stated_tolerances(ctx, nz):
             assert float(eg.max()) < GAM32_WIDE_TOL, (float(eg.median()), float(eg.max()))
         del g32, c32, f32, r64, r32, rw
         torch.cuda.empty_cache()
+    print("N_zeta = %d: all-FP32 results that failed the FP64 certificate and were re-solved: %s of %d" % (nz, resolved, n))
 
 
 # ---------------------------------------------------------------------------------------------- configs[3]
