@@ -488,16 +488,35 @@ __global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float
 // rate re-stages g (scaling of the eigenvector + the g dX^2 sum), then c, then f.  LDS per wave: N doubles.
 template <typename T, int M, typename TI = T>
 __device__ __forceinline__ void stage_row(T* row, const TI* __restrict__ src, int N, int lane) {
-  // batches of up to 17 coalesced loads in flight (34 VGPRs), then their LDS writes.  (The whole row in one batch -- 33 loads at
-  // N_zeta = 2048, one exposed memory latency per row instead of two -- spills more than it hides: 1.72e7 against 1.83e7 solves/s.)
+  // batches of up to 17 coalesced loads in flight (34 VGPRs for FP64 rows), then their LDS writes.  (The whole row in one batch --
+  // 33 loads at N_zeta = 2048, one exposed memory latency per row instead of two -- spills more than it hides for FP64 rows, 1.72e7
+  // against 1.83e7 solves/s, and changes nothing for FP32 rows: 12.6 against 12.4 us per three staged rows.)
   constexpr int B = 17;
 #pragma unroll
   for (int k0 = 0; k0 <= M; k0 += B) {
-    T v[B];
+    TI v[B];
+    if constexpr (sizeof(TI) == 8) {
 #pragma unroll
-    for (int k = 0; k < B; ++k) { const int j = lane + (k0 + k) * kWave; v[k] = (k0 + k <= M && j < N) ? (T)src[j] : T(0); }
+      for (int k = 0; k < B; ++k) { const int j = lane + (k0 + k) * kWave; v[k] = (k0 + k <= M && j < N) ? src[j] : TI(0); }
+    } else {
+      // (FP32 rows: a load under a lane condition is compiled as a branch with a wait behind EVERY such load -- 1.8 us longer per
+      //  staged row.  N > 64 (M - 1) + 2 for this instantiation, so the loads k <= M - 2 are in bounds for every lane and
+      //  unconditional, at immediate offsets from one base; only the last two take a clamped index: three staged rows 12.4 instead
+      //  of 21.6 us at N_zeta = 2048.  The FP64 rows keep the conditional form: the other one spills 216 instead of 20 bytes at
+      //  M = 32 and takes 26.7 instead of 17.0 us.)
 #pragma unroll
-    for (int k = 0; k < B; ++k) { const int j = lane + (k0 + k) * kWave; if (k0 + k <= M && j < N) row[lpos(j)] = v[k]; }
+      for (int k = 0; k < B; ++k) {
+        if (k0 + k <= M) {
+          const int j = lane + (k0 + k) * kWave;
+          if (k0 + k <= M - 2) v[k] = src[j];
+          else v[k] = src[j < N ? j : N - 1];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      if (k0 + k <= M) { const int j = lane + (k0 + k) * kWave; if (j < N) row[lpos(j)] = (T)v[k]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
