@@ -184,7 +184,7 @@ def solve_trial(sysd, fracs=(1 / 16, 1 / 4, 1.0)):
     return n + it, lam
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "dual"):
     S = add_trial(systems())
     base = np.array([solve(s)[0] for s in S])
     print("bench batch (configs[1] shape, 1,024 systems, N = 513)")
@@ -192,3 +192,178 @@ if __name__ == "__main__":
     for fr in ((0.25, 1.25, 5.25), (1.0,), (1 / 16, 1 / 4, 1.0)):
         its = np.array([solve_trial(s, fr)[0] for s in S])
         print("  trial-vector bracket, first shifts rho + delta * %s: mean %.2f max %d hist(8..) %s" % (str(fr), its.mean(), its.max(), np.bincount(its)[8:].tolist()))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 4: the iteration AS BUILT in round 3 (trial-vector bracket handed to the warm path of WaveSolver::solve: first shift
+# rho + del / 4, walk up x 4 while the count stays >= 1, then rho - del / 4, then the count / interpolation phases) and the
+# TWO-SHIFTS-PER-ITERATION variant of VERDICT r3 item 5 (two waves per system, each sweeping its own shift; both see both results):
+# solve_pair is the policy that was built (tools/experiments/pair_two_shifts.patch) -- measured and dropped, docs/EXPERIMENTS.md.
+def solve_asbuilt(sysd, trace=None):
+    w = sysd["w"]; normA = sysd["normA"]
+    count = lambda s: int(np.sum(w > s))
+    tol = 64 * EPS * normA
+    lo, hi = sysd["lo"], sysd["hi"]
+    rho_t, dl = sysd["rho"], sysd["delta"]
+    use = math.isfinite(rho_t) and dl > 0 and dl < 0.25 * (hi - lo)
+    mrg = (8 + 513 / 2) * EPS * normA
+    if use: lo = max(lo, rho_t - mrg)
+    guess, width = (rho_t, 0.25 * dl) if use else (float("nan"), 0.0)
+    sig = 0.5 * (lo + hi)
+    expand = try_below = False; wstep = 0.0
+    if use and lo < guess + width < hi:
+        sig = guess + width; expand = True; wstep = 4 * width; try_below = True
+    off_up = off_dn = tol; rho_trust = hi; aimed = 0
+    lo1 = hi_f = old_ok = was_interp = conv = force_bis = False
+    lg_prev = 0.0
+    Plo = Pt(lo); Phi = Pt(hi); Pold = Pt(hi)
+    sig_prev = sig; it = 0; done = False
+    while not done and it < 200:
+        C = count(sig); sg, lg = shoot(w, sig); it += 1
+        if trace is not None: trace.append((sig, C))
+        if C == 0:
+            if hi_f: Pold = Phi; old_ok = True
+            hi = sig; Phi = Pt(sig, sg, lg); hi_f = True
+        else:
+            if lo1: Pold = Plo; old_ok = True
+            lo = sig; lo1 = (C == 1); Plo = Pt(sig, sg, lg)
+        prevstep = abs(sig - sig_prev); sig_prev = sig
+        if expand:
+            if C != 0 and sig + wstep < hi: sig += wstep; wstep *= 4; continue
+            expand = False
+        if not lo1:
+            if hi - lo <= 4 * tol: done = True; break
+            if try_below and lo < guess - width < hi: sig = guess - width
+            else: sig = 0.5 * (lo + hi)
+            try_below = False
+            continue
+        if was_interp:
+            red = lg_prev - lg
+            conv = red >= 4; force_bis = red < 1
+        elif aimed == 0: conv = False
+        cert = aimed != 0
+        if aimed > 0 and C != 0: off_up *= 2
+        if aimed < 0 and C == 0: off_dn *= 2
+        aimed = 0
+        if hi - lo <= 4 * tol: done = True; break
+        rho = sig; ok = False; near = False
+        if cert: rho = rho_trust; ok = True; near = True
+        elif hi_f and not force_bis:
+            b_is_lo = Plo.lg <= Phi.lg
+            lg_prev = Plo.lg if b_is_lo else Phi.lg
+            b = Plo if b_is_lo else Phi; a = Phi if b_is_lo else Plo
+            use_o = old_ok and Pold.x != a.x and Pold.x != b.x
+            got, r = interpolate(Pold, use_o, a, b, lo, hi)
+            q = 0.25 * (3 * a.x + b.x)
+            inside = min(q, b.x) <= r <= max(q, b.x)
+            stepb = abs(r - b.x)
+            nr = was_interp and conv and stepb <= 4096 * tol
+            acc = got and inside and (nr or (stepb < 0.5 * prevstep and stepb >= 9.5367431640625e-07 * prevstep))
+            if acc: rho = r; ok = True; near = nr
+        moved = False; interp_now = False
+        if ok:
+            if near:
+                if not cert and abs(rho - rho_trust) > 4096 * tol: off_up = off_dn = tol
+                rho_trust = rho
+                up = max(rho, lo); dn = min(rho, hi); nxt = rho
+                if hi > up + 2 * off_up: nxt = up + off_up; aimed = 1
+                elif lo < dn - 2 * off_dn: nxt = dn - off_dn; aimed = -1
+                if aimed != 0 and lo < nxt < hi: sig = nxt; moved = True
+                else: aimed = 0
+            else:
+                sig = rho; moved = True; interp_now = True
+        force_bis = False
+        if not moved: sig = 0.5 * (lo + hi)
+        was_interp = interp_now
+    return it, 0.5 * (lo + hi)
+
+
+def solve_pair(sysd, first=(0.07, 0.21), mirror=0.5, trace=None):
+    """bounded state, as it can be built: bracket ends Plo / Phi + TWO spare points (the most recently displaced or unused points
+    with count <= 1); everything else as solve_dual4"""
+    w = sysd["w"]; normA = sysd["normA"]
+    count = lambda s: int(np.sum(w > s))
+    tol = 64 * EPS * normA
+    lo, hi = sysd["lo"], sysd["hi"]
+    rho_t, dl = sysd["rho"], sysd["delta"]
+    use = math.isfinite(rho_t) and dl > 0 and dl < 0.25 * (hi - lo)
+    mrg = (8 + 513 / 2) * EPS * normA
+    if use: lo = max(lo, rho_t - mrg)
+    it = 0
+    lo1 = False; hi_f = False
+    Plo = Pt(lo); Phi = Pt(hi)
+    spare = []                      # at most 2, newest first
+    def push(P):
+        spare.insert(0, P)
+        del spare[2:]
+    def take(x):
+        C = count(x); sg, lg = shoot(w, x)
+        return Pt(x, sg, lg), C
+    def absorb(P, C):
+        nonlocal lo, hi, lo1, hi_f, Plo, Phi
+        if not (lo < P.x < hi):
+            if C <= 1: push(P)
+            return
+        if C == 0:
+            if hi_f: push(Phi)
+            hi = P.x; Phi = P; hi_f = True
+        else:
+            if lo1: push(Plo)
+            lo = P.x; Plo = P; lo1 = (C == 1)
+    if use and lo < rho_t + first[0] * dl and rho_t + first[1] * dl < hi:
+        s1, s2 = rho_t + first[0] * dl, rho_t + first[1] * dl
+    else:
+        s1, s2 = lo + (hi - lo) / 3, lo + 2 * (hi - lo) / 3
+    lg_best_prev = None; off = tol
+    while it < 200:
+        (P1, C1), (P2, C2) = take(s1), take(s2); it += 1
+        if trace is not None: trace.append((s1, C1, s2, C2, lo, hi))
+        # the point farther from the root first, so that the nearer one ends up as the bracket end and the other as a spare
+        if C1 >= 1: absorb(P1, C1); absorb(P2, C2)      # s1 below the root: s1 then s2 (s2 above: other end; s2 below: nearer)
+        else: absorb(P2, C2); absorb(P1, C1)            # both above: s2 (farther) first
+        width = hi - lo
+        if width <= 4 * tol: break
+        if not lo1 or not hi_f:
+            s1, s2 = lo + width / 3, lo + 2 * width / 3
+            continue
+        b_is_lo = Plo.lg <= Phi.lg
+        b = Plo if b_is_lo else Phi; a = Phi if b_is_lo else Plo
+        cand = [P for P in spare if P.x != a.x and P.x != b.x]
+        o = min(cand, key=lambda P: abs(P.x - b.x)) if cand else None
+        got, r = interpolate(o if o is not None else a, o is not None, a, b, lo, hi)
+        stalled = lg_best_prev is not None and (lg_best_prev - b.lg) < 1
+        lg_best_prev = b.lg
+        if not got or stalled:
+            s1, s2 = lo + width / 3, lo + 2 * width / 3
+            lg_best_prev = None
+            continue
+        d = abs(r - b.x)
+        if d <= 4096 * tol:
+            sA, sB = r - off, r + off
+            off *= 2
+        else:
+            sgn = 1.0 if a.x > b.x else -1.0
+            sA = r
+            sB = r + sgn * mirror * d
+            if not (lo < sB < hi): sB = 0.5 * (r + a.x)
+        s1, s2 = (sA, sB) if sA < sB else (sB, sA)
+        if s1 <= lo: s1 = 0.5 * (lo + min(s2, hi))
+        if s2 >= hi: s2 = 0.5 * (max(s1, lo) + hi)
+    return it, 0.5 * (lo + hi)
+
+
+def report_round4():
+    S = add_trial(systems())
+    a = np.array([solve_asbuilt(s)[0] for s in S])
+    print("as built (round 3), one shift per sweep: sweeps mean %.2f max %d hist(6..) %s   [GPU: 10.42 / 13, the same histogram]" % (
+        a.mean(), a.max(), np.bincount(a)[6:].tolist()))
+    for first in ((0.07, 0.21), (1 / 16, 1 / 4)):
+        res = [solve_pair(s, first, 0.5) for s in S]
+        d = np.array([r[0] for r in res])
+        err = max(abs(r[1] - s["w"][-1]) / s["normA"] for r, s in zip(res, S))
+        print("two shifts per iteration (two waves per system), first pair rho + %s del: iterations mean %.2f max %d hist(3..) %s ; max |lam - lam_1| / |A| %.1e"
+              "   [GPU, first pair (0.07, 0.21): 7.41 / 11]" % (str(first), d.mean(), d.max(), np.bincount(d)[3:].tolist(), err))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "dual":
+    report_round4()
