@@ -49,34 +49,35 @@ def pmc_set_name():
     return d["_set"] if isinstance(d.get("_set"), str) else "unnamed"
 
 
-def pmc_entry(kernel, waves):
+def pmc_entry(kernel, waves, work_class=0):
     """The committed rocprofv3 --pmc figures of ONE leg (tools/profile_run.py -> tools/pmc_summary.py ->
-    profiles/pmc_current.json): the entry whose kernel name is EXACTLY `kernel` ("ibs::k_gamma_scan<double, 8>") and whose
-    launches held `waves` waves (SQ_WAVES, i.e. the leg's own batch size) and were all alike (a persistent kernel's grid does
-    not show the batch size; the spread of its launches' instruction counts does).  Returns (entry, None) or (None, reason):
-    a leg never quotes another kernel's or another batch size's counters."""
+    profiles/pmc_current.json): the entry whose kernel name is EXACTLY `kernel` ("ibs::k_gamma_scan<double, 8>"), whose
+    launches held `waves` waves (SQ_WAVES, i.e. the leg's own batch size) and which is the `work_class`-th class of equal work
+    among the launches of that kernel at that size, in order of first appearance (the PMC passes run the bench's own legs in the
+    bench's order: configs[4] runs the smooth family before the rough one through the same kernels).  Returns (entry, None) or
+    (None, reason): a leg never quotes another kernel's, another batch size's or another data set's counters."""
     d = _pmc_file()
     if d is None:
         return None, "profiles/pmc_current.json is absent"
     cands = [v for k, v in d.items() if isinstance(v, dict) and v.get("kernel", k.split(" @")[0]) == kernel]
     if not cands:
         return None, "no PMC entry for the kernel '%s'" % kernel
-    fit = [v for v in cands if "SQ_WAVES" in v and abs(v["SQ_WAVES"]["mean"] - waves) < 0.5]
-    if len(fit) != 1:
-        return None, "%d PMC entries of '%s' hold %d waves per launch (found: %s)" % (
-            len(fit), kernel, waves, sorted(int(v["SQ_WAVES"]["mean"]) for v in cands if "SQ_WAVES" in v))
-    if fit[0].get("valu_spread", 1.0) > 1.05:
-        return None, "the PMC entry of '%s' mixes launches of different batch sizes (instruction counts spread %.2fx)" % (
-            kernel, fit[0]["valu_spread"])
-    return fit[0], None
+    fit = sorted((v for v in cands if "SQ_WAVES" in v and abs(v["SQ_WAVES"]["mean"] - waves) < 0.5), key=lambda v: v.get("work_class", 0))
+    if len(fit) <= work_class:
+        return None, "%d PMC entries of '%s' hold %d waves per launch, class %d asked for (waves found: %s)" % (
+            len(fit), kernel, waves, work_class, sorted(set(int(v["SQ_WAVES"]["mean"]) for v in cands if "SQ_WAVES" in v)))
+    e = fit[work_class]
+    if e.get("valu_spread", 1.0) > 1.05:
+        return None, "the PMC entry of '%s' mixes launches of different work (instruction counts spread %.2fx)" % (kernel, e["valu_spread"])
+    return e, None
 
 
-def pmc_fields(kernel, waves, ms, alg_bytes=None):
+def pmc_fields(kernel, waves, ms, alg_bytes=None, work_class=0):
     """roofline fields every leg with a PMC entry reports: `traffic` (HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE in
     KiB, the gfx950 correction of MI355X_MICROARCH.md), its ratio to the algorithmic bytes, VALU instructions per wave and
     the bound that binds: `valu_issue` = wave64 VALU instructions issued per second (count from the PMC pass, time from
     THIS run) against one instruction per SIMD per 4 clocks."""
-    e, why = pmc_entry(kernel, waves)
+    e, why = pmc_entry(kernel, waves, work_class)
     src = "profiles/pmc_current.json (committed rocprofv3 --pmc passes of this leg at this size, set %s; replayed, not " \
           "measured by this run)" % pmc_set_name()
     if e is None:
@@ -92,13 +93,13 @@ def pmc_fields(kernel, waves, ms, alg_bytes=None):
     return out
 
 
-def hbm_roofline(alg_bytes, ms, bound, kernel, waves, **extra):
+def hbm_roofline(alg_bytes, ms, bound, kernel, waves, work_class=0, **extra):
     """the `roofline` object of a leg: HBM figures on ALGORITHMIC bytes (`achieved`, `peak`, `frac` = `hbm_frac`, the
     task's definition) whatever binds, `bound` = what does bind, and the PMC fields of the leg's kernel"""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     out = dict(bound=bound, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, hbm_frac=gbs / HBM_PEAK_GBS,
                kernel=kernel.replace("ibs::", ""), algorithmic_bytes_per_launch=alg_bytes)
-    out.update(pmc_fields(kernel, waves, ms, alg_bytes))
+    out.update(pmc_fields(kernel, waves, ms, alg_bytes, work_class))
     out.update(extra)
     return out
 
@@ -511,6 +512,7 @@ def c5_matrix(ctx, device, n_sys=1 << 20, budget_s=75.0):
     once the leg's time budget is spent."""
     import torch
     rows = []
+    seen = {}                       # (kernel, waves) -> rows so far: the work class of the next one in the PMC summary
     t_leg = time.perf_counter()
     for nz in (256, 512, 1024, 2048):
         N = nz + 1
@@ -547,7 +549,9 @@ def c5_matrix(ctx, device, n_sys=1 << 20, budget_s=75.0):
                 row = dict(n_zeta=nz, family=family, mode=mode, systems=n_sys, solves_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms,
                            mean_sweeps=float((r["info"] & 0xffff).double().mean().item()),
                            flagged=int((((r["info"] >> 16) & 3) != 0).sum().item()),
-                           roofline=hbm_roofline(n_sys * (3 * N + 1) * w, ms, "valu_issue", kern, waves, bytes_per_solve=(3 * N + 1) * w))
+                           roofline=hbm_roofline(n_sys * (3 * N + 1) * w, ms, "valu_issue", kern, waves, work_class=seen.get((kern, waves), 0),
+                                                 bytes_per_solve=(3 * N + 1) * w))
+                seen[(kern, waves)] = seen.get((kern, waves), 0) + 1
                 if mode == "f32_lam":     # (informational status bit 2: the all-FP32 result failed its FP64 certificate, solved in FP64)
                     row["resolved_in_f64"] = int((((r["info"] >> 16) & 4) != 0).sum().item())
                 if mode != "f64":

@@ -1411,7 +1411,7 @@ static hipError_t launch_gcf_rows(const GcfArgs<T>& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
                        a.lam, a.gam, a.X, a.dX, a.info);
-    note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_rows<%s, %d>", type_name<T>(), IBS_M);
+    note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_rows<%s, %d, %s>", type_name<T>(), IBS_M, type_name<T>());
     return hipGetLastError();
   } else {
     return hipErrorInvalidValue;

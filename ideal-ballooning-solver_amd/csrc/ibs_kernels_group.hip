@@ -325,7 +325,7 @@ static hipError_t launch_gcf_g(const GcfArgs<T>& a, hipStream_t st) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
                      a.lam, a.gam, a.X, a.dX, a.info);
-  note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_g<%s, %d, %d>", type_name<T>(), IBS_M, IBS_P);
+  note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_g<%s, %d, %d, %s>", type_name<T>(), IBS_M, IBS_P, type_name<T>());
   return hipGetLastError();
 }
 #ifdef IBS_WITH_F32

@@ -99,56 +99,82 @@ class SurfaceTables:
         return out
 
     @classmethod
-    def from_wouts(cls, wouts, svals, n_threads=0):
-        """the surfaces `svals` of SEVERAL equilibria in one table set (the base equilibrium and its DOF-perturbed copies
-        of one optimizer step, sims_runner_NCSX.py:151-276; upstream every one of them runs its own vmec_splines,
-        utils.py:37-158): surface index = i_equilibrium * len(svals) + i_surface, like concat([from_wout(w, svals) ...]).
-        The radial splines are linear in the data and the meshes are shared: the four weight matrices (value / derivative
-        on the full / half mesh) are applied to the tables of ALL equilibria by the library's threaded host routine
-        (ibs_surface_tables_f64: every table is read once where it lies; 73 equilibria = 115 MB) instead of 13 small
-        matrix products per equilibrium."""
-        wouts = list(wouts)
-        w0 = wouts[0]
-        ns = int(w0["ns"])
+    def frame(cls, wout0, svals, n_eq, pinned=False):
+        """an EMPTY table set for the surfaces `svals` of n_eq equilibria that share wout0's radial mesh and mode tables
+        (surface index = i_equilibrium * len(svals) + i_surface); fill(first, wouts) computes the tables of a run of
+        equilibria in place.  pinned: the big arrays live in page-locked host memory (torch), so that their upload can run
+        asynchronously while the host computes the next run (AdjointStep)."""
+        ns = int(wout0["ns"])
         svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))
-        n_eq, n_s = len(wouts), len(svals)
-        for w in wouts[1:]:
-            if int(w["ns"]) != ns or not all(w[k] is w0[k] or np.array_equal(w[k], w0[k]) for k in ("xm", "xn", "xm_nyq", "xn_nyq")):
-                raise ValueError("SurfaceTables.from_wouts: the equilibria must share the radial mesh and the mode tables")
+        n_s = len(svals)
+        out = cls.__new__(cls)
+        out.s = np.tile(svals, n_eq)
+        out.xm, out.xn = (np.ascontiguousarray(wout0[k], dtype=np.float64) for k in ("xm", "xn"))
+        out.xm_nyq, out.xn_nyq = (np.ascontiguousarray(wout0[k], dtype=np.float64) for k in ("xm_nyq", "xn_nyq"))
+        mnmax, mnq = len(out.xm), len(out.xm_nyq)
+
+        def alloc(shape):
+            if pinned:
+                import torch
+                t = torch.empty(shape, dtype=torch.float64).pin_memory()
+                out.__dict__.setdefault("_pinned", []).append(t)
+                return t.numpy()
+            return np.empty(shape)
+        out.tab_mn, out.tab_nyq, out.scal = alloc((n_eq * n_s, 6, mnmax)), alloc((n_eq * n_s, 7, mnq)), alloc((n_eq * n_s, 6))
+        out.scal[:, 0] = out.s
+        out.rows_mn, out.dn_mn = _mode_rows_cached(out.xm.tobytes(), out.xn.tobytes())
+        out.rows_nyq, out.dn_nyq = _mode_rows_cached(out.xm_nyq.tobytes(), out.xn_nyq.tobytes())
+        out.n_equilibria, out.n_surf_per_equilibrium, out._ns, out._svals = n_eq, n_s, ns, svals
         Wf, Wfd, Wh, Whd = _radial_weights(ns, svals.tobytes())
         # half-mesh data sit in columns 1..ns-1 of the (mn, ns) tables: a zero column in front of the weights lets the
         # product run on the table as it lies in memory
         z = np.zeros((n_s, 1))
-        Wh0, Whd0 = np.ascontiguousarray(np.hstack([z, Wh])), np.ascontiguousarray(np.hstack([z, Whd]))
-        mnmax, mnq = len(w0["xm"]), len(w0["xm_nyq"])
-        tab_mn = np.empty((n_eq * n_s, 6, mnmax)); tab_nyq = np.empty((n_eq * n_s, 7, mnq))
+        out._weights = (Wf, Wfd, np.ascontiguousarray(np.hstack([z, Wh])), np.ascontiguousarray(np.hstack([z, Whd])), Wh, Whd)
+        return out
+
+    def fill(self, first, wouts, n_threads=0):
+        """tables of the equilibria first .. first + len(wouts) - 1 of a frame(), in place: the radial splines of
+        vmec_splines (utils.py:58-119) evaluated at the surfaces (utils.py:311-357) for all of them by the library's
+        threaded host routine (ibs_surface_tables_f64: every wout table is read once where it lies)."""
         import ctypes as C
         from . import _lib
-        keep, ptrs = [], (C.c_void_p * (9 * n_eq))()
+        wouts = list(wouts)
+        ns, n_s, n = self._ns, self.n_surf_per_equilibrium, len(wouts)
+        if first < 0 or first + n > self.n_equilibria:
+            raise ValueError("SurfaceTables.fill: equilibria %d..%d outside the frame of %d" % (first, first + n - 1, self.n_equilibria))
+        mnmax, mnq = len(self.xm), len(self.xm_nyq)
+        Wf, Wfd, Wh0, Whd0, Wh, Whd = self._weights
+        keep, ptrs = [], (C.c_void_p * (9 * n))()
         for q, w in enumerate(wouts):
+            if int(w["ns"]) != ns or not all(w[k] is getattr(self, k) or np.array_equal(w[k], getattr(self, k)) for k in ("xm", "xn", "xm_nyq", "xn_nyq")):
+                raise ValueError("SurfaceTables: the equilibria must share the radial mesh and the mode tables")
             for k, name in enumerate(WOUT_ARRAYS):
                 a = np.ascontiguousarray(w[name], dtype=np.float64)          # (no copy for the arrays simsopt / numpy hand over)
                 if a.shape != ((mnmax if k < 3 else mnq), ns):
-                    raise ValueError("SurfaceTables.from_wouts: %s of equilibrium %d has shape %s" % (name, q, a.shape))
+                    raise ValueError("SurfaceTables: %s of equilibrium %d has shape %s" % (name, first + q, a.shape))
                 keep.append(a)
                 ptrs[9 * q + k] = a.ctypes.data
         p = lambda a: C.c_void_p(a.ctypes.data)
-        _lib.check(_lib.lib().ibs_surface_tables_f64(n_eq, ns, n_s, mnmax, mnq, ptrs, p(Wf), p(Wfd), p(Wh0), p(Whd0),
-                                                     p(tab_mn), p(tab_nyq), int(n_threads)), "ibs_surface_tables_f64")
+        r0, r1 = first * n_s, (first + n) * n_s
+        _lib.check(_lib.lib().ibs_surface_tables_f64(n, ns, n_s, mnmax, mnq, ptrs, p(Wf), p(Wfd), p(Wh0), p(Whd0),
+                                                     p(self.tab_mn[r0:r1]), p(self.tab_nyq[r0:r1]), int(n_threads)), "ibs_surface_tables_f64")
         pres = np.stack([np.asarray(w["pres"], dtype=np.float64)[1:] for w in wouts])        # utils.py:112
         iota = np.stack([np.asarray(w["iotas"], dtype=np.float64)[1:] for w in wouts])       # utils.py:118
-        out = cls.__new__(cls)
-        out.s = np.tile(svals, n_eq)
-        out.xm, out.xn = (np.ascontiguousarray(w0[k], dtype=np.float64) for k in ("xm", "xn"))
-        out.xm_nyq, out.xn_nyq = (np.ascontiguousarray(w0[k], dtype=np.float64) for k in ("xm_nyq", "xn_nyq"))
-        out.tab_mn, out.tab_nyq = tab_mn, tab_nyq
-        phiedge = np.repeat([float(np.asarray(w["phi"])[-1]) for w in wouts], n_s)
-        aminor = np.repeat([float(w["Aminor_p"]) for w in wouts], n_s)
-        out.scal = np.ascontiguousarray(np.stack([out.s, (iota @ Wh.T).reshape(-1), (iota @ Whd.T).reshape(-1),
-                                                  (pres @ Whd.T).reshape(-1), phiedge, aminor], axis=1))
-        out.rows_mn, out.dn_mn = _mode_rows_cached(out.xm.tobytes(), out.xn.tobytes())
-        out.rows_nyq, out.dn_nyq = _mode_rows_cached(out.xm_nyq.tobytes(), out.xn_nyq.tobytes())
-        out.n_equilibria, out.n_surf_per_equilibrium = n_eq, n_s
+        sc = self.scal[r0:r1]
+        sc[:, 1] = (iota @ Wh.T).reshape(-1); sc[:, 2] = (iota @ Whd.T).reshape(-1); sc[:, 3] = (pres @ Whd.T).reshape(-1)
+        sc[:, 4] = np.repeat([float(np.asarray(w["phi"])[-1]) for w in wouts], n_s)
+        sc[:, 5] = np.repeat([float(w["Aminor_p"]) for w in wouts], n_s)
+        return r0, r1
+
+    @classmethod
+    def from_wouts(cls, wouts, svals, n_threads=0):
+        """the surfaces `svals` of SEVERAL equilibria in one table set (the base equilibrium and its DOF-perturbed copies
+        of one optimizer step, sims_runner_NCSX.py:151-276; upstream every one of them runs its own vmec_splines,
+        utils.py:37-158): surface index = i_equilibrium * len(svals) + i_surface, like concat([from_wout(w, svals) ...]).
+        = frame() + fill() of all equilibria (73 equilibria = 115 MB of wout tables: 2.2 ms with 16 threads)."""
+        wouts = list(wouts)
+        out = cls.frame(wouts[0], svals, len(wouts))
+        out.fill(0, wouts, n_threads)
         return out
 
     @classmethod

@@ -71,14 +71,19 @@ class AdjointStep:
     (dof_steps / ScanConfig.dof_step)."""
 
     def __init__(self, ctx, theta, svals, device, nalpha=24, ntheta0=15, del_alpha=0.004, gamma_thresh=-2.0e-4, prefac=50.0,
-                 rank=0, world=1, dist=None, n_threads=0):
+                 rank=0, world=1, dist=None, n_threads=0, n_chunks=4):
         self.ctx, self.device = ctx, device
         self.theta = np.asarray(theta, dtype=np.float64)
         self.svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))       # ball_scan.py:197
         self.nalpha, self.ntheta0, self.del_alpha = int(nalpha), int(ntheta0), float(del_alpha)
         self.gamma_thresh, self.prefac = float(gamma_thresh), float(prefac)
         self.rank, self.world, self.dist, self.n_threads = int(rank), int(world), dist, int(n_threads)
+        # the coarse part runs in n_chunks runs of equilibria: the host computes (ibs_surface_tables_f64) and uploads the tables
+        # of run k + 1 while the GPU scans run k -- of the 2.2 ms the radial step of 73 equilibria takes, the first run's share
+        # is all that stays exposed
+        self.n_chunks = max(1, int(n_chunks))
         self._scan = None
+        self._frame = None
 
     def _scan_for(self, tables, n_eq_local):
         from .scan import BallooningScan
@@ -103,11 +108,27 @@ class AdjointStep:
         err = None
         try:                               # row of an equilibrium: n_surf x (theta0*, alpha*, gam) + the count of what went wrong
             if own:
-                t0 = time.perf_counter()
-                tables = SurfaceTables.from_wouts([wouts[q] for q in own], self.svals, n_threads=self.n_threads)
-                if phases is not None:
-                    phases["host_tables_ms"] = (time.perf_counter() - t0) * 1e3
-                r, bad = self._scan_for(tables, len(own)).device_rows(refine, phases)
+                mine = [wouts[q] for q in own]
+                fr = self._frame
+                if fr is None or fr.n_equilibria != len(own) or not np.array_equal(fr._svals, self.svals) or \
+                        fr._ns != int(mine[0]["ns"]) or len(fr.xm) != len(mine[0]["xm"]) or len(fr.xm_nyq) != len(mine[0]["xm_nyq"]):
+                    pinned = str(self.device).startswith("cuda")
+                    fr = self._frame = SurfaceTables.frame(mine[0], self.svals, len(own), pinned=pinned)
+                    self._scan = None
+                scan = self._scan_for(fr, len(own))
+                nch = min(self.n_chunks, len(own))
+                cuts = [len(own) * k // nch for k in range(nch + 1)]
+
+                def fill(c0, c1):          # (owned-surface range -> equilibria range: chunks are cut at equilibrium boundaries)
+                    q0, q1 = c0 // ns, c1 // ns
+                    r0, r1 = fr.fill(q0, mine[q0:q1], self.n_threads)
+                    if pinned_upload:
+                        self.ctx.upload_tables_rows(fr, self.device, r0, r1)
+                pinned_upload = str(self.device).startswith("cuda")
+                if not pinned_upload:      # (CPU stand-ins in the tests: no device copies to manage)
+                    fr.fill(0, mine, self.n_threads)
+                r, bad = scan.device_rows(refine, phases, chunks=[(cuts[k] * ns, cuts[k + 1] * ns) for k in range(nch)],
+                                          fill=fill if pinned_upload else None)
                 rows = torch.cat([r.reshape(len(own), 3 * ns), bad.reshape(1, 1).expand(len(own), 1)], dim=1)
             else:
                 rows = torch.zeros((0, 3 * ns + 1), dtype=torch.float64, device=self.device)

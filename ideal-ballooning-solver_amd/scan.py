@@ -251,35 +251,53 @@ class BallooningScan:
                                   n_bad=torch.zeros(1, dtype=torch.int32, device=dev))
         return self._resident
 
-    def device_rows(self, refine=True, phases=None):
+    def device_rows(self, refine=True, phases=None, chunks=None, fill=None):
         """(theta0*, alpha*, gam) of the owned surfaces as an (n_own, 3) DEVICE tensor + a device scalar counting what went
         wrong (flagged solves, non-finite maxima): geometry -> coarse scan with the fused per-surface first maximum
         (ibs_gamma_scan_argmax_f64) -> start points on the device (ibs_scan_starts_f64) -> L-BFGS-B per surface on the device
         (ibs_refine_f64 on device pointers) -> final geometry + solve, one line per point (ibs_gamma_points_f64).  Nothing
-        returns to the host in between.  phases: optional dict filled with the per-phase milliseconds (HIP events; adds
-        one synchronisation at the end)."""
+        returns to the host in between.
+        chunks: optional list of (c0, c1) ranges of owned surfaces: the coarse part (geometry, scan, starts) runs chunk by chunk,
+        and fill(c0, c1) -- if given -- is called on the host before a chunk's launches (AdjointStep: the tables of the next
+        equilibria are computed and uploaded while the GPU works on the previous ones).
+        phases: optional dict filled with per-phase milliseconds (HIP events; adds one synchronisation at the end)."""
+        import time
         import torch
         ctx, dev = self.ctx, self.device
         n = len(self.own)
         if n == 0:
             return torch.empty((0, 3), dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float64, device=dev)
         res = self._resident_inputs()
-        ev = []
+        na = len(self.alpha_scan)
+        ev = {}
 
-        def mark():
+        def mark(name):
             if phases is not None:
-                e = torch.cuda.Event(enable_timing=True); e.record(); ev.append(e)
+                e = torch.cuda.Event(enable_timing=True); e.record(); ev.setdefault(name, []).append(e)
         res["n_bad"].zero_()
-        mark()
-        geo = ctx.fieldline_geometry(self.tables, res["surf"], res["al"], res["th"], device=dev)
-        mark()
-        sc = ctx.gamma_scan_argmax(self.h, [geo["geo"][k] for k in range(7)], geo["dPdrho"], res["t0"], n)
-        start = ctx.scan_starts(res["alpha"], res["t0"], sc["pack"], res["n_bad"])
-        mark()
-        bad = ((sc["info"] >> 16) != 0).sum() + res["n_bad"][0]
+        chunks = chunks or [(0, n)]
+        start = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        gmax = torch.empty((n,), dtype=torch.float64, device=dev)
+        bad = res["n_bad"][0] * 0
+        t_fill = 0.0
+        for c0, c1 in chunks:
+            if fill is not None:
+                t0 = time.perf_counter(); fill(c0, c1); t_fill += time.perf_counter() - t0
+            mark("g0")
+            geo = ctx.fieldline_geometry(self.tables, res["surf"][c0 * na:c1 * na], res["al"][c0 * na:c1 * na], res["th"], device=dev)
+            mark("g1")
+            sc = ctx.gamma_scan_argmax(self.h, [geo["geo"][k] for k in range(7)], geo["dPdrho"], res["t0"], c1 - c0)
+            st = ctx.scan_starts(res["alpha"], res["t0"], sc["pack"], res["n_bad"])
+            mark("s1")
+            if len(chunks) == 1:
+                start, gmax = st, sc["pack"][:, 0]
+            else:
+                start[c0:c1] = st; gmax[c0:c1] = sc["pack"][:, 0]
+            bad = bad + ((sc["info"] >> 16) != 0).sum()
+        mark("r0")
         if refine:
             xo, fo, ne, rounds = ctx.refine_device(self.tables, res["pt_surf"], start, res["th"], self.del_alpha)
-            mark()
+            mark("r1")
             xa, xt = xo[:, 0].contiguous(), xo[:, 1].contiguous()
             gf = ctx.fieldline_geometry(self.tables, res["pt_surf"], xa, res["th"], device=dev)
             fin = ctx.gamma_points(self.h, *[gf["geo"][k] for k in range(7)], gf["dPdrho"], xt, want_info=True)
@@ -287,14 +305,18 @@ class BallooningScan:
             bad = bad + ((fin["info"] >> 16) != 0).sum()
             self.last_refine = dict(n_evals=ne, rounds=rounds)
         else:
-            mark()
-            rows = torch.stack([start[:, 1], start[:, 0], sc["pack"][:, 0]], dim=1)
-        mark()
+            mark("r1")
+            rows = torch.stack([start[:, 1], start[:, 0], gmax], dim=1)
+        bad = bad + res["n_bad"][0]
+        mark("f1")
         if phases is not None:
             torch.cuda.synchronize()
-            names = ("geometry_ms", "scan_argmax_ms", "refine_ms", "final_solve_ms")
-            for k, nm in enumerate(names):
-                phases[nm] = ev[k].elapsed_time(ev[k + 1])
+            span = lambda a, b: sum(x.elapsed_time(y) for x, y in zip(ev[a], ev[b]))
+            phases["geometry_ms"] = span("g0", "g1"); phases["scan_argmax_ms"] = span("g1", "s1")
+            phases["refine_ms"] = span("r0", "r1"); phases["final_solve_ms"] = span("r1", "f1")
+            if fill is not None:
+                phases["host_tables_ms"] = t_fill * 1e3
+                phases["coarse_chunks"] = len(chunks)
         return rows, bad.to(torch.float64)
 
     def local_rows(self, refine=True):

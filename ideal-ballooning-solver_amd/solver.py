@@ -366,6 +366,22 @@ class Context:
             cache[key] = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in host + [tables.rows_mn, tables.rows_nyq]]
         return cache[key]
 
+    def upload_tables_rows(self, tables, device, r0, r1):
+        """(re)upload the surfaces r0 .. r1 - 1 of `tables` into its resident device copies (allocated on first use);
+        asynchronous on the current torch stream when the host arrays are page-locked (SurfaceTables.frame(pinned=True)).
+        For callers that fill a frame piece by piece while earlier pieces are already being worked on."""
+        import torch
+        cache = tables.__dict__.setdefault("_device_copies", {})
+        key = str(device)
+        if key not in cache:
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            e = lambda a: torch.empty(a.shape, dtype=torch.float64, device=device)
+            cache[key] = [t(tables.xm), t(tables.xn), t(tables.xm_nyq), t(tables.xn_nyq), e(tables.tab_mn), e(tables.tab_nyq),
+                          e(tables.scal), t(tables.rows_mn), t(tables.rows_nyq)]
+        dev = cache[key]
+        for k, host in ((4, tables.tab_mn), (5, tables.tab_nyq), (6, tables.scal)):
+            dev[k][r0:r1].copy_(torch.from_numpy(host[r0:r1]), non_blocking=True)
+
     def refine(self, tables, pt_surf, starts, theta, del_alpha=0.004, maxiter=30, ftol=5.0e-11, gtol=2.0e-8, device=None):
         """maximise gam over (alpha, theta0) from starts (n, 2) on surfaces tables.s[pt_surf] -- the whole
         quasi-Newton loop runs on the device (ibs_refine_f64; replaces ball_scan.py:305-314).

@@ -29,8 +29,14 @@ def test_pmc_counters_are_quoted_for_the_exact_kernel_and_batch_size_only(monkey
     assert e is None and "4096" in why
     e, why = bench.pmc_entry("ibs::k_gamma_scan<double", 1024)              # a prefix is not a kernel
     assert e is None
-    e, why = bench.pmc_entry("ibs::k_geo_rows<2, 1, 12>", 2048)             # launches of mixed batch sizes under one grid
+    e, why = bench.pmc_entry("ibs::k_geo_rows<2, 1, 12>", 2048)             # launches of mixed work under one entry
     assert e is None and "mixes" in why
+    table["ibs::k_solve_gcf<double, 16> @67108864x64 #0"] = dict(_entry("ibs::k_solve_gcf<double, 16>", 1048576, 7.0e9), work_class=0)
+    table["ibs::k_solve_gcf<double, 16> @67108864x64 #1"] = dict(_entry("ibs::k_solve_gcf<double, 16>", 1048576, 9.6e9), work_class=1)
+    e0, _ = bench.pmc_entry("ibs::k_solve_gcf<double, 16>", 1048576, 0)       # smooth family first, rough second: by class
+    e1, _ = bench.pmc_entry("ibs::k_solve_gcf<double, 16>", 1048576, 1)
+    assert e0["SQ_INSTS_VALU"]["mean"] == 7.0e9 and e1["SQ_INSTS_VALU"]["mean"] == 9.6e9
+    assert bench.pmc_entry("ibs::k_solve_gcf<double, 16>", 1048576, 2)[0] is None
     r = bench.hbm_roofline(3686400, 0.025, "valu_issue", "ibs::k_gamma_scan<double, 8>", 1024)
     assert r["bound"] == "valu_issue" and r["frac"] == r["hbm_frac"] and abs(r["achieved"] - 147.456) < 1e-9
     assert r["traffic"] == (2 * 100.0 + 10.0) * 1024 and r["valu_insts_per_wave"] == 6.0e6 / 1024

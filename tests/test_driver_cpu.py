@@ -442,7 +442,7 @@ class _FakeScan:
     def __init__(self, tables, fail):
         self.tables, self.fail = tables, fail
 
-    def device_rows(self, refine=True, phases=None):
+    def device_rows(self, refine=True, phases=None, chunks=None, fill=None):
         import torch
         if self.fail:
             raise ValueError("injected failure")

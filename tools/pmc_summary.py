@@ -2,10 +2,12 @@
 """Condense rocprofv3 --pmc CSVs (separate FETCH_SIZE / WRITE_SIZE / SQ passes of tools/profile_run.py)
 into profiles/<tag>_pmc.json.   usage: tools/pmc_summary.py gpurun_out/pmc_r01 profiles/r01_pmc.json [set-name]
 
-Launches are grouped by (kernel name, grid size, workgroup size): two legs that run the same kernel at different sizes get
-two entries, keyed "<kernel> @<grid>x<wg>" (grid = threads of the launch).  Every entry carries the spread of its
-launches' VALU instruction counts (`valu_spread` = max / min): a persistent kernel whose grid does not depend on the
-batch (k_geo_rows) shows mixed batch sizes there, and bench.py refuses to quote such an entry.
+One entry per (kernel name, grid size, workgroup size, WORK CLASS), keyed "<kernel> @<grid>x<wg> #<k>": launches of one kernel at
+one launch size are split into classes of equal work -- VALU instruction counts within 2 % of the class's first launch, in order of
+first appearance -- so that two legs which run the same kernel at the same size on different data (the smooth and the rough
+family of configs[4]) or a persistent kernel whose grid does not show its batch size (k_geo_rows) never share an entry.  The
+classes come from the SQ pass; the FETCH / WRITE passes run the same program, so their launches are matched by their ordinal among
+the library's launches.  bench.py looks an entry up by exact kernel name, waves per launch and class number.
 (the set name is stored under "_set": bench.py quotes it next to every counter it replays from this file)"""
 import collections
 import csv
@@ -14,36 +16,80 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-out = collections.defaultdict(dict)
-for tag in ("fetch", "write", "sq"):
+
+
+def launches(tag):
+    """the library's launches of one pass in dispatch order: [(short name, grid, wg, {counter: value})]"""
     fn = os.path.join(src, "%s_counter_collection.csv" % tag)
     if not os.path.exists(fn):
-        continue
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        return None
+    by_id = collections.OrderedDict()
     for r in csv.DictReader(open(fn)):
         k = r["Kernel_Name"]
         if "ibs::" not in k:
             continue
-        short = k.split("(")[0].replace("void ", "").strip()
-        key = "%s @%sx%s" % (short, r["Grid_Size"], r["Workgroup_Size"])
-        acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        for c, vals in v.items():
-            out[k][c] = dict(mean=sum(vals) / len(vals), n=len(vals))
-            if c == "SQ_INSTS_VALU":
-                out[k]["valu_spread"] = max(vals) / max(min(vals), 1.0)
-for k, v in list(out.items()):
-    name, _, dims = k.partition(" @")
-    v["kernel"] = name
-    v["grid_threads"], v["workgroup"] = (int(x) for x in dims.split("x"))
-    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        did = int(r["Dispatch_Id"])
+        if did not in by_id:
+            by_id[did] = [k.split("(")[0].replace("void ", "").strip(), int(r["Grid_Size"]), int(r["Workgroup_Size"]), {}]
+        by_id[did][3][r["Counter_Name"]] = float(r["Counter_Value"])
+    return [by_id[d] for d in sorted(by_id)]
+
+
+sq = launches("sq")
+if sq is None:
+    sys.exit("pmc_summary: %s holds no sq_counter_collection.csv" % src)
+classes = collections.defaultdict(list)          # (name, grid, wg) -> [reference VALU count of class k]
+keys = []
+for name, grid, wg, c in sq:
+    v = c.get("SQ_INSTS_VALU", 0.0)
+    refs = classes[(name, grid, wg)]
+    for k, ref in enumerate(refs):
+        if abs(v - ref) <= 0.02 * max(ref, 1.0):
+            break
+    else:
+        refs.append(v); k = len(refs) - 1
+    keys.append("%s @%dx%d #%d" % (name, grid, wg, k))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for key, (name, grid, wg, c) in zip(keys, sq):
+    for cn, val in c.items():
+        acc[key][cn].append(val)
+mismatch = 0
+for tag in ("fetch", "write"):
+    ls = launches(tag)
+    if ls is None:
+        continue
+    if len(ls) != len(sq):
+        print("pmc_summary: the %s pass saw %d launches, the sq pass %d: matched by kernel and grid only" % (tag, len(ls), len(sq)), file=sys.stderr)
+    for i, (name, grid, wg, c) in enumerate(ls):
+        key = keys[i] if i < len(keys) and keys[i].startswith("%s @%dx%d #" % (name, grid, wg)) and len(ls) == len(sq) else None
+        if key is None:
+            mismatch += 1
+            key = "%s @%dx%d #0" % (name, grid, wg)
+        for cn, val in c.items():
+            acc[key][cn].append(val)
+out = {}
+for key, v in acc.items():
+    e = {c: dict(mean=sum(vals) / len(vals), n=len(vals)) for c, vals in v.items()}
+    name, _, rest = key.partition(" @")
+    dims, _, cls = rest.partition(" #")
+    e["kernel"] = name
+    e["grid_threads"], e["workgroup"] = (int(x) for x in dims.split("x"))
+    e["work_class"] = int(cls)
+    if "SQ_INSTS_VALU" in v:
+        e["valu_spread"] = max(v["SQ_INSTS_VALU"]) / max(min(v["SQ_INSTS_VALU"]), 1.0)
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of
         # the bytes of a coalesced streaming read -> double it; WRITE_SIZE is exact.
-        v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024
-    if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
-        v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"]["mean"] / v["SQ_WAVES"]["mean"]
-        v["valu_busy_frac_of_wave_lifetime"] = v["SQ_ACTIVE_INST_VALU"]["mean"] / v["SQ_WAVE_CYCLES"]["mean"]
+        e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024
+    if "SQ_INSTS_VALU" in e and "SQ_WAVES" in e:
+        e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"]["mean"] / e["SQ_WAVES"]["mean"]
+        e["valu_busy_frac_of_wave_lifetime"] = e["SQ_ACTIVE_INST_VALU"]["mean"] / e["SQ_WAVE_CYCLES"]["mean"]
+    out[key] = e
 out["_set"] = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(dst).replace("_pmc.json", "")
+out["_unmatched_launches_of_the_byte_passes"] = mismatch
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
-print(json.dumps({k: ({kk: vv for kk, vv in v.items() if not isinstance(vv, dict)} if isinstance(v, dict) else v)
-                  for k, v in out.items()}, indent=1, sort_keys=True))
+for k in sorted(out):
+    v = out[k]
+    if isinstance(v, dict):
+        print("%-72s n %3d waves %9.0f valu/wave %8.0f traffic %s" % (k, v.get("SQ_WAVES", {}).get("n", 0), v.get("SQ_WAVES", {}).get("mean", 0),
+                                                                      v.get("valu_insts_per_wave", 0), v.get("hbm_bytes_per_launch")))
