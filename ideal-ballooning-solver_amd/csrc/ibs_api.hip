@@ -1015,9 +1015,12 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
   a.line_surf = line_surf; a.line_alpha = line_alpha; a.theta = theta; a.geo = geo; a.dPdrho = dPdrho;
   if (rows) { a.rows_mn = rows_mn; a.rows_nyq = rows_nyq; }
   if (img_bytes) {
-    if (int r = ensure_ws(ctx, img_bytes + 4096)) return r;
+    // a call whose lines touch few of the surfaces (a large table set worked through piece by piece) builds their images only
+    const bool mark = n_surf >= 32 && (long)n_lines < 8L * n_surf;
+    if (int r = ensure_ws(ctx, img_bytes + pad256((size_t)n_surf * sizeof(int)) + 4096)) return r;
     Arena ar(ctx);
     a.img[ibs::geo_lpp_index(a.form.lpp)] = ar.take<double>(img_bytes / sizeof(double));
+    if (mark) a.surf_used = ar.take<int>(n_surf);
   }
   HIPCHK(ibs::launch_geometry(a, ctx->stream, ctx->n_cu));
   return 0;

@@ -198,10 +198,16 @@ size_t geo_image_doubles(const GeoArgs& a, int lpp) {
 //   bits 0-1: 0 = same m as the row before (or m = 0 in the first row), 1 = m advanced by one (plane rotation), 2 = any
 //             other m (sincos);   bits 2-3: 0 = first n is 0 (one lane per point), 1 = the same first n as the last row that
 //             computed cos / sin(n phi), 2 = compute them.
+__global__ void k_geo_mark(int n_lines, int n_surf, const int* line_surf, int* used) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_lines) used[min(max(line_surf[i], 0), n_surf - 1)] = 1;
+}
+
 __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double* img) {
   __shared__ int goff1[kGeoMaxRows + 1], goff2[kGeoMaxRows + 1], cnt1[kGeoMaxRows], cnt2[kGeoMaxRows];
   __shared__ double rm_s[2][kGeoMaxRows], rn_s[2][kGeoMaxRows];
   const int js = blockIdx.x, t = threadIdx.x;
+  if (a.surf_used && a.surf_used[js] == 0) return;          // (block-uniform) no line of this call lies on the surface
   const int nr1 = a.nrows_mn, nr2 = a.nrows_nyq;
   const GeoImgLayout L = geo_layout(a.mnmax, nr1, a.mnmax_nyq, nr2, lpp);
   double* I = img + (size_t)js * L.total;
@@ -833,7 +839,11 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_tail(GeoArgs a) {
   const double* drmnc = lmns + a.mnmax; const double* dzmns = drmnc + a.mnmax; const double* dlmns = dzmns + a.mnmax;
   auto resid = [&](double tv) {
     double acc = 0.0;
-    for (int k = lane; k < a.mnmax; k += 64) acc += lmns[k] * sin(a.xm[k] * tv - a.xn[k] * phi);
+    for (int k = lane; k < a.mnmax; k += 64) {
+      double sa, ca;
+      geo_sincos(a.xm[k] * tv - a.xn[k] * phi, &sa, &ca);           // (|angle| stays far below the 1e5 the fast form covers)
+      acc += lmns[k] * sa;
+    }
     return tp - (tv + geo_wave_sum(acc));
   };
   // the secant iteration of the row kernels (start: one fixed-point step; stop on the step size)
@@ -855,7 +865,7 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_tail(GeoArgs a) {
   for (int k = lane; k < a.mnmax; k += 64) {
     const double m = a.xm[k], n = a.xn[k];
     double sa, ca;
-    sincos(m * tv - n * phi, &sa, &ca);
+    geo_sincos(m * tv - n * phi, &sa, &ca);
     S.R += rmnc[k] * ca; S.R_s += drmnc[k] * ca; S.R_t -= rmnc[k] * m * sa; S.R_p += rmnc[k] * n * sa;
     S.Z_s += dzmns[k] * sa; S.Z_t += zmns[k] * m * ca; S.Z_p -= zmns[k] * n * ca;
     S.l_s += dlmns[k] * sa; S.l_t += lmns[k] * m * ca; S.l_p -= lmns[k] * n * ca;
@@ -867,7 +877,7 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_tail(GeoArgs a) {
   for (int k = lane; k < a.mnmax_nyq; k += 64) {
     const double m = a.xm_nyq[k], n = a.xn_nyq[k];
     double sa, ca;
-    sincos(m * tv - n * phi, &sa, &ca);
+    geo_sincos(m * tv - n * phi, &sa, &ca);
     S.sqg += gmnc[k] * ca; S.modB += bmnc[k] * ca; S.B_s += dbmnc[k] * ca;
     S.B_t -= bmnc[k] * m * sa; S.B_p += bmnc[k] * n * sa;
     S.Bsup_phi += bsupv[k] * ca; S.Bsub_s += bsubs[k] * sa; S.Bsub_t += bsubu[k] * ca; S.Bsub_p += bsubv[k] * ca;
@@ -926,6 +936,10 @@ hipError_t launch_geometry(GeoArgs& a, hipStream_t st, int n_cu) {
   const int li = geo_lpp_index(f.lpp);
   if (geo_rows_usable(a, f.lpp) && a.img[li]) {
     if (!(a.img_ready & (1u << li))) {
+      if (a.surf_used) {                                    // images of the surfaces this call's lines lie on only
+        (void)hipMemsetAsync(a.surf_used, 0, (size_t)a.n_surf * sizeof(int), st);
+        hipLaunchKernelGGL(k_geo_mark, dim3((a.n_lines + 255) / 256), dim3(256), 0, st, a.n_lines, a.n_surf, a.line_surf, a.surf_used);
+      }
       hipLaunchKernelGGL(k_geo_prepare, dim3(a.n_surf), dim3(256), 0, st, a, f.lpp, a.img[li]);
       a.img_ready |= 1u << li;
     }

@@ -71,6 +71,8 @@ struct GeoArgs {
   const int* n_lines_dev;  // optional: the number of lines actually requested, read on the device (<= n_lines, which then
                            // only sizes the grid): the refinement rounds of ibs_refine_f64 shrink without a host round trip
   size_t plane;            // distance between the 8 output planes in elements; 0 = n_lines * ld
+  int* surf_used;          // optional [n_surf] scratch: launch_geometry marks the surfaces the lines refer to and k_geo_prepare builds
+                           // only their images (a caller that works through a large table set piece by piece: AdjointStep)
 };
 GeoForm geo_pick_form(long n_lines, int N, int n_cu, int lpp_opt);
 int geo_lpp_index(int lpp);
