@@ -787,6 +787,46 @@ def c2_refined_leg(ctx, device, rank, world, dist, fence, passes=3):
     return out
 
 
+def c4_sharded_leg(ctx, device, rank, world, dist, fence, passes=2):
+    """BASELINE configs[3] over the ranks: the 73 equilibria of an optimizer step dealt round-robin (the reference's one srun per
+    DOF, ball_submit.py:64-95), every rank running its share as ONE batch (AdjointStep), ONE all-gather of the per-equilibrium
+    rows, objective and 72-gradient formed everywhere.  Checked on rank 0 against the same step computed there alone: growth rates
+    to 1e-10 (the refinement's geometry form follows the batch size, i.e. other summation orders), gradient to 1e-8 relative."""
+    import torch
+    import ibs_amd
+    wout0 = dict(np.load(os.path.join(ROOT, "tests", "golden", "G8_wout_ncsx_op.npz")))
+    wouts, steps, x0 = emulated_equilibria(wout0)
+    n_eq, ns = len(wouts), 5
+    svals = np.linspace(0.5, 0.95, ns)
+    th = ibs_amd.theta_grid_for(11, 11)
+    f_other = 0.8 + 0.01 * np.arange(n_eq)
+    step = ibs_amd.AdjointStep(ctx, th, svals, device, rank=rank, world=world, dist=dist,
+                               gather_device=None if dist.get_backend() == "nccl" else "cpu")
+    out = step.run(wouts, f_other, steps)                    # warm-up + the result to check
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        out = step.run(wouts, f_other, steps)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else torch.device("cpu"))
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    res = None
+    if rank == 0:
+        alone = ibs_amd.AdjointStep(ctx, th, svals, device).run(wouts, f_other, steps)
+        dg = float(np.abs(alone["gam"] - out["gam"]).max())
+        dd = float(np.abs(alone["dfobj"] - out["dfobj"]).max() / max(1.0, np.abs(alone["dfobj"]).max()))
+        ok = dg < 1e-10 and dd < 1e-8
+        if not ok:
+            print("bench.py: c4_adjoint_step_sharded check FAILED (max|dgam| %g, relative gradient difference %g)" % (dg, dd), file=sys.stderr, flush=True)
+        res = dict(workload="configs[3]: %d equilibria round-robin over %d ranks, each rank's share as one AdjointStep batch, ONE all-gather of "
+                            "[n_eq_local, 3 n_surf + 1]" % (n_eq, world), scaling="strong", n_gpus=world, passes=passes,
+                   ms_per_step=dt / passes * 1e3, checks_passed=ok, max_abs_dgam_vs_one_rank=dg, rel_dgradient_vs_one_rank=dd,
+                   fobj=out["fobj"])
+    return res
+
+
 class Watchdog:
     """Bounds the phases that can hang for ever inside a collective (a second RCCL communicator next to torch's, the first
     multi-rank gathers of a new build).  When a phase overruns, rank 0 prints the JSON line it has so far -- the headline
@@ -1056,7 +1096,9 @@ def main():
         for key, leg, label in (("ncsx_c2_sharded", lambda: c2_sharded_leg(ctx, device, rank, world, dist, fence, native=False),
                                  "configs[2] sharded, torch.distributed gather"),
                                 ("ncsx_c2_sharded_refined", lambda: c2_refined_leg(ctx, device, rank, world, dist, fence),
-                                 "configs[2] sharded with the refinement")):
+                                 "configs[2] sharded with the refinement"),
+                                ("c4_adjoint_step_sharded", lambda: c4_sharded_leg(ctx, device, rank, world, dist, fence),
+                                 "configs[3] sharded over the equilibria")):
             dog.arm(label, 300)
             try:
                 res = leg()

@@ -71,7 +71,7 @@ class AdjointStep:
     (dof_steps / ScanConfig.dof_step)."""
 
     def __init__(self, ctx, theta, svals, device, nalpha=24, ntheta0=15, del_alpha=0.004, gamma_thresh=-2.0e-4, prefac=50.0,
-                 rank=0, world=1, dist=None, n_threads=0, n_chunks=4):
+                 rank=0, world=1, dist=None, n_threads=0, n_chunks=4, gather_device=None):
         self.ctx, self.device = ctx, device
         self.theta = np.asarray(theta, dtype=np.float64)
         self.svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))       # ball_scan.py:197
@@ -82,6 +82,7 @@ class AdjointStep:
         # of run k + 1 while the GPU scans run k -- of the 2.2 ms the radial step of 73 equilibria takes, the first run's share
         # is all that stays exposed
         self.n_chunks = max(1, int(n_chunks))
+        self.gather_device = gather_device        # None: the rows are gathered where they are (RCCL); "cpu": through host copies (gloo)
         self._scan = None
         self._frame = None
 
@@ -136,6 +137,8 @@ class AdjointStep:
             err = e
             rows = torch.full((len(own), 3 * ns + 1), float("nan"), dtype=torch.float64, device=self.device)
         t0 = time.perf_counter()
+        if self.gather_device is not None and self.world > 1:
+            rows = rows.to(self.gather_device)
         full = gather_rows_tensor(rows, n_eq, self.rank, self.world, self.dist, self.ctx if getattr(self.ctx, "_comm_world", 0) == self.world else None)
         host = full.cpu().numpy()                                          # the one copy (and synchronisation)
         if err is not None:

@@ -19,7 +19,7 @@ for q in range(n_eq):
     tabs_all.append(ibs_amd.SurfaceTables.from_wout(w, svals))
 big = ibs_amd.SurfaceTables.concat(tabs_all)
 print("tables for %d equilibria: %.1f s" % (n_eq, time.time() - t0), flush=True)
-scan = ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), tables=big, device=dev)
+scan = ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), tables=big, device=dev, surf_index=np.arange(len(big.s)))
 tabs_c = scan.coarse()
 st = np.array([ibs_amd.pick_start(t, scan.alpha_scan, scan.theta0_scan)[:2] for t in tabs_c])
 for rep in range(2):

@@ -13,7 +13,7 @@ for n_eq in (1, 73):
             w["rmnc"] = wout["rmnc"].copy(); w["rmnc"][q % 200, :] *= (1 + 2e-3 * np.linspace(0, 1, wout["rmnc"].shape[1]) ** 2)
         tabs_all.append(ibs_amd.SurfaceTables.from_wout(w, svals))
     big = ibs_amd.SurfaceTables.concat(tabs_all)
-    scan = ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), tables=big, device=dev)
+    scan = ibs_amd.BallooningScan(ctx, None, th, np.tile(svals, n_eq), tables=big, device=dev, surf_index=np.arange(len(big.s)))
     st = np.array([ibs_amd.pick_start(t, scan.alpha_scan, scan.theta0_scan)[:2] for t in scan.coarse()])
     runs = [scan.refine_device(st) for _ in range(6)]
     same = all(np.array_equal(runs[0][0], r[0]) and np.array_equal(runs[0][1], r[1]) and np.array_equal(runs[0][2], r[2]) for r in runs[1:])
