@@ -426,7 +426,7 @@ struct GroupSolver {
     auto sel = [](bool c, const Pt& a, const Pt& b) { return Pt{c ? a.x : b.x, c ? a.m : b.m, c ? a.e : b.e}; };
     while (__any(!done) && guard < kMaxIt) {
       ++guard;
-      const int C = sweep_fwd<false>(sig);
+      const int C = sweep_fwd<true>(sig);      // (the incoming pair is kept: the last sweep of every group is the one its eigenvector replays)
       const bool act = !done;
       it += act ? 1 : 0;
       const Pt cur{sig, shoot_m, shoot_e};
@@ -505,8 +505,11 @@ struct GroupSolver {
       aimed = (go && !ovr) ? (aim_ok ? (c_up ? 1 : -1) : 0) : 0;
       was_interp = go && interp_now && !ovr;
     }
-    // eigenvector and Rayleigh-quotient polish at each group's last shift
-    sweep_fwd<true>(sig);
+    // eigenvector and Rayleigh-quotient polish at each group's last shift.  A group that is done has swept its final shift last (it
+    // keeps re-evaluating the frozen shift while the wave's other groups finish), so the forward solution is already in place; only
+    // a wave that left on the iteration cap holds a shift it has not swept yet.  (Until round 4 every solve paid one more forward
+    // sweep here: 1 of 11.)
+    if (__any(!done)) sweep_fwd<true>(sig);
     sweep_bwd(sig);
     const T rho = twisted(sig);
     iters_out = it;

@@ -113,14 +113,16 @@ class SurfaceTables:
         out.xm_nyq, out.xn_nyq = (np.ascontiguousarray(wout0[k], dtype=np.float64) for k in ("xm_nyq", "xn_nyq"))
         mnmax, mnq = len(out.xm), len(out.xm_nyq)
 
-        def alloc(shape):
+        out._pinned = {}                  # name -> page-locked torch tensor the numpy array of that name is a view of
+
+        def alloc(name, shape):
             if pinned:
                 import torch
                 t = torch.empty(shape, dtype=torch.float64).pin_memory()
-                out.__dict__.setdefault("_pinned", []).append(t)
+                out._pinned[name] = t
                 return t.numpy()
             return np.empty(shape)
-        out.tab_mn, out.tab_nyq, out.scal = alloc((n_eq * n_s, 6, mnmax)), alloc((n_eq * n_s, 7, mnq)), alloc((n_eq * n_s, 6))
+        out.tab_mn, out.tab_nyq, out.scal = alloc("tab_mn", (n_eq * n_s, 6, mnmax)), alloc("tab_nyq", (n_eq * n_s, 7, mnq)), alloc("scal", (n_eq * n_s, 6))
         out.scal[:, 0] = out.s
         out.rows_mn, out.dn_mn = _mode_rows_cached(out.xm.tobytes(), out.xn.tobytes())
         out.rows_nyq, out.dn_nyq = _mode_rows_cached(out.xm_nyq.tobytes(), out.xn_nyq.tobytes())

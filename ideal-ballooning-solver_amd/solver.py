@@ -379,8 +379,10 @@ class Context:
             cache[key] = [t(tables.xm), t(tables.xn), t(tables.xm_nyq), t(tables.xn_nyq), e(tables.tab_mn), e(tables.tab_nyq),
                           e(tables.scal), t(tables.rows_mn), t(tables.rows_nyq)]
         dev = cache[key]
-        for k, host in ((4, tables.tab_mn), (5, tables.tab_nyq), (6, tables.scal)):
-            dev[k][r0:r1].copy_(torch.from_numpy(host[r0:r1]), non_blocking=True)
+        pinned = getattr(tables, "_pinned", {})
+        for k, name in ((4, "tab_mn"), (5, "tab_nyq"), (6, "scal")):
+            src = pinned[name] if name in pinned else torch.from_numpy(getattr(tables, name))
+            dev[k][r0:r1].copy_(src[r0:r1], non_blocking=True)
 
     def refine(self, tables, pt_surf, starts, theta, del_alpha=0.004, maxiter=30, ftol=5.0e-11, gtol=2.0e-8, device=None):
         """maximise gam over (alpha, theta0) from starts (n, 2) on surfaces tables.s[pt_surf] -- the whole
