@@ -54,3 +54,38 @@ def test_committed_pmc_file_serves_the_headline_kernel():
     e, why = bench.pmc_entry("ibs::k_gamma_scan<double, 8>", 1024)
     assert why is None, why
     assert 3.6e6 < e["hbm_bytes_per_launch"] < 5.5e6
+
+
+def test_pmc_summary_splits_launches_into_work_classes(tmp_path):
+    """tools/pmc_summary.py: launches of one kernel at one launch size on different data get separate entries (work classes by
+    VALU instruction count, in order of first appearance); the byte passes are matched to them by launch ordinal."""
+    import json
+    import subprocess
+    hdr = '"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name",' \
+          '"Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value",' \
+          '"Start_Timestamp","End_Timestamp"\n'
+    kern = '"void ibs::k_solve_gcf<double, 16>(long, int, double)"'
+    other = '"void at::native::vectorized_elementwise_kernel<4>(int)"'
+
+    def rows(did, name, counters):
+        return "".join('%d,%d,"Agent 2",1,1,1,4096,7,%s,64,0,0,8,0,32,"%s",%f,1,2\n' % (did, did, name, c, v) for c, v in counters)
+    # dispatch order: smooth, smooth, (a torch kernel), rough, rough, smooth
+    valu = [7000.0, 7001.0, None, 9600.0, 9590.0, 7000.5]
+    sq = hdr; fetch = hdr; write = hdr
+    for i, v in enumerate(valu, start=1):
+        if v is None:
+            sq += rows(i, other, [("SQ_WAVES", 1.0)]); fetch += rows(i, other, [("FETCH_SIZE", 1.0)]); write += rows(i, other, [("WRITE_SIZE", 1.0)])
+            continue
+        sq += rows(i, kern, [("SQ_WAVES", 64.0), ("SQ_INSTS_VALU", v), ("SQ_ACTIVE_INST_VALU", 10.0), ("SQ_WAVE_CYCLES", 20.0)])
+        fetch += rows(i, kern, [("FETCH_SIZE", 100.0 if v < 8000 else 300.0)])
+        write += rows(i, kern, [("WRITE_SIZE", 10.0)])
+    for tag, text in (("sq", sq), ("fetch", fetch), ("write", write)):
+        (tmp_path / ("%s_counter_collection.csv" % tag)).write_text(text)
+    out = tmp_path / "x_pmc.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(tmp_path), str(out), "test"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.load(open(out))
+    k0, k1 = "ibs::k_solve_gcf<double, 16> @4096x64 #0", "ibs::k_solve_gcf<double, 16> @4096x64 #1"
+    assert d[k0]["SQ_WAVES"]["n"] == 3 and d[k1]["SQ_WAVES"]["n"] == 2 and d["_unmatched_launches_of_the_byte_passes"] == 0
+    assert d[k0]["hbm_bytes_per_launch"] == (2 * 100.0 + 10.0) * 1024 and d[k1]["hbm_bytes_per_launch"] == (2 * 300.0 + 10.0) * 1024
+    assert d[k0]["work_class"] == 0 and d[k1]["work_class"] == 1 and d[k0]["valu_spread"] < 1.01
