@@ -157,32 +157,42 @@ __device__ long long geo_probe_buf[256 * 16];
 
 struct GeoImgLayout {      // offsets (in doubles) inside one surface's image: a function of the table sizes and LPP only
   int T1c, T2c;            // capacities (groups per lane) of the two lists, even
-  int o_ri1, o_ri2;        // row info [nr][4]: m, first n, n advance per lane, groups per lane
-  int o_int;               // ints: goff1[nr1 + 1], goff2[nr2 + 1], code1[nr1], code2[nr2]
-  int o_lm, o_amn, o_anq;  // lane-major lists
+  int o_ri1, o_ri2;        // row info [nr][4]: m, first n, n advance per lane, groups per lane (LPP = 1: pairs)
+  int o_int;               // ints: goff1[nr1 + 1], goff2[nr2 + 1], code1[nr1], code2[nr2] (+ LPP = 1: soff1[nr1 + 1], soff2[nr2 + 1])
+  int o_lm, o_amn, o_anq;  // lane-major lists (LPP > 1)
   int s_lm, s_amn, s_anq;  // lane strides
-  int Tsc, o_sy0, o_sym;   // n-symmetric form of the lmns rows (one lane per point): capacity, [nr1][2] + 2, [Tsc][nr1][2]
-  int total;
+  int o_c0mn, o_c0nq;      // LPP = 1, n-symmetric rows: centre coefficients [nr][10] (slot 9: the centre n)
+  int o_symn;              //   pair tables in 16-double blocks (one lane of a 16-lane row each, see fmac_bc): mn [pairs][32] = (sum, difference) of
+                           //   9 columns + pad, then nyq [pairs][16] = 8 columns (offset: header slot 14), then the lmns pairs of ALL rows by
+                           //   pair index [t][16 NB] for the root solve (offset: header slot 18; NB = 2, or 3 with more than 12 rows)
+  int total;               // capacity; LPP = 1: the used length is header slot 13
 };
 __host__ __device__ inline GeoImgLayout geo_layout(int mnmax, int nr1, int mnmax_nyq, int nr2, int lpp) {
   GeoImgLayout L;
   // a row of c modes gives every lane ceil(c / (2 lpp)) groups of two modes; + 1 keeps the total even
   L.T1c = (mnmax / (2 * lpp) + nr1 + 2) & ~1;
   L.T2c = (mnmax_nyq / (2 * lpp) + nr2 + 2) & ~1;
-  L.o_ri1 = 16;            // header: s iota d_iota_d_s phiedge Aminor_p + the per-surface factors of the metric algebra
+  L.o_ri1 = 20;            // header: s iota d_iota_d_s phiedge Aminor_p + the per-surface factors of the metric algebra + list sizes
   L.o_ri2 = L.o_ri1 + 4 * nr1;
   L.o_int = L.o_ri2 + 4 * nr2;
-  const int n_int = (nr1 + 1) + (nr2 + 1) + nr1 + nr2;
+  const int n_int = ((nr1 + 1) + (nr2 + 1)) * (lpp == 1 ? 2 : 1) + nr1 + nr2;
   L.o_lm = (L.o_int + ((n_int + 1) >> 1) + 1) & ~1;
+  if (lpp == 1) {
+    // a row of c modes centred at k0 has max(k0, c - 1 - k0) < c pairs: the pair tables never hold more than one entry per mode
+    L.s_lm = L.s_amn = L.s_anq = 0; L.o_amn = L.o_anq = L.o_lm;
+    L.o_c0mn = L.o_lm;
+    L.o_c0nq = L.o_c0mn + 10 * nr1;
+    L.o_symn = L.o_c0nq + 10 * nr2;
+    L.total = L.o_symn + 32 * mnmax + 16 * mnmax_nyq + 64 * 16 * (nr1 > 12 ? 3 : 2);
+    return L;
+  }
   L.s_lm = 2 * (L.T1c + 1);
   L.o_amn = L.o_lm + lpp * L.s_lm;
   L.s_amn = 2 * (10 * L.T1c + 1);
   L.o_anq = L.o_amn + lpp * L.s_amn;
   L.s_anq = 2 * (10 * L.T2c + 1);
-  L.Tsc = mnmax < 64 ? mnmax : 64;
-  L.o_sy0 = L.o_anq + lpp * L.s_anq;
-  L.o_sym = L.o_sy0 + 2 * nr1 + 2;
-  L.total = L.o_sym + (lpp == 1 ? 2 * L.Tsc * nr1 : 0);
+  L.o_c0mn = L.o_c0nq = L.o_symn = 0;
+  L.total = L.o_anq + lpp * L.s_anq;
   return L;
 }
 int geo_lpp_index(int lpp) { return lpp == 1 ? 0 : (lpp == 2 ? 1 : (lpp == 4 ? 2 : 3)); }
@@ -263,43 +273,96 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
     I[10] = -1.0 * 2 * shat / sq * sgn;                   // gbdrift0 = I10 BxgB_psi / B^3
     I[11] = 2 * Bref * Lm * Lm * sq * mu0 * dp * sgn / etf;   // cvdrift = gbdrift - I11 / B^2
     I[12] = Lm * iota;                                    // gradpar = I12 B^phi / B
-    I[13] = (double)T1; I[14] = (double)T2;
-    if (lpp != 1) I[15] = -1.0;                             // (lpp == 1: set with the n-symmetric lists below)
+    if (lpp != 1) { I[13] = (double)T1; I[14] = (double)T2; I[15] = -1.0; I[16] = I[17] = 0.0; }
   }
-  // ---- lmns rows in n-symmetric form (one lane per point): with the row's n = n_c + t dn, t = -k0 .. cnt-1-k0 (n_c = 0
-  // whenever the row holds n = 0: VMEC's rows run n = -ntor .. ntor, or 0 .. ntor for m = 0),
-  //   sum_n l cos(n phi) = cos(n_c phi) A_c - sin(n_c phi) A_s,   sum_n l sin(n phi) = sin(n_c phi) A_c + cos(n_c phi) A_s,
-  //   A_c = l_0 + sum_{t>0} (l_t + l_-t) cos(t D),   A_s = sum_{t>0} (l_t - l_-t) sin(t D),   D = dn phi
-  // and cos / sin(t D) are the same for EVERY row: the (P_m, Q_m) pass of the root solve becomes one recurrence over t with
-  // two fma per row instead of four per mode
+  const double* g_mn = a.tab_mn + (size_t)js * 6 * a.mnmax;
+  const double* g_nq = a.tab_nyq + (size_t)js * 7 * a.mnmax_nyq;
+  const int n1 = a.mnmax, n2 = a.mnmax_nyq;
+  // ---- one lane per point: rows in n-symmetric form.  With the row's n = n_c + t dn, t = -k0 .. cnt-1-k0 (n_c = 0 whenever
+  // the row holds n = 0: VMEC's rows run n = -ntor .. ntor, or 0 .. ntor for m = 0), beta = m theta - n_c phi, D = dn phi:
+  //   sum_t v_t cos(beta - t D) = cos(beta) P + sin(beta) Q,    sum_t v_t sin(beta - t D) = sin(beta) P - cos(beta) Q,
+  //   P = v_0 + sum_{t>0} (v_t + v_-t) cos(t D),                Q = sum_{t>0} (v_t - v_-t) sin(t D)
+  // so a PAIR of modes costs one fma per accumulated quantity and point instead of two, cos / sin(t D) are the same for every
+  // row, and the (P_m, Q_m) of the root solve are the lmns column of the same tables.
   if (lpp == 1) {
-    __shared__ int k0_s[kGeoMaxRows], tmax_s, anync_s;
-    const double* lmn = a.tab_mn + (size_t)js * 6 * a.mnmax + 2 * (size_t)a.mnmax;
-    double* sy0 = I + L.o_sy0;
-    if (t == 0) { tmax_s = 0; anync_s = 0; }
+    __shared__ int k0_s[2][kGeoMaxRows], tm_s[2][kGeoMaxRows], so_s[2][kGeoMaxRows + 1], any_s[2], tmax_s;
+    if (t == 0) { any_s[0] = any_s[1] = 0; tmax_s = 0; }
     __syncthreads();
-    for (int r = t; r < nr1; r += blockDim.x) {
-      const double n0 = rn_s[0][r];
+    for (int e = t; e < nr1 + nr2; e += blockDim.x) {
+      const int w = e >= nr1 ? 1 : 0, r = w ? e - nr1 : e;
+      const int cnt = w ? cnt2[r] : cnt1[r];
+      const double dn = w ? a.dn_nyq : a.dn_mn, n0 = rn_s[w][r];
       int k0 = 0; double nc = n0;
-      const double kz = -n0 / a.dn_mn;
+      const double kz = -n0 / dn;
       const int kr = (int)(kz + (kz >= 0 ? 0.5 : -0.5));
-      if (kr >= 0 && kr < cnt1[r] && fabs(n0 + kr * a.dn_mn) <= 1e-9 * fabs(a.dn_mn)) { k0 = kr; nc = 0.0; }
-      k0_s[r] = k0;
-      sy0[2 * r] = lmn[a.rows_mn[2 * r] + k0]; sy0[2 * r + 1] = nc;
-      const int tm = k0 > cnt1[r] - 1 - k0 ? k0 : cnt1[r] - 1 - k0;
-      atomicMax(&tmax_s, tm);
-      if (nc != 0.0) atomicMax(&anync_s, 1);                  // some row is centred away from n = 0
+      if (kr >= 0 && kr < cnt && fabs(n0 + kr * dn) <= 1e-9 * fabs(dn)) { k0 = kr; nc = 0.0; }
+      k0_s[w][r] = k0;
+      const int tm = k0 > cnt - 1 - k0 ? k0 : cnt - 1 - k0;
+      tm_s[w][r] = tm;
+      (I + (w ? L.o_c0nq : L.o_c0mn))[10 * r + 9] = nc;
+      if (w) (I + L.o_c0nq)[10 * r + 8] = 0.0;
+      if (nc != 0.0) atomicMax(&any_s[w], 1);                  // some row is centred away from n = 0
+      if (!w) atomicMax(&tmax_s, tm);
     }
     __syncthreads();
-    const int any_nc = anync_s, Ts = tmax_s;
-    if (t == 0) { sy0[2 * nr1] = any_nc ? 1.0 : 0.0; I[15] = Ts <= L.Tsc ? (double)Ts : -1.0; }
-    double* sym = I + L.o_sym;
-    for (int e = t; e < L.Tsc * nr1; e += blockDim.x) {
-      const int tt = e / nr1 + 1, r = e - (tt - 1) * nr1;
-      const int k0 = k0_s[r], kp = k0 + tt, km = k0 - tt;
-      const double lp = kp < cnt1[r] ? lmn[a.rows_mn[2 * r] + kp] : 0.0, lq = km >= 0 ? lmn[a.rows_mn[2 * r] + km] : 0.0;
-      sym[2 * e] = lp + lq; sym[2 * e + 1] = lp - lq;
+    if (t < 2) {
+      const int nr = t ? nr2 : nr1;
+      int* isoff = code2 + nr2 + (t ? nr1 + 1 : 0);
+      double* ri = I + (t ? L.o_ri2 : L.o_ri1);
+      int o = 0;
+      for (int r = 0; r < nr; ++r) { so_s[t][r] = o; isoff[r] = o; ri[4 * r + 3] = tm_s[t][r]; o += tm_s[t][r]; }
+      so_s[t][nr] = o; isoff[nr] = o;
     }
+    __syncthreads();
+    const int S1 = so_s[0][nr1], S2 = so_s[1][nr2];
+    const int NB = nr1 > 12 ? 3 : 2, Ts = tmax_s;
+    const int o_synq = L.o_symn + 32 * S1, o_pq = o_synq + 16 * S2;
+    if (t == 0) {
+      I[13] = (double)(o_pq + 16 * NB * Ts); I[14] = (double)o_synq; I[15] = (double)Ts; I[16] = (double)any_s[0]; I[17] = (double)any_s[1];
+      I[18] = (double)o_pq;
+    }
+    // value of column c of mode k:  mn  rmnc d_rmnc n*rmnc | zmns d_zmns n*zmns | lmns d_lmns n*lmns
+    //                               nyq gmnc bmnc d_bmnc n*bmnc bsupv bsubs bsubu bsubv
+    auto val_mn = [&](int k, int c) {
+      const int fam = c / 3, kind = c - 3 * fam;
+      const double v = g_mn[(size_t)(kind == 1 ? 3 + fam : fam) * n1 + k];
+      return kind == 2 ? a.xn[k] * v : v;
+    };
+    auto val_nq = [&](int k, int c) {
+      const int pl = c <= 2 ? c : (c == 3 ? 1 : c - 1);
+      const double v = g_nq[(size_t)pl * n2 + k];
+      return c == 3 ? a.xn_nyq[k] * v : v;
+    };
+    for (int e = t; e < 9 * nr1; e += blockDim.x) { const int r = e / 9, c = e - 9 * r; (I + L.o_c0mn)[10 * r + c] = val_mn(a.rows_mn[2 * r] + k0_s[0][r], c); }
+    for (int e = t; e < 8 * nr2; e += blockDim.x) { const int r = e / 8, c = e - 8 * r; (I + L.o_c0nq)[10 * r + c] = val_nq(a.rows_nyq[2 * r] + k0_s[1][r], c); }
+    auto pair_row = [](int tt, int nr, const int* so) { int r = 0; while (r + 1 < nr && so[r + 1] <= tt) ++r; return r; };
+    double* symn = I + L.o_symn;
+    for (int e = t; e < 9 * S1; e += blockDim.x) {
+      const int tt = e / 9, c = e - 9 * tt, r = pair_row(tt, nr1, so_s[0]);
+      const int dt = tt - so_s[0][r] + 1, k0 = k0_s[0][r], kp = k0 + dt, km = k0 - dt, kb = a.rows_mn[2 * r];
+      const double vp = kp < cnt1[r] ? val_mn(kb + kp, c) : 0.0, vm = km >= 0 ? val_mn(kb + km, c) : 0.0;
+      symn[32 * tt + 2 * c] = vp + vm; symn[32 * tt + 2 * c + 1] = vp - vm;
+    }
+    double* synq = I + o_synq;
+    for (int e = t; e < 8 * S2; e += blockDim.x) {
+      const int tt = e >> 3, c = e & 7, r = pair_row(tt, nr2, so_s[1]);
+      const int dt = tt - so_s[1][r] + 1, k0 = k0_s[1][r], kp = k0 + dt, km = k0 - dt, kb = a.rows_nyq[2 * r];
+      const double vp = kp < cnt2[r] ? val_nq(kb + kp, c) : 0.0, vm = km >= 0 ? val_nq(kb + km, c) : 0.0;
+      synq[2 * e] = vp + vm; synq[2 * e + 1] = vp - vm;
+    }
+    double* pq = I + o_pq;
+    const double* lmn = g_mn + 2 * (size_t)n1;
+    for (int e = t; e < 8 * NB * Ts; e += blockDim.x) {           // (rows with fewer pairs, and the slots beyond the rows: zeros)
+      const int tt = e / (8 * NB), r = e - tt * 8 * NB;
+      double vp = 0.0, vm = 0.0;
+      if (r < nr1) {
+        const int k0 = k0_s[0][r], kp = k0 + tt + 1, km = k0 - tt - 1, kb = a.rows_mn[2 * r];
+        if (kp < cnt1[r]) vp = lmn[kb + kp];
+        if (km >= 0) vm = lmn[kb + km];
+      }
+      pq[16 * NB * tt + 2 * r] = vp + vm; pq[16 * NB * tt + 2 * r + 1] = vp - vm;
+    }
+    return;
   }
   auto row_of = [](int g, int nr, const int* goff) { int r = 0; while (r + 1 < nr && goff[r + 1] <= g) ++r; return r; };
   // source mode of slot u (0 | 1) of group g of lane sub, or -1 (padding)
@@ -309,9 +372,6 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
     const int i = (sub * gs + (g - goff[r])) * 2 + u;
     return i < cnt[r] ? rows[2 * r] + i : -1;
   };
-  const double* g_mn = a.tab_mn + (size_t)js * 6 * a.mnmax;
-  const double* g_nq = a.tab_nyq + (size_t)js * 7 * a.mnmax_nyq;
-  const int n1 = a.mnmax, n2 = a.mnmax_nyq;
   for (int e = t; e < lpp * T1 * 2; e += blockDim.x) {
     const int sub = e / (T1 * 2), rem = e - sub * T1 * 2, g = rem >> 1, u = rem & 1;
     const int k = src_mode(sub, g, u, nr1, goff1, cnt1, a.rows_mn);
@@ -520,6 +580,21 @@ __device__ __forceinline__ double geo_rcp(double x) {
   return fma(fma(-x, r, 1.0), r, r);
 }
 
+// acc += tab[lane K of this lane's 16-lane row] * x: the 64-bit DPP form of v_fmac_f64 (row_newbcast, the one DPP control the
+// FP64 pipe takes; full rate, tools/dpp64_probe.hip).  ONE ds_read_b64 -- every lane its (lane & 15)-th entry of a 16-double
+// block -- so feeds sixteen multiply-adds per point instead of one 16-byte broadcast read per two: the table reads leave the
+// LDS pipe (which a ds_read_b128 occupies as long as a v_fma_f64 occupies the FP64 pipe) and the 36 registers they landed in.
+// `tab` must come straight from the LDS read (a VALU write needs two wait states before a DPP read: the blocks are loaded a
+// whole step before they are used).
+template <int K>
+__device__ __forceinline__ void fmac_bc(double& acc, double tab, double x) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(K));
+}
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
+}
+
 // One wave-item: grid points [jfirst, jfirst + 64 PPL / LPP) of `line`, tables of its surface staged in LDS at I.
 template <int PPL, int LPP, int MAXR>
 __device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, const GeoImgLayout& L, int line, int jfirst) {
@@ -552,39 +627,57 @@ __device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, cons
   GEO_PROBE_AT(2);
   // ---- (P_m, Q_m) of the root solve
   double Pm[PPL][MAXR], Qm[PPL][MAXR];
-  const int Tsym = LPP == 1 ? __builtin_amdgcn_readfirstlane((int)I[15]) : -1;
-  if (LPP == 1 && Tsym >= 0) {
-    // n-symmetric rows (k_geo_prepare): one recurrence for cos / sin(t D), two fma per row and t
-    const double2* Sy = reinterpret_cast<const double2*>(I + L.o_sym);
-    const double* sy0 = I + L.o_sy0;
+  const int* soff1 = code2 + nr2; const int* soff2 = soff1 + nr1 + 1;         // (LPP = 1 images only)
+  if constexpr (LPP == 1) {
+    // n-symmetric rows (k_geo_prepare): one recurrence for cos / sin(t D), two multiply-adds per row and pair index, all rows'
+    // (sum, difference) of one pair index in NB blocks of sixteen
+    constexpr int NB = (2 * MAXR + 15) / 16;
+    const double* pq = I + __builtin_amdgcn_readfirstlane((int)I[18]);
+    const double* c0 = I + L.o_c0mn;
+    const int Tsym = __builtin_amdgcn_readfirstlane((int)I[15]);
+    const int l16 = lane & 15;
+    if (Tsym > 0) {
+      double cx[PPL], sx[PPL], cy[PPL], sy[PPL];
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r)
+      for (int r = 0; r < MAXR; ++r) {                                          // first pair: starts the sums (uniform reads)
+        const double2 u = *reinterpret_cast<const double2*>(pq + 2 * r);
+        const double l0 = r < nr1 ? c0[10 * (r < nr1 ? r : 0) + 6] : 0.0;
 #pragma unroll
-      for (int p = 0; p < PPL; ++p) { Pm[p][r] = r < nr1 ? sy0[2 * (r < nr1 ? r : 0)] : 0.0; Qm[p][r] = 0.0; }
-    double ct[PPL], st[PPL], ctm[PPL], stm[PPL];
-#pragma unroll
-    for (int p = 0; p < PPL; ++p) { ct[p] = cD[p]; st[p] = sD[p]; ctm[p] = 1.0; stm[p] = 0.0; }
-    for (int t = 0; t < Tsym; ++t) {
-      const double2* row = Sy + (size_t)t * nr1;
-#pragma unroll
-      for (int r = 0; r < MAXR; ++r) {
-        if (r < nr1) {
-          const double2 u = row[r];
-#pragma unroll
-          for (int p = 0; p < PPL; ++p) { Pm[p][r] = fma(u.x, ct[p], Pm[p][r]); Qm[p][r] = fma(u.y, st[p], Qm[p][r]); }
-        }
+        for (int p = 0; p < PPL; ++p) { Pm[p][r] = fma(u.x, cD[p], l0); Qm[p][r] = u.y * sD[p]; }
       }
 #pragma unroll
-      for (int p = 0; p < PPL; ++p) {
-        const double cn = fma(two_cD[p], ct[p], -ctm[p]), sn = fma(two_cD[p], st[p], -stm[p]);
-        ctm[p] = ct[p]; stm[p] = st[p]; ct[p] = cn; st[p] = sn;
+      for (int p = 0; p < PPL; ++p) { cx[p] = cD[p]; sx[p] = sD[p]; cy[p] = fma(two_cD[p], cD[p], -1.0); sy[p] = two_cD[p] * sD[p]; }
+      auto pq_step = [&](const double* blk, const double (&c_)[PPL], const double (&s_)[PPL]) {
+        double tb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) tb[b] = blk[16 * b + l16];
+        static_for<0, MAXR>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) { fmac_bc<(2 * r) & 15>(Pm[p][r], tb[(2 * r) >> 4], c_[p]); fmac_bc<(2 * r + 1) & 15>(Qm[p][r], tb[(2 * r) >> 4], s_[p]); }
+        });
+      };
+      int t = 1;
+      for (; t + 1 < Tsym; t += 2) {
+        pq_step(pq + 16 * NB * t, cy, sy);
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) { cx[p] = fma(two_cD[p], cy[p], -cx[p]); sx[p] = fma(two_cD[p], sy[p], -sx[p]); }
+        pq_step(pq + 16 * NB * (t + 1), cx, sx);
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) { cy[p] = fma(two_cD[p], cx[p], -cy[p]); sy[p] = fma(two_cD[p], sx[p], -sy[p]); }
       }
+      if (t < Tsym) pq_step(pq + 16 * NB * t, cy, sy);
+    } else {
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) { Pm[p][r] = r < nr1 ? c0[10 * (r < nr1 ? r : 0) + 6] : 0.0; Qm[p][r] = 0.0; }
     }
-    if (__builtin_amdgcn_readfirstlane((int)sy0[2 * nr1]) != 0) {             // rows centred away from n = 0 (not VMEC's)
+    if (__builtin_amdgcn_readfirstlane((int)I[16]) != 0) {                      // rows centred away from n = 0 (not VMEC's)
 #pragma unroll
       for (int r = 0; r < MAXR; ++r) {
         if (r < nr1) {
-          const double nc = sy0[2 * r + 1];
+          const double nc = c0[10 * r + 9];
 #pragma unroll
           for (int p = 0; p < PPL; ++p) {
             double sn, cn;
@@ -734,13 +827,111 @@ __device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, cons
       }
     }
   };
-  run_set(std::false_type{}, I + L.o_amn + (size_t)sub * L.s_amn, goff1, code1, ri1, nr1);
+  // one lane per point: a row's (P, Q) of every column by ONE recurrence over the pairs, then the row's cos / sin(beta)
+  // distribute them over the sums (k_geo_prepare)
+  auto run_sym = [&](auto is_nyq, const double* c0t, const double* tab, const int* soff, const int* code, const double* ri, int nr, bool any_nc) {
+    constexpr bool NYQ = decltype(is_nyq)::value;
+    constexpr int A = NYQ ? 8 : 9, W = NYQ ? 16 : 32;                           // columns; doubles per pair in the table
+    const int l16 = lane & 15;
+    rs.rewind();
+    for (int r = 0; r < nr; ++r) {
+      const int t0 = __builtin_amdgcn_readfirstlane(soff[r]), t1 = __builtin_amdgcn_readfirstlane(soff[r + 1]);
+      const double m_r = ri[4 * r];
+      rs.advance_m(__builtin_amdgcn_readfirstlane(code[r]) & 3, m_r);
+      const double* c0 = c0t + 10 * r;
+      // cos / sin(t D) live in two register sets that take turns (x = t, y = t + 1, then x <- 2 cos(D) y - x = t + 2, ...):
+      // no register moves in the loop
+      double P[PPL][A], Q[PPL][A], cx[PPL], sx[PPL], cy[PPL], sy[PPL];
+      auto pair_step = [&](const double* blk, const double (&c_)[PPL], const double (&s_)[PPL]) {
+        const double tb0 = blk[l16];
+        double tb1 = 0.0;
+        if constexpr (!NYQ) tb1 = blk[16 + l16];                               // (lanes 0, 1: column 8)
+        static_for<0, 8>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) { fmac_bc<2 * c>(P[p][c], tb0, c_[p]); fmac_bc<2 * c + 1>(Q[p][c], tb0, s_[p]); }
+        });
+        if constexpr (!NYQ) {
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) { fmac_bc<0>(P[p][A - 1], tb1, c_[p]); fmac_bc<1>(Q[p][A - 1], tb1, s_[p]); }
+        }
+      };
+      const double* q = tab + (size_t)W * t0;
+      if (t0 < t1) {                                                           // first pair: starts the sums (uniform reads)
+#pragma unroll
+        for (int c = 0; c < A; ++c) {
+          const double2 u = *reinterpret_cast<const double2*>(q + 2 * c);
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) { P[p][c] = fma(u.x, cD[p], c0[c]); Q[p][c] = u.y * sD[p]; }
+        }
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+          cx[p] = cD[p]; sx[p] = sD[p];
+          cy[p] = fma(two_cD[p], cD[p], -1.0); sy[p] = two_cD[p] * sD[p];         // t = 2
+        }
+        q += W;
+        int t = t0 + 1;
+        for (; t + 1 < t1; t += 2, q += 2 * W) {
+          pair_step(q, cy, sy);
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) { cx[p] = fma(two_cD[p], cy[p], -cx[p]); sx[p] = fma(two_cD[p], sy[p], -sx[p]); }
+          pair_step(q + W, cx, sx);
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) { cy[p] = fma(two_cD[p], cx[p], -cy[p]); sy[p] = fma(two_cD[p], sx[p], -sy[p]); }
+        }
+        if (t < t1) pair_step(q, cy, sy);
+      } else {
+#pragma unroll
+        for (int p = 0; p < PPL; ++p)
+#pragma unroll
+          for (int c = 0; c < A; ++c) { P[p][c] = c0[c]; Q[p][c] = 0.0; }
+      }
+      double cb[PPL], sb[PPL];
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) { cb[p] = rs.cm[p]; sb[p] = rs.sm[p]; }
+      if (any_nc) {                                                            // (block-uniform; not VMEC's rows)
+        const double nc = c0[9];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+          double sn, cn;
+          geo_sincos(nc * phi[p], &sn, &cn);
+          cb[p] = rs.cm[p] * cn + rs.sm[p] * sn; sb[p] = rs.sm[p] * cn - rs.cm[p] * sn;      // cos / sin(m tv - n_c phi)
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) {
+        GeoSums& X = S[p];
+        const double c_ = cb[p], s_ = sb[p], mc = m_r * c_, ms = m_r * s_;
+        auto Cs = [&](int c) { return fma(c_, P[p][c], s_ * Q[p][c]); };       // sum v cos(angle)
+        auto Sn = [&](int c) { return fma(s_, P[p][c], -(c_ * Q[p][c])); };    // sum v sin(angle)
+        if constexpr (!NYQ) {
+          X.R += Cs(0); X.R_s += Cs(1); X.R_t -= fma(ms, P[p][0], -(mc * Q[p][0])); X.R_p += Sn(2);
+          X.Z_s += Sn(4); X.Z_t += fma(mc, P[p][3], ms * Q[p][3]); X.Z_p -= Cs(5);
+          X.l_s += Sn(7); X.l_t += fma(mc, P[p][6], ms * Q[p][6]); X.l_p -= Cs(8);
+        } else {
+          X.sqg += Cs(0); X.modB += Cs(1); X.B_s += Cs(2); X.B_t -= fma(ms, P[p][1], -(mc * Q[p][1])); X.B_p += Sn(3);
+          X.Bsup_phi += Cs(4); X.Bsub_s += Sn(5); X.Bsub_t += Cs(6); X.Bsub_p += Cs(7);
+        }
+      }
+    }
+  };
+  if constexpr (LPP == 1) {
+    run_sym(std::false_type{}, I + L.o_c0mn, I + L.o_symn, soff1, code1, ri1, nr1,
+            __builtin_amdgcn_readfirstlane((int)I[16]) != 0);
+  } else {
+    run_set(std::false_type{}, I + L.o_amn + (size_t)sub * L.s_amn, goff1, code1, ri1, nr1);
+  }
   GEO_PROBE_AT(5);
   if (a.dn_nyq != a.dn_mn) {
 #pragma unroll
     for (int p = 0; p < PPL; ++p) { geo_sincos(a.dn_nyq * phi[p], &sD[p], &cD[p]); two_cD[p] = 2.0 * cD[p]; }
   }
-  run_set(std::true_type{}, I + L.o_anq + (size_t)sub * L.s_anq, goff2, code2, ri2, nr2);
+  if constexpr (LPP == 1) {
+    run_sym(std::true_type{}, I + L.o_c0nq, I + __builtin_amdgcn_readfirstlane((int)I[14]), soff2, code2, ri2, nr2,
+            __builtin_amdgcn_readfirstlane((int)I[17]) != 0);
+  } else {
+    run_set(std::true_type{}, I + L.o_anq + (size_t)sub * L.s_anq, goff2, code2, ri2, nr2);
+  }
   GEO_PROBE_AT(6);
   if constexpr (LPP > 1) {
     GeoSums& A = S[0];
@@ -793,7 +984,8 @@ __global__ void __launch_bounds__(kGeoBlock) k_geo_rows(GeoArgs a, const double*
       // straight copy of the prepared image, four 16-byte loads in flight per thread
       const double2* src = reinterpret_cast<const double2*>(img + (size_t)js * L.total);
       double2* dst = reinterpret_cast<double2*>(I);
-      const int n2 = L.total >> 1;                       // (L.total is even)
+      // (lengths are even; an LPP = 1 image is used up to its header slot 13)
+      const int n2 = (LPP == 1 ? __builtin_amdgcn_readfirstlane((int)img[(size_t)js * L.total + 13]) : L.total) >> 1;
       for (int k = threadIdx.x; k < n2; k += 4 * kGeoBlock) {
         double2 v[4];
 #pragma unroll
