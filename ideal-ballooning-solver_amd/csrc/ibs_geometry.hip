@@ -842,22 +842,26 @@ __device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, cons
       // cos / sin(t D) live in two register sets that take turns (x = t, y = t + 1, then x <- 2 cos(D) y - x = t + 2, ...):
       // no register moves in the loop
       double P[PPL][A], Q[PPL][A], cx[PPL], sx[PPL], cy[PPL], sy[PPL];
-      auto pair_step = [&](const double* blk, const double (&c_)[PPL], const double (&s_)[PPL]) {
-        const double tb0 = blk[l16];
-        double tb1 = 0.0;
-        if constexpr (!NYQ) tb1 = blk[16 + l16];                               // (lanes 0, 1: column 8)
+      // (a pair's table block is read while the pair before it is consumed: the read latency stays off the FP64 pipe's path)
+      auto load_blk = [&](const double* blk, double (&tb)[2]) {
+        tb[0] = blk[l16];
+        if constexpr (!NYQ) tb[1] = blk[16 + l16];                             // (lanes 0, 1: column 8)
+      };
+      auto pair_step = [&](const double (&tb)[2], const double (&c_)[PPL], const double (&s_)[PPL]) {
         static_for<0, 8>([&](auto cc) {
           constexpr int c = decltype(cc)::value;
 #pragma unroll
-          for (int p = 0; p < PPL; ++p) { fmac_bc<2 * c>(P[p][c], tb0, c_[p]); fmac_bc<2 * c + 1>(Q[p][c], tb0, s_[p]); }
+          for (int p = 0; p < PPL; ++p) { fmac_bc<2 * c>(P[p][c], tb[0], c_[p]); fmac_bc<2 * c + 1>(Q[p][c], tb[0], s_[p]); }
         });
         if constexpr (!NYQ) {
 #pragma unroll
-          for (int p = 0; p < PPL; ++p) { fmac_bc<0>(P[p][A - 1], tb1, c_[p]); fmac_bc<1>(Q[p][A - 1], tb1, s_[p]); }
+          for (int p = 0; p < PPL; ++p) { fmac_bc<0>(P[p][A - 1], tb[1], c_[p]); fmac_bc<1>(Q[p][A - 1], tb[1], s_[p]); }
         }
       };
       const double* q = tab + (size_t)W * t0;
       if (t0 < t1) {                                                           // first pair: starts the sums (uniform reads)
+        double ty[2], tx[2];
+        load_blk(q + W, ty);                                                   // (beyond a row's last pair: the next row's, unused)
 #pragma unroll
         for (int c = 0; c < A; ++c) {
           const double2 u = *reinterpret_cast<const double2*>(q + 2 * c);
@@ -872,14 +876,18 @@ __device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, cons
         q += W;
         int t = t0 + 1;
         for (; t + 1 < t1; t += 2, q += 2 * W) {
-          pair_step(q, cy, sy);
+          load_blk(q + W, tx);
+          __builtin_amdgcn_sched_barrier(0);                                   // (the scheduler would sink the read to its first use)
+          pair_step(ty, cy, sy);
 #pragma unroll
           for (int p = 0; p < PPL; ++p) { cx[p] = fma(two_cD[p], cy[p], -cx[p]); sx[p] = fma(two_cD[p], sy[p], -sx[p]); }
-          pair_step(q + W, cx, sx);
+          load_blk(q + 2 * W, ty);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_step(tx, cx, sx);
 #pragma unroll
           for (int p = 0; p < PPL; ++p) { cy[p] = fma(two_cD[p], cx[p], -cy[p]); sy[p] = fma(two_cD[p], sx[p], -sy[p]); }
         }
-        if (t < t1) pair_step(q, cy, sy);
+        if (t < t1) pair_step(ty, cy, sy);
       } else {
 #pragma unroll
         for (int p = 0; p < PPL; ++p)
@@ -973,34 +981,55 @@ __global__ void __launch_bounds__(kGeoBlock) k_geo_rows(GeoArgs a, const double*
   const long U = (long)n_lines * upl;
   const long u_begin = U * blockIdx.x / gridDim.x, u_end = U * (blockIdx.x + 1) / gridDim.x;
   const int wave = threadIdx.x >> 6;
+  __shared__ int claim;                                  // next unclaimed wave-item of the segment
   int cur = -1;
   GEO_PROBE_AT(0);
-  for (long u = u_begin; u < u_end; ++u) {
-    const int line = (int)(u / upl);
-    const int item = (int)(u - (long)line * upl) * WPB + wave;
-    const int js = min(max(__builtin_amdgcn_readfirstlane(a.line_surf[line]), 0), a.n_surf - 1);   // (device-resident indices are not range-checked by the C ABI)
-    if (js != cur) {                                     // (block-uniform)
-      __syncthreads();                                   // every wave is done with the staged image
+  auto surf_of = [&](long u) { return min(max(__builtin_amdgcn_readfirstlane(a.line_surf[(int)(u / upl)]), 0), a.n_surf - 1); };   // (device-resident indices are not range-checked by the C ABI)
+  for (long u = u_begin; u < u_end;) {
+    // segment: the units from u on that lie on one surface (block-uniform)
+    const int js = surf_of(u);
+    long v = u + 1;
+    while (v < u_end && surf_of(v) == js) ++v;
+    __syncthreads();                                     // every wave is done with the staged image and with the claim counter
+    if (threadIdx.x == 0) claim = 0;
+    if (js != cur) {
       // straight copy of the prepared image, four 16-byte loads in flight per thread
       const double2* src = reinterpret_cast<const double2*>(img + (size_t)js * L.total);
       double2* dst = reinterpret_cast<double2*>(I);
       // (lengths are even; an LPP = 1 image is used up to its header slot 13)
       const int n2 = (LPP == 1 ? __builtin_amdgcn_readfirstlane((int)img[(size_t)js * L.total + 13]) : L.total) >> 1;
       for (int k = threadIdx.x; k < n2; k += 4 * kGeoBlock) {
-        double2 v[4];
+        double2 v4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int kk = k + q * kGeoBlock; v[q] = kk < n2 ? src[kk] : double2{0.0, 0.0}; }
+        for (int q = 0; q < 4; ++q) { const int kk = k + q * kGeoBlock; v4[q] = kk < n2 ? src[kk] : double2{0.0, 0.0}; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int kk = k + q * kGeoBlock; if (kk < n2) dst[kk] = v[q]; }
+        for (int q = 0; q < 4; ++q) { const int kk = k + q * kGeoBlock; if (kk < n2) dst[kk] = v4[q]; }
       }
       cur = js;
-      __syncthreads();
     }
-    if (item < ipl) {
-      GEO_PROBE_AT(1);
-      geo_item<PPL, LPP, MAXR>(a, I, L, line, item * PTS);
+    __syncthreads();
+    // The waves CLAIM their items: the older wave of each SIMD, which the issue arbiter favours whatever s_setprio says, gets
+    // through an item in ~0.65 of its mate's time; with a fixed item per wave and unit it sat at the next re-staging barrier
+    // (or had left the kernel) while the mate finished alone at the lone-wave issue rate.
+    const int n_items = (int)(v - u) * WPB;
+    for (;;) {
+      int k = 0;
+      if ((threadIdx.x & 63) == 0) k = atomicAdd(&claim, 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (k >= n_items) break;
+      const long uu = u + k / WPB;
+      const int line = (int)(uu / upl);
+      const int item = (int)(uu - (long)line * upl) * WPB + (k % WPB);
+      if (item < ipl) {
+        GEO_PROBE_AT(1);
+        geo_item<PPL, LPP, MAXR>(a, I, L, line, item * PTS);
+      }
     }
+    u = v;
   }
+#ifdef GEO_PROBE
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && wave < 8) geo_probe_buf[blockIdx.x * 16 + 8 + wave] = wall_clock64();   // when each wave is done
+#endif
 }
 
 // ---- one grid point per WAVE: the few points a line has beyond a multiple of the block's 512 ---------------------

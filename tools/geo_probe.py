@@ -32,4 +32,6 @@ for ns, na, N, lpp in ((5, 3, 969, 8), (5, 3, 969, 4), (73, 3, 969, 1), (64, 32,
     ok = buf[:, 0] > 0
     print("   blocks probed %d: block start skew us min/median/max %.2f %.2f %.2f ; block end min/median/max %.2f %.2f %.2f" % (
         ok.sum(), st[ok].min(), np.median(st[ok]), st[ok].max(), en[ok].min(), np.median(en[ok]), en[ok].max()))
+    ends = (buf[ok, 8:16] - buf[ok, 0:1]) * 0.01
+    print("   waves 0..7 done at (us after block start, median over blocks): " + " ".join("%.1f" % np.median(ends[:, w]) for w in range(8)))
     print("   total item       %7.2f ; block span (start -> end of last item) median %.2f" % (np.median(d[:, 1:].sum(axis=1)), np.median((buf[:64, 7] - buf[:64, 0]) * 0.01)))
