@@ -910,15 +910,15 @@ __device__ __forceinline__ void geo_item(const GeoArgs& a, const double* I, cons
       for (int p = 0; p < PPL; ++p) {
         GeoSums& X = S[p];
         const double c_ = cb[p], s_ = sb[p], mc = m_r * c_, ms = m_r * s_;
-        auto Cs = [&](int c) { return fma(c_, P[p][c], s_ * Q[p][c]); };       // sum v cos(angle)
-        auto Sn = [&](int c) { return fma(s_, P[p][c], -(c_ * Q[p][c])); };    // sum v sin(angle)
+        // acc +- (x P + y Q): two multiply-adds per sum
+        auto add = [&](double& acc, double x, double y, int c) { acc = fma(x, P[p][c], fma(y, Q[p][c], acc)); };
         if constexpr (!NYQ) {
-          X.R += Cs(0); X.R_s += Cs(1); X.R_t -= fma(ms, P[p][0], -(mc * Q[p][0])); X.R_p += Sn(2);
-          X.Z_s += Sn(4); X.Z_t += fma(mc, P[p][3], ms * Q[p][3]); X.Z_p -= Cs(5);
-          X.l_s += Sn(7); X.l_t += fma(mc, P[p][6], ms * Q[p][6]); X.l_p -= Cs(8);
+          add(X.R, c_, s_, 0); add(X.R_s, c_, s_, 1); add(X.R_t, -ms, mc, 0); add(X.R_p, s_, -c_, 2);         // sum v cos = c P + s Q, sum v sin = s P - c Q
+          add(X.Z_s, s_, -c_, 4); add(X.Z_t, mc, ms, 3); add(X.Z_p, -c_, -s_, 5);
+          add(X.l_s, s_, -c_, 7); add(X.l_t, mc, ms, 6); add(X.l_p, -c_, -s_, 8);
         } else {
-          X.sqg += Cs(0); X.modB += Cs(1); X.B_s += Cs(2); X.B_t -= fma(ms, P[p][1], -(mc * Q[p][1])); X.B_p += Sn(3);
-          X.Bsup_phi += Cs(4); X.Bsub_s += Sn(5); X.Bsub_t += Cs(6); X.Bsub_p += Cs(7);
+          add(X.sqg, c_, s_, 0); add(X.modB, c_, s_, 1); add(X.B_s, c_, s_, 2); add(X.B_t, -ms, mc, 1); add(X.B_p, s_, -c_, 3);
+          add(X.Bsup_phi, c_, s_, 4); add(X.Bsub_s, s_, -c_, 5); add(X.Bsub_t, c_, s_, 6); add(X.Bsub_p, c_, s_, 7);
         }
       }
     }
