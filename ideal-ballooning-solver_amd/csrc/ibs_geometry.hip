@@ -1128,17 +1128,19 @@ __global__ void __launch_bounds__(256) k_line_dPdrho(int n_lines, int N, long ld
   if (threadIdx.x == 0) dPdrho[line] = -0.5 * (part[0] + part[1] + part[2] + part[3]) / N;
 }
 
-// Which form serves a batch of n_lines x N grid points on a chip of n_cu CUs: the persistent kernel has 8 n_cu wave
-// slots (two waves per SIMD), and the form is the cheapest per point that still fills them.
+// Which form serves a batch of n_lines x N grid points on a chip of n_cu CUs: the persistent kernel has 8 n_cu wave slots
+// (two waves per SIMD); the forms with more points per wave-item cost less per point (one lane per point: rows in n-symmetric
+// form fed by DPP broadcasts), so the choice is the SMALLEST item that still gives no wave slot a second item
+// (tools/geo_form_sweep.py: 30 / 54 / 84 / 201 lines of 969 points -> 4 / 2 / 1 lanes per point / two points per lane).
 //   lpp_opt: 0 = by batch size, 1 | 2 | 4 | 8 = lanes per point, -2 = two points per lane.
 GeoForm geo_pick_form(long n_lines, int N, int n_cu, int lpp_opt) {
   if (lpp_opt == -2) return GeoForm{2, 1};
   if (lpp_opt == 1 || lpp_opt == 2 || lpp_opt == 4 || lpp_opt == 8) return GeoForm{1, lpp_opt};
   const long pts = n_lines * (long)N, slots = 8L * n_cu;
-  if (pts >= slots * 128) return GeoForm{2, 1};
-  if (pts >= slots * 64) return GeoForm{1, 1};
-  if (pts >= slots * 32) return GeoForm{1, 2};
-  if (pts >= slots * 16) return GeoForm{1, 4};
+  if (pts > slots * 64) return GeoForm{2, 1};
+  if (pts > slots * 32) return GeoForm{1, 1};
+  if (pts > slots * 16) return GeoForm{1, 2};
+  if (pts > slots * 8) return GeoForm{1, 4};
   return GeoForm{1, 8};
 }
 bool geo_rows_usable(const GeoArgs& a, int lpp) {
