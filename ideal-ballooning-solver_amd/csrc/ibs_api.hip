@@ -1165,7 +1165,7 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   if (!eval) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   // LDS of the evaluation kernel: centre line (7 derived arrays) + eigenfunction + alpha-tangent (4 arrays) when they fit
   const size_t row_b = (size_t)ibs::lds_pitch(N) * sizeof(double);
-  const size_t lds_extra = 32 * sizeof(double) + sizeof(RefineState);
+  const size_t lds_extra = 32 * sizeof(double) + sizeof(RefineState) + sizeof(ibs::lbfgsb2::Work);
   // The alpha-tangent (4 more rows) in LDS saves the evaluation's sums a second trip to global memory but leaves room for ONE
   // block per CU at N = 969 (105 of 160 KB); without it two fit (70 KB each).  Batches with more points than CUs take the
   // second form: their first rounds would otherwise run in two waves of blocks.

@@ -1046,6 +1046,7 @@ __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
   T* s_red = smem + (size_t)(a.lds_tangent ? 12 : 8) * P;       // [4 waves][8] partial sums
   double* s_state = s_red + 32;
   constexpr int kStateWords = (int)(sizeof(RefineState) / 8);
+  lbfgsb2::Work* s_work = reinterpret_cast<lbfgsb2::Work*>(s_state + kStateWords);   // the optimizer step's run-time-indexed arrays
   const int k = a.idx[slot];
   const T th0 = a.th0[slot], two_th0 = T(2) * th0, th0sq = th0 * th0;
   const T inv_da = T(1) / a.prm.del_alpha;
@@ -1188,7 +1189,7 @@ __global__ void __launch_bounds__(256) k_refine_eval(RefineEvalArgs<T> a) {
     S.have = bad ? 0 : 1;
     S.sweeps += inf.iters;
     S.nev++;
-    S.active = lbfgsb2::step(S.q, val, g) ? 1 : 0;
+    S.active = lbfgsb2::step(S.q, val, g, *s_work) ? 1 : 0;
   }
   IBS_PROBE_AT(6);
   wave_lds_sync();
@@ -1495,7 +1496,7 @@ static hipError_t launch_grad(const GradArgs<T>& a, hipStream_t st) {
 
 template <typename T>
 static hipError_t launch_refine_eval(const RefineEvalArgs<T>& a, hipStream_t st) {
-  const size_t lds = (size_t)(a.lds_tangent ? 12 : 8) * lds_pitch(a.N) * sizeof(T) + 32 * sizeof(T) + sizeof(RefineState);
+  const size_t lds = (size_t)(a.lds_tangent ? 12 : 8) * lds_pitch(a.N) * sizeof(T) + 32 * sizeof(T) + sizeof(RefineState) + sizeof(lbfgsb2::Work);
   auto kern = k_refine_eval<T, IBS_M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -70,6 +70,13 @@ struct State {
   double ls_ginit, ls_gtest, ls_gx, ls_gy, ls_finit, ls_fx, ls_fy, ls_stx, ls_sty, ls_stmin, ls_stmax, ls_width, ls_width1;
 };
 
+// Work arrays of one step (indexed by run-time values: as locals of a GPU kernel they would live in scratch memory; the
+// refinement kernel hands in a piece of LDS)
+struct Work {
+  double d[2], tb[2], ot[2], zc[2], dold[2], rr[2], xp[2];
+  int iorder[2], oidx[2], ind[2];
+};
+
 IBS_HD double dmax(double a, double b) { return a > b ? a : b; }
 IBS_HD double dmin(double a, double b) { return a < b ? a : b; }
 IBS_HD double dabs(double a) { return a < 0 ? -a : a; }
@@ -108,13 +115,13 @@ IBS_HD double projgr(const State& s) {
 
 // ------------------------------------------------------------------ cauchy: generalized Cauchy point -> s.z
 // (piecewise-linear path x(t) = P(x - t g); the first local minimiser of the quadratic model along it)
-IBS_HD void cauchy(State& s) {
+IBS_HD void cauchy(State& s, Work& w) {
   if (s.sbgnrm <= 0.0) { s.z[0] = s.x[0]; s.z[1] = s.x[1]; return; }
   bool bnded = true;
   int nbreak = 0, ibkmin = 0, nfree_cnt = 0;
   double bkmin = 0.0, f1 = 0.0;
-  double d[2], tb[2] = {0.0, 0.0};
-  int iorder[2] = {0, 0};
+  double* d = w.d; double* tb = w.tb; int* iorder = w.iorder;
+  tb[0] = tb[1] = 0.0; iorder[0] = iorder[1] = 0;
   for (int i = 0; i < 2; ++i) {
     const double neggi = -s.g[i];
     double tl = 0.0, tu = 0.0;
@@ -160,11 +167,12 @@ IBS_HD void cauchy(State& s) {
     int nleft = nbreak, it = 1;
     double tj = 0.0;
     // breakpoints in ascending order (two at most)
-    int order_idx[2]; double order_t[2];
+    int* order_idx = w.oidx; double* order_t = w.ot;
     order_idx[0] = iorder[ibkmin]; order_t[0] = bkmin;
     if (nbreak == 2) { const int o = 1 - ibkmin; order_idx[1] = iorder[o]; order_t[1] = tb[o]; }
     bool all_fixed = false;
-    double zc[2] = {0.0, 0.0};                 // path displacement x(t_j) - x, accumulated segment by segment (the c of cauchy)
+    double* zc = w.zc;                         // path displacement x(t_j) - x, accumulated segment by segment (the c of cauchy)
+    zc[0] = zc[1] = 0.0;
     while (true) {
       const double tj0 = tj;
       tj = order_t[it - 1];
@@ -173,7 +181,8 @@ IBS_HD void cauchy(State& s) {
       if (dtm < dt) break;                     // the minimiser lies inside this segment
       tsum += dt; --nleft; ++it;
       const double dibp = d[ibp];
-      const double d_old[2] = {d[0], d[1]};
+      double* d_old = w.dold;
+      d_old[0] = d[0]; d_old[1] = d[1];
       d[ibp] = 0.0;
       double zibp;
       if (dibp > 0.0) { zibp = s.u[ibp] - s.x[ibp]; s.z[ibp] = s.u[ibp]; s.iwhere[ibp] = 2; }
@@ -208,14 +217,16 @@ IBS_HD void cauchy(State& s) {
 
 // ------------------------------------------------------------------ subsm: subspace minimisation over the free variables
 // at the Cauchy point, with the projection / backtracking step of L-BFGS-B 3.0.  s.z: in = xcp, out = the new point
-IBS_HD void subsm(State& s) {
-  int ind[2], nsub = 0;
+IBS_HD void subsm(State& s, Work& w) {
+  int* ind = w.ind; int nsub = 0;
   for (int i = 0; i < 2; ++i) if (s.iwhere[i] <= 0) ind[nsub++] = i;
   if (nsub == 0 || s.col == 0) return;
   // r = -Z'(g + B (xcp - x))
   const double dz0 = s.z[0] - s.x[0], dz1 = s.z[1] - s.x[1];
-  const double rr[2] = {-(s.g[0] + s.B[0][0] * dz0 + s.B[0][1] * dz1), -(s.g[1] + s.B[1][0] * dz0 + s.B[1][1] * dz1)};
-  double d[2] = {0.0, 0.0};                  // Newton direction in the free subspace (indexed like ind)
+  double* rr = w.rr;
+  rr[0] = -(s.g[0] + s.B[0][0] * dz0 + s.B[0][1] * dz1); rr[1] = -(s.g[1] + s.B[1][0] * dz0 + s.B[1][1] * dz1);
+  double* d = w.d;                           // Newton direction in the free subspace (indexed like ind)
+  d[0] = d[1] = 0.0;
   if (nsub == 2) {
     const double det = s.B[0][0] * s.B[1][1] - s.B[0][1] * s.B[1][0];
     d[0] = (s.B[1][1] * rr[0] - s.B[0][1] * rr[1]) / det;
@@ -224,7 +235,8 @@ IBS_HD void subsm(State& s) {
     d[0] = rr[ind[0]] / s.B[ind[0]][ind[0]];
   }
   // try the projection of xcp + d onto the box
-  const double xp[2] = {s.z[0], s.z[1]};
+  double* xp = w.xp;
+  xp[0] = s.z[0]; xp[1] = s.z[1];
   bool hit = false;
   for (int i = 0; i < nsub; ++i) {
     const int k = ind[i];
@@ -325,11 +337,13 @@ IBS_HD void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy,
     } else if (stp > stx) stpf = stpmax;
     else stpf = stpmin;
   }
-  if (fp > fx) { sty = stp; fy = fp; dy = dp; }
-  else {
-    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-    stx = stp; fx = fp; dx = dp;
-  }
+  // the interval that contains a minimiser: (fp > fx) y <- trial;  else { (sgnd < 0) y <- x; }  x <- trial.  Written as
+  // selects on the VALUES: conditional stores through the reference arguments become one store through a selected address,
+  // which keeps the caller's copies in memory (a GPU kernel's scratch)
+  const bool up = fp > fx, sw = !up && sgnd < 0.0;
+  const double nsty = up ? stp : (sw ? stx : sty), nfy = up ? fp : (sw ? fx : fy), ndy = up ? dp : (sw ? dx : dy);
+  const double nstx = up ? stx : stp, nfx = up ? fx : fp, ndx = up ? dx : dp;
+  stx = nstx; fx = nfx; dx = ndx; sty = nsty; fy = nfy; dy = ndy;
   stp = stpf;
 }
 
@@ -357,16 +371,17 @@ IBS_HD void dcsrch(State& s, double f, double g, double stpmin, double stpmax) {
   if (s.stp == stpmin && (f > ftest || g >= s.ls_gtest)) task = 3;                // stp = stpmin
   if (f <= ftest && dabs(g) <= gtol * (-s.ls_ginit)) task = 2;                    // convergence
   if (task != 1) { s.ls_task = task; return; }
-  if (s.ls_stage == 1 && f <= s.ls_fx && f > ftest) {
-    const double fm = f - s.stp * s.ls_gtest, gm = g - s.ls_gtest;
-    double fxm = s.ls_fx - s.ls_stx * s.ls_gtest, fym = s.ls_fy - s.ls_sty * s.ls_gtest;
-    double gxm = s.ls_gx - s.ls_gtest, gym = s.ls_gy - s.ls_gtest;
-    dcstep(s.ls_stx, fxm, gxm, s.ls_sty, fym, gym, s.stp, fm, gm, s.ls_brackt, s.ls_stmin, s.ls_stmax);
-    s.ls_fx = fxm + s.ls_stx * s.ls_gtest; s.ls_fy = fym + s.ls_sty * s.ls_gtest;
-    s.ls_gx = gxm + s.ls_gtest; s.ls_gy = gym + s.ls_gtest;
-  } else {
-    dcstep(s.ls_stx, s.ls_fx, s.ls_gx, s.ls_sty, s.ls_fy, s.ls_gy, s.stp, f, g, s.ls_brackt, s.ls_stmin, s.ls_stmax);
-  }
+  // (ONE call of dcstep on local copies: two calls, one on locals and one on the state's fields, merge into one body that
+  // reaches its operands through pointers, which puts the locals into a GPU kernel's scratch memory.  With shift = 0 the
+  // arithmetic below returns its operands bit for bit.)
+  const bool modified = s.ls_stage == 1 && f <= s.ls_fx && f > ftest;
+  const double shift = modified ? s.ls_gtest : 0.0;                          // the modified function f - stp gtest
+  double fxm = s.ls_fx - s.ls_stx * shift, fym = s.ls_fy - s.ls_sty * shift, gxm = s.ls_gx - shift, gym = s.ls_gy - shift;
+  double stx = s.ls_stx, sty = s.ls_sty, stp = s.stp;
+  int brackt = s.ls_brackt;
+  dcstep(stx, fxm, gxm, sty, fym, gym, stp, f - s.stp * shift, g - shift, brackt, s.ls_stmin, s.ls_stmax);
+  s.ls_fx = fxm + stx * shift; s.ls_fy = fym + sty * shift; s.ls_gx = gxm + shift; s.ls_gy = gym + shift;    // (shift = 0: the values themselves)
+  s.ls_stx = stx; s.ls_sty = sty; s.stp = stp; s.ls_brackt = brackt;
   if (s.ls_brackt) {
     if (dabs(s.ls_sty - s.ls_stx) >= 0.66 * s.ls_width1) s.stp = s.ls_stx + 0.5 * (s.ls_sty - s.ls_stx);
     s.ls_width1 = s.ls_width;
@@ -455,7 +470,7 @@ IBS_HD bool finished(const State& s) { return s.task >= T_CONV_PG; }
 
 // Advance with (f, g) evaluated at s.x.  Returns true when another evaluation at the (new) s.x is wanted,
 // false when the minimisation has ended (s.x, s.f = result; s.task says why).
-IBS_HD bool step(State& s, double f, const double* g) {
+IBS_HD bool step(State& s, double f, const double* g, Work& w) {
   if (finished(s)) return false;
   s.f = f; s.g[0] = g[0]; s.g[1] = g[1];
   bool new_search = false;
@@ -468,8 +483,8 @@ IBS_HD bool step(State& s, double f, const double* g) {
   while (true) {
     if (new_search) {
       // ---- 222: generalized Cauchy point, subspace minimisation, direction
-      cauchy(s);
-      subsm(s);
+      cauchy(s, w);
+      subsm(s, w);
       s.d[0] = s.z[0] - s.x[0]; s.d[1] = s.z[1] - s.x[1];
     }
     // ---- 666: line search
@@ -522,6 +537,10 @@ IBS_HD bool step(State& s, double f, const double* g) {
     }
     new_search = true;
   }
+}
+IBS_HD bool step(State& s, double f, const double* g) {
+  Work w;
+  return step(s, f, g, w);
 }
 
 }  // namespace lbfgsb2
