@@ -976,7 +976,7 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
   a.lpp = ctx->opt.geo_lpp;
   const bool rows = nrows_mn > 0 && nrows_nyq > 0;
   if (rows) { a.nrows_mn = nrows_mn; a.nrows_nyq = nrows_nyq; a.dn_mn = dn_mn; a.dn_nyq = dn_nyq; }
-  a.form = ibs::geo_pick_form(n_lines, N, ctx->n_cu, a.lpp);
+  a.form = ibs::geo_pick_usable(a, n_lines, N, ctx->n_cu);
   const size_t img_bytes = geo_img_bytes(a, a.form.lpp);
   if (mem == IBS_MEM_HOST) {
     for (int i = 0; i < n_lines; ++i)
@@ -1200,8 +1200,8 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   size_t need = pad256(n_geo * 8) + pad256((size_t)n_lines * 4) + pad256((size_t)n_lines * 8) + 10 * pad256((size_t)n_pts * 16) +
                 pad256((size_t)n_pts * sizeof(RefineState)) + pad256((size_t)N * 8) + 8192;
   // the lanes-per-point forms the rounds can take as the batch shrinks (geo_pick_form is monotone in the batch size)
-  const int lpp_first = ibs::geo_pick_form(n_lines, N, ctx->n_cu, ga.lpp).lpp;
-  const int lpp_last = ibs::geo_pick_form(3, N, ctx->n_cu, ga.lpp).lpp;
+  const int lpp_first = ibs::geo_pick_usable(ga, n_lines, N, ctx->n_cu).lpp;
+  const int lpp_last = ibs::geo_pick_usable(ga, 3, N, ctx->n_cu).lpp;
   for (int lpp = lpp_first; lpp <= lpp_last; lpp *= 2) need += geo_img_bytes(ga, lpp) + 256;
   if (host) need += pad256(n_mn * 8) + pad256(n_nyq * 8) + 2 * pad256((size_t)mnmax * 8) + 2 * pad256((size_t)mnmax_nyq * 8) +
                     pad256((size_t)n_surf * 48) + pad256((size_t)nrows_mn * 8) + pad256((size_t)nrows_nyq * 8) + 4096;
@@ -1284,7 +1284,7 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
     const int nc = hist[need_r] - 1;
     if (nc <= 0) { rounds = need_r; break; }
     ga.n_lines = 3 * nc;
-    ga.form = ibs::geo_pick_form(ga.n_lines, N, ctx->n_cu, ga.lpp);
+    ga.form = ibs::geo_pick_usable(ga, ga.n_lines, N, ctx->n_cu);
     HIPCHK(ibs::launch_geometry(ga, st, ctx->n_cu));
     ea.n_c_max = nc;
     HIPCHK(eval(ea, st));

@@ -1149,11 +1149,20 @@ bool geo_rows_usable(const GeoArgs& a, int lpp) {
   return geo_image_doubles(a, lpp) * sizeof(double) <= 150 * 1024;
 }
 
-// a.form (set by the caller through geo_pick_form, or {0, 0} = pick here), a.img[geo_lpp_index(lpp)] = room for
+// The form for a.n_lines-like batches of THESE tables: an image in the one-lane-per-point layout is sized for the worst case (one
+// pair per mode), so big mode sets (W7-X-like: ~400 + ~600 modes) do not fit the LDS there; they run with two (four, eight)
+// lanes per point, whose per-lane lists are half (...) as long, before anything falls back to the one-sincos-per-mode kernel.
+GeoForm geo_pick_usable(const GeoArgs& a, long n_lines, int N, int n_cu) {
+  GeoForm f = geo_pick_form(n_lines, N, n_cu, a.lpp);
+  while (f.lpp < 8 && !geo_rows_usable(a, f.lpp)) f = GeoForm{1, f.lpp * 2};
+  return f;
+}
+
+// a.form (set by the caller through geo_pick_usable, or {0, 0} = pick here), a.img[geo_lpp_index(lpp)] = room for
 // n_surf * geo_image_doubles(a, lpp) doubles, a.img_ready = bit per image already built from these tables (updated).
 hipError_t launch_geometry(GeoArgs& a, hipStream_t st, int n_cu) {
   GeoForm f = a.form;
-  if (f.ppl == 0) f = geo_pick_form(a.n_lines, a.N, n_cu, a.lpp);
+  if (f.ppl == 0) f = geo_pick_usable(a, a.n_lines, a.N, n_cu);
   const size_t plane = a.plane ? a.plane : (size_t)a.n_lines * a.ld;
   a.plane = plane;
   const int li = geo_lpp_index(f.lpp);

@@ -75,6 +75,7 @@ struct GeoArgs {
                            // only their images (a caller that works through a large table set piece by piece: AdjointStep)
 };
 GeoForm geo_pick_form(long n_lines, int N, int n_cu, int lpp_opt);
+GeoForm geo_pick_usable(const GeoArgs& a, long n_lines, int N, int n_cu);      // ... among the forms whose table image fits the LDS
 int geo_lpp_index(int lpp);
 size_t geo_image_doubles(const GeoArgs& a, int lpp);      // per surface
 bool geo_rows_usable(const GeoArgs& a, int lpp);

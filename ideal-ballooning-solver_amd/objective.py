@@ -71,7 +71,7 @@ class AdjointStep:
     (dof_steps / ScanConfig.dof_step)."""
 
     def __init__(self, ctx, theta, svals, device, nalpha=24, ntheta0=15, del_alpha=0.004, gamma_thresh=-2.0e-4, prefac=50.0,
-                 rank=0, world=1, dist=None, n_threads=0, n_chunks=4, gather_device=None):
+                 rank=0, world=1, dist=None, n_threads=0, n_chunks=4, gather_device=None, chunk_growth=1.0):
         self.ctx, self.device = ctx, device
         self.theta = np.asarray(theta, dtype=np.float64)
         self.svals = np.atleast_1d(np.asarray(svals, dtype=np.float64))       # ball_scan.py:197
@@ -82,6 +82,9 @@ class AdjointStep:
         # of run k + 1 while the GPU scans run k -- of the 2.2 ms the radial step of 73 equilibria takes, the first run's share
         # is all that stays exposed
         self.n_chunks = max(1, int(n_chunks))
+        # (chunk_growth > 1: run k + 1 holds that many times the equilibria of run k -- a short first run exposes less host time;
+        # the host must still finish run k + 1's tables while the GPU works on run k)
+        self.chunk_growth = float(chunk_growth)
         self.gather_device = gather_device        # None: the rows are gathered where they are (RCCL); "cpu": through host copies (gloo)
         self._scan = None
         self._frame = None
@@ -118,7 +121,9 @@ class AdjointStep:
                     self._scan = None
                 scan = self._scan_for(fr, len(own))
                 nch = min(self.n_chunks, len(own))
-                cuts = [len(own) * k // nch for k in range(nch + 1)]
+                wts = np.cumsum([0.0] + [self.chunk_growth ** k for k in range(nch)])
+                cuts = [int(round(len(own) * w / wts[-1])) for w in wts]
+                cuts = sorted(set(cuts)); nch = len(cuts) - 1
 
                 def fill(c0, c1):          # (owned-surface range -> equilibria range: chunks are cut at equilibrium boundaries)
                     q0, q1 = c0 // ns, c1 // ns

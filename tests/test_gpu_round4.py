@@ -175,3 +175,49 @@ def test_adjoint_step_configs3_end_to_end(ctx):
     assert abs(out["fobj"] - np.sqrt(f0_arr[0])) < 1e-15
     print("configs[3] as one AdjointStep: phases %s; worst |gam - oracle| of the sample %.2e" % (
         {k: round(v, 3) for k, v in ph.items()}, worst))
+
+
+def test_geometry_on_a_mode_set_too_big_for_the_one_lane_per_point_image(ctx):
+    """F1 on tables with 2.2x NCSX's modes (12 rows of 47 + 14 rows of 51: the size of a W7-X-like run): the image of the
+    one-lane-per-point forms is sized for one pair per mode and does not fit the LDS there, so every batch size must run on the
+    lanes-per-point forms (NOT on the one-sincos-per-mode kernel) and agree with the numpy oracle (utils.py:359-720 restated).
+    The extra modes carry small coefficients (a data manipulation for shape coverage: both sides evaluate the same formulas)."""
+    import torch
+    import ibs_amd
+    from oracle import geometry_oracle as go
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    nfp = int(np.min(np.abs(wout["xn"][wout["xn"] != 0])))
+    rng = np.random.default_rng(11)
+    w = dict(wout)
+
+    def widen(xm, xn, names, nmax):
+        have = set(zip(xm.astype(int).tolist(), xn.astype(int).tolist()))
+        extra = [(m, n * nfp) for m in range(int(xm.max()) + 1) for n in range(-nmax, nmax + 1)
+                 if (m > 0 or n >= 0) and (m, n * nfp) not in have]
+        em = np.array([e[0] for e in extra], dtype=float); en = np.array([e[1] for e in extra], dtype=float)
+        order = np.lexsort((np.concatenate([xn, en]), np.concatenate([xm, em])))           # VMEC order: m, then n
+        prof = np.linspace(0, 1, wout[names[0]].shape[1]) ** 2
+        for k in names:
+            scale = 1e-4 * np.abs(wout[k]).max()
+            add = scale * rng.standard_normal((len(extra), 1)) * prof[None, :] / (1.0 + np.abs(en[:, None]) / nfp)
+            w[k] = np.concatenate([wout[k], add])[order]
+        return np.concatenate([xm, em])[order], np.concatenate([xn, en])[order]
+
+    w["xm"], w["xn"] = widen(wout["xm"], wout["xn"], ("rmnc", "zmns", "lmns"), 23)
+    w["xm_nyq"], w["xn_nyq"] = widen(wout["xm_nyq"], wout["xn_nyq"], ("gmnc", "bmnc", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc"), 25)
+    assert len(w["xm"]) > 500 and len(w["xm_nyq"]) > 650
+    svals = np.array([0.45, 0.8])
+    tabs = ibs_amd.SurfaceTables.from_wout(w, svals)
+    otab = go.surface_tables_from_wout(w, svals)
+    dev = torch.device("cuda:0")
+    for N, n_lines in ((257, 3), (969, 40), (969, 400)):
+        th = ibs_amd.theta_grid(N)
+        surf = np.arange(n_lines) % 2; al = np.linspace(0.0, np.pi, n_lines)
+        r = ctx.fieldline_geometry(tabs, surf, al, th, device=dev)
+        name = ctx.last_launch()[0]
+        assert "k_geo_rows<1, " in name and "k_geo_rows<1, 1," not in name, name
+        got = r["geo"].cpu().numpy().transpose(1, 0, 2)
+        for i in range(0, n_lines, max(1, n_lines // 5)):
+            ref = go.fieldline_geometry(otab, int(surf[i]), np.array([al[i]]), th)[0]
+            err = (np.abs(got[i] - ref) / np.abs(ref).max(axis=1, keepdims=True)).max()
+            assert err < 1e-10, (N, n_lines, i, name, err)
