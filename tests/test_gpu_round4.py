@@ -178,7 +178,7 @@ def test_adjoint_step_configs3_end_to_end(ctx):
 
 
 def test_geometry_on_a_mode_set_too_big_for_the_one_lane_per_point_image(ctx):
-    """F1 on tables with 2.2x NCSX's modes (12 rows of 47 + 14 rows of 51: the size of a W7-X-like run): the image of the
+    """F1 on tables with twice NCSX's modes (11 rows of 47 + 15 rows of 51: the size of a W7-X-like run): the image of the
     one-lane-per-point forms is sized for one pair per mode and does not fit the LDS there, so every batch size must run on the
     lanes-per-point forms (NOT on the one-sincos-per-mode kernel) and agree with the numpy oracle (utils.py:359-720 restated).
     The extra modes carry small coefficients (a data manipulation for shape coverage: both sides evaluate the same formulas)."""
@@ -205,7 +205,7 @@ def test_geometry_on_a_mode_set_too_big_for_the_one_lane_per_point_image(ctx):
 
     w["xm"], w["xn"] = widen(wout["xm"], wout["xn"], ("rmnc", "zmns", "lmns"), 23)
     w["xm_nyq"], w["xn_nyq"] = widen(wout["xm_nyq"], wout["xn_nyq"], ("gmnc", "bmnc", "bsupvmnc", "bsubsmns", "bsubumnc", "bsubvmnc"), 25)
-    assert len(w["xm"]) > 500 and len(w["xm_nyq"]) > 650
+    assert len(w["xm"]) > 480 and len(w["xm_nyq"]) > 650
     svals = np.array([0.45, 0.8])
     tabs = ibs_amd.SurfaceTables.from_wout(w, svals)
     otab = go.surface_tables_from_wout(w, svals)
