@@ -54,6 +54,14 @@ def allreduce_dof_vector(local_values, owned, n_dof_plus_1, world, dist=None, de
     return t.cpu().numpy()
 
 
+def chunk_cuts(n, n_chunks, growth=1.0):
+    """boundaries of the coarse runs of AdjointStep: n equilibria in at most n_chunks runs, run k + 1 holding `growth` times the
+    equilibria of run k (rounded; empty runs dropped).  Returns the increasing list [0, ..., n]."""
+    nch = max(1, min(int(n_chunks), int(n)))
+    wts = np.cumsum([0.0] + [float(growth) ** k for k in range(nch)])
+    return sorted(set(int(round(n * w / wts[-1])) for w in wts))
+
+
 class AdjointStep:
     """The ballooning work of ONE optimizer iteration for all equilibria of the step at once: the base equilibrium and one
     per boundary DOF (BASELINE configs[3]: 73 x 5 surfaces x 24 alpha x 15 theta0, N = 969).
@@ -121,9 +129,7 @@ class AdjointStep:
                     self._scan = None
                 scan = self._scan_for(fr, len(own))
                 nch = min(self.n_chunks, len(own))
-                wts = np.cumsum([0.0] + [self.chunk_growth ** k for k in range(nch)])
-                cuts = [int(round(len(own) * w / wts[-1])) for w in wts]
-                cuts = sorted(set(cuts)); nch = len(cuts) - 1
+                cuts = chunk_cuts(len(own), nch, self.chunk_growth); nch = len(cuts) - 1
 
                 def fill(c0, c1):          # (owned-surface range -> equilibria range: chunks are cut at equilibrium boundaries)
                     q0, q1 = c0 // ns, c1 // ns

@@ -508,3 +508,18 @@ def test_two_rank_gloo_adjoint_step_equals_single_rank(fail_rank):
         assert np.array_equal(np.asarray(res[0][1][k]), np.asarray(single[1][k])), k
     f0 = np.asarray(single[1]["f0"]); gam = np.asarray(single[1]["gam"])
     assert gam.shape == (7, 5) and abs(f0[2] - (0.82 + 50.0 * np.maximum(gam[2] + 2e-4, 0).sum())) < 1e-14
+
+
+def test_adjoint_step_coarse_runs_cover_every_equilibrium_once():
+    """chunk_cuts: whatever the number of runs and the growth factor, the runs are non-empty, in order, and cover 0 .. n exactly;
+    growth 1 gives the equal cuts, growth > 1 a first run no longer than any later one."""
+    from ibs_amd.objective import chunk_cuts
+    for n in (1, 2, 5, 36, 37, 73):
+        for nch in (1, 2, 4, 6, 9, 100):
+            for gr in (1.0, 1.25, 1.5, 2.0, 0.8):
+                c = chunk_cuts(n, nch, gr)
+                assert c[0] == 0 and c[-1] == n and all(b > a for a, b in zip(c, c[1:])) and len(c) - 1 <= min(nch, n), (n, nch, gr, c)
+                if gr > 1.0 and len(c) > 2:
+                    sizes = np.diff(c)
+                    assert sizes[0] <= sizes[1:].min() + 1, (n, nch, gr, c)
+    assert chunk_cuts(73, 4, 1.0) == [0, 18, 36, 55, 73]
