@@ -4,11 +4,11 @@
 // the radial splines (utils.py:37-158, 311-357) stay on the host and hand over per-surface Fourier
 // coefficient vectors.
 //
-// One thread per grid point: theta_pest -> theta_vmec by a secant solve on
+// Per grid point: theta_pest -> theta_vmec by a secant solve on
 //   theta_vmec + sum_mn lmns sin(m theta_vmec - n phi) = theta_pest            (utils.py:391-416)
 // then two Fourier syntheses (mnmax and Nyquist mode sets, utils.py:420-468) and the metric algebra
-// (utils.py:474-720).  Mode coefficients are wave-uniform (a block works on one field line), so they
-// arrive through scalar loads; the work is FP64 sin/cos evaluation, i.e. compute bound.
+// (utils.py:474-720).  k_fieldline_geometry below is the plain form (one thread per point, one sincos per
+// mode: any mode ordering, the fallback); the row kernels further down are what runs (FP64-issue bound).
 #include <hip/hip_runtime.h>
 #include "ibs_launch.hpp"
 #include <cstdlib>
@@ -133,17 +133,19 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry(GeoArgs a) {
 //        P_m = sum_n l_mn cos(n phi),  Q_m = sum_n l_mn sin(n phi)
 //      so ONE pass over the 242 modes gives (P_m, Q_m) -- kept in registers, MAXR rows at most -- and each of the ~6
 //      secant evaluations costs a sincos and 6 flops per ROW instead of 2 per MODE.
-//  (3) PERSISTENT BLOCKS.  One 512-thread block per CU (two waves per SIMD: a lone wave gets half of its SIMD's issue
-//      rate) walks a contiguous range of wave-items and re-stages its table image only when the surface changes.
-//  (4) LANE-MAJOR FLAT GROUP LISTS.  A wave-item is 64*PPL/LPP consecutive grid points of one line: PPL = 2 points per
-//      lane for batches that fill the chip (every table entry read from LDS feeds two points: the LDS pipe, which a
-//      ds_read_b128 occupies for 4 cycles per wave whether or not its lanes broadcast, stops being the bound), or
-//      LPP = 2 / 4 / 8 lanes per point for small batches (the refinement rounds of ibs_refine_f64: a handful of lines).
-//      With LPP lanes per point every lane takes an equally long n-segment of EVERY row; the image stores each lane's
-//      groups of all rows back to back (lane stride odd in 16-byte units: the LPP addresses of a read fall on distinct
-//      banks), so the synthesis is ONE flat loop over the lane's groups with the next group's ten 16-byte reads in
-//      flight while the current one is consumed -- rows of two groups (LPP = 8) would otherwise expose the LDS latency
-//      26 + 11 times per point.
+//  (3) PERSISTENT BLOCKS.  One 512-thread block per CU (two waves per SIMD) owns a contiguous range of lines and re-stages its
+//      table image only when the surface changes; between re-stagings its waves CLAIM wave-items one at a time.
+//  (4) TWO FAMILIES OF FORMS.  A wave-item is 64*PPL/LPP consecutive grid points of one line.
+//      One lane per point (LPP = 1; PPL = 2 points per lane for batches that fill the chip, 1 for medium ones) -- round 4: the
+//      rows in N-SYMMETRIC form (a pair of modes n_c +- t dn costs one multiply-add per sum and point, cos / sin(t dn phi) by
+//      one recurrence per row) with the table coefficients BROADCAST BY 64-BIT DPP (fmac_bc below: one ds_read_b64 per
+//      sixteen coefficients, so the table reads are off the LDS pipe, which a ds_read_b128 occupies as long as a v_fma_f64
+//      occupies the FP64 pipe whether or not its lanes broadcast).
+//      Several lanes per point (LPP = 2 / 4 / 8) for small batches (the last rounds of ibs_refine_f64: a handful of lines):
+//      every lane takes an equally long n-segment of EVERY row; the image stores each lane's groups of two modes of all
+//      rows back to back (lane stride odd in 16-byte units: the LPP addresses of a read fall on distinct banks), so the
+//      synthesis is ONE flat loop over the lane's groups with the next group's ten 16-byte reads in flight while the current
+//      one is consumed -- rows of two groups (LPP = 8) would otherwise expose the LDS latency 26 + 11 times per point.
 constexpr int kGeoBlock = 512;
 constexpr int kGeoMaxRows = 128;
 
