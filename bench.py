@@ -49,6 +49,38 @@ def pmc_set_name():
     return d["_set"] if isinstance(d.get("_set"), str) else "unnamed"
 
 
+CSRC = os.path.join(ROOT, "ideal-ballooning-solver_amd", "csrc")
+# which sources a kernel's instruction stream comes from: the geometry kernels live in one translation unit, every solver /
+# scan / refinement kernel is built from the wave + group solver headers (ibs_api.hip only CHOOSES kernels, and an entry is
+# looked up by the exact kernel name and launch size the library reports, so a changed choice cannot quote wrong counters)
+SRC_GROUPS = {"geometry": ("ibs_geometry.hip", "ibs_launch.hpp"),
+              "solver": ("ibs_kernels.hip", "ibs_kernels_group.hip", "ibs_wave.hpp", "ibs_group.hpp", "ibs_refine.hpp",
+                         "ibs_lbfgsb2.hpp", "ibs_launch.hpp")}
+
+
+def kernel_group(kernel):
+    return "geometry" if "k_geo_" in kernel else "solver"
+
+
+def src_sha(csrc=None):
+    """{"geometry": sha, "solver": sha}: sha256 (16 hex digits) over the names and bytes of the sources each kernel group is
+    compiled from.  tools/pmc_summary.py stores it as "_src_sha" in the PMC set; pmc_entry() refuses an entry whose group's
+    sources have changed since ("stale": a kernel edited after the last PMC pass must not quote the old counters)."""
+    import hashlib
+    csrc = csrc or CSRC
+    out = {}
+    for grp, files in SRC_GROUPS.items():
+        hh = hashlib.sha256()
+        for f in files:
+            hh.update(f.encode() + b"\0")
+            try:
+                hh.update(open(os.path.join(csrc, f), "rb").read())
+            except OSError:
+                hh.update(b"<absent>")
+        out[grp] = hh.hexdigest()[:16]
+    return out
+
+
 def pmc_entry(kernel, waves, work_class=0):
     """The committed rocprofv3 --pmc figures of ONE leg (tools/profile_run.py -> tools/pmc_summary.py ->
     profiles/pmc_current.json): the entry whose kernel name is EXACTLY `kernel` ("ibs::k_gamma_scan<double, 8>"), whose
@@ -59,6 +91,13 @@ def pmc_entry(kernel, waves, work_class=0):
     d = _pmc_file()
     if d is None:
         return None, "profiles/pmc_current.json is absent"
+    grp = kernel_group(kernel)
+    if not hasattr(src_sha, "tree"):
+        src_sha.tree = src_sha()
+    have = (d.get("_src_sha") or {}).get(grp) if isinstance(d.get("_src_sha"), dict) else None
+    if have != src_sha.tree[grp]:
+        return None, "stale: the %s sources have changed since the PMC set %s was taken (set %s, tree %s)" % (
+            grp, pmc_set_name(), have, src_sha.tree[grp])
     cands = [v for k, v in d.items() if isinstance(v, dict) and v.get("kernel", k.split(" @")[0]) == kernel]
     if not cands:
         return None, "no PMC entry for the kernel '%s'" % kernel
@@ -82,9 +121,15 @@ def pmc_fields(kernel, waves, ms, alg_bytes=None, work_class=0):
           "measured by this run)" % pmc_set_name()
     if e is None:
         return dict(traffic=None, counters_error=why, counters_kernel=kernel, counters_waves_per_launch=waves)
+    unmatched = (_pmc_file() or {}).get("_unmatched_launches_of_the_byte_passes", 0)
+    if unmatched:       # the FETCH / WRITE passes could not be matched launch by launch to the SQ pass's work classes:
+        e = dict(e)     # byte counts may belong to another data set -> no traffic figure (the instruction counts stand)
+        e.pop("hbm_bytes_per_launch", None)
     out = dict(traffic=e.get("hbm_bytes_per_launch"), counters_kernel=kernel, counters_waves_per_launch=waves,
                counters_source=src, valu_insts_per_wave=e.get("valu_insts_per_wave"),
                valu_busy_frac=e.get("valu_busy_frac_of_wave_lifetime"))
+    if unmatched:
+        out["counters_error"] = "unmatched: %d launches of the byte passes could not be attributed; traffic withheld" % unmatched
     if alg_bytes and out["traffic"]:
         out["traffic_over_algorithmic"] = out["traffic"] / alg_bytes
     if "SQ_INSTS_VALU" in e and ms:
@@ -102,6 +147,200 @@ def hbm_roofline(alg_bytes, ms, bound, kernel, waves, work_class=0, **extra):
     out.update(pmc_fields(kernel, waves, ms, alg_bytes, work_class))
     out.update(extra)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The line the driver keeps.  The driver's record holds an ~8 KB tail of stdout; the round-4 line was 40.5 KB and was cut
+# (BENCH_r04.json: parsed = null).  stdout therefore carries ONE line of at most LINE_LIMIT bytes -- the contract's keys,
+# `roofline`, `cpu_baseline` and a few numbers per extra leg -- and everything else goes to bench_detail.json (next to
+# bench.py, or $IBS_BENCH_DETAIL) and, as one line, to stderr.  tests/test_bench_cpu.py holds the length under the limit.
+LINE_LIMIT = 6000
+DETAIL_FILE = os.environ.get("IBS_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+
+
+def _sig(x, n=5):
+    """floats to n significant digits, through lists and dicts (ints, bools, strings, None untouched)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (n, x)) if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return _sig(float(x), n)
+
+
+def _counters_tag(r):
+    """where a roofline's counters come from, in a few bytes: "pmc:<set>" (replayed from profiles/pmc_current.json: DESIGN.md 5)
+    or "none:<reason class>" """
+    if r.get("counters_error"):
+        e = r["counters_error"]
+        if e.startswith("unmatched"):
+            return "pmc:%s(traffic withheld)" % pmc_set_name()
+        return "none:" + ("stale" if e.startswith("stale") else "absent")
+    return "pmc:" + pmc_set_name()
+
+
+def compact_roofline(r, head=False):
+    """a leg's roofline object without the prose: the contract's six keys + the kernel, the VALU-issue fraction (the bound that
+    binds: DESIGN.md 4), instructions per wave and the counters' source tag"""
+    if not isinstance(r, dict):
+        return r
+    vi = r.get("valu_issue") or {}
+    out = dict(bound=r.get("bound"), achieved=r.get("achieved"), peak=r.get("peak"), unit=r.get("unit"), frac=r.get("frac"),
+               traffic=r.get("traffic"), kernel=r.get("kernel"), traffic_over_algorithmic=r.get("traffic_over_algorithmic"),
+               valu_issue_frac=vi.get("frac"), valu_insts_per_wave=r.get("valu_insts_per_wave"), counters=_counters_tag(r))
+    if head:
+        out.update(algorithmic_bytes_per_launch=r.get("algorithmic_bytes_per_launch"), kernel_ms=r.get("kernel_ms"),
+                   kernel_ms_rocprof=r.get("kernel_ms_rocprof"), kernel_ms_rocprof_source=r.get("kernel_ms_rocprof_source"),
+                   waves_per_launch=r.get("counters_waves_per_launch"))
+    return out
+
+
+def _leg4(leg, rate_key):
+    """[rate, hbm_frac, valu_issue_frac, traffic_over_algorithmic] of a throughput leg"""
+    r = leg.get("roofline") or {}
+    return [leg.get(rate_key), r.get("hbm_frac"), (r.get("valu_issue") or {}).get("frac"), r.get("traffic_over_algorithmic")]
+
+
+C5_COLS = ["n_zeta", "family", "mode", "solves_per_s", "hbm_frac", "valu_issue_frac", "traffic_over_algorithmic", "kernel"]
+
+
+def compact_c5(m):
+    """configs[4]: one array per (N_zeta, family, mode) row (C5_COLS); kernel names once, rows point into the list"""
+    kernels, rows = [], []
+    for r in m.get("rows", []):
+        if "mode" not in r:
+            rows.append([r.get("n_zeta"), r.get("family", "?")[0], "skipped"])
+            continue
+        k = (r.get("roofline") or {}).get("kernel")
+        if k not in kernels:
+            kernels.append(k)
+        rows.append([r["n_zeta"], r["family"][0], r["mode"].replace("f32_", "f32")] + _leg4(r, "solves_per_s")[0:4] + [kernels.index(k)])
+    return dict(systems_per_row=next((r.get("systems") for r in m.get("rows", []) if "systems" in r), None), cols=C5_COLS,
+                rows=rows, kernels=kernels, f32_gam_over_f64_min=min([v for v in (m.get("f32_gam_over_f64") or {}).values() if v] or [None]),
+                f32_results_outside_tolerance=m.get("f32_results_outside_tolerance"),
+                flagged=sum(r.get("flagged", 0) for r in m.get("rows", [])), seconds=m.get("seconds"))
+
+
+def _strip_prose(d, limit=90):
+    """an extra leg without its long strings (workload descriptions, notes, *_how): for legs with no schema of their own below"""
+    if not isinstance(d, dict):
+        return d
+    return {k: (_strip_prose(v, limit) if isinstance(v, dict) else v) for k, v in d.items()
+            if not (isinstance(v, str) and len(v) > limit) and not k.endswith("_how") and k != "note"}
+
+
+# what may be dropped, first to last, if a line is still over the limit (it never is with today's legs: the test pins 6,000)
+_DROP_ORDER = ("batch_scaling", "warm_rescan", "gather_modes", "dropin_call_us", "sturm_sweep", "scan_large", "stress_rough",
+               "reference_batch", "ncsx_c3", "c5_matrix", "ncsx_c2_sharded_native", "cpu_reference_cost")
+
+
+def compact_line(out, limit=LINE_LIMIT):
+    """the ONE stdout line: `out` (everything the run measured) reduced to the contract's keys + 3-8 numbers per leg, floats at
+    5 significant digits except value / ms_per_step; at most `limit` bytes whatever the legs hold"""
+    o = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data") if k in out}
+    cfg = dict(out.get("config", {}))
+    if len(cfg.get("workload", "")) > 340:
+        cfg["workload"] = cfg["workload"][:337] + "..."
+    o["config"] = _sig(cfg)
+    o["solves_per_s_kernel"] = _sig(out.get("solves_per_s_kernel"))
+    o["roofline"] = _sig(compact_roofline(out.get("roofline"), head=True))
+    for k in ("cpu_baseline", "cpu_reference_cost"):
+        if k in out:
+            o[k] = _sig({a: b for a, b in out[k].items() if a != "sample" or k == "cpu_baseline"})
+            if isinstance(o[k].get("sample"), str) and len(o[k]["sample"]) > 120:
+                o[k]["sample"] = o[k]["sample"][:117] + "..."
+    for k in ("parity_ok", "max_abs_dgam_vs_oracle"):
+        if k in out:
+            o[k] = _sig(out[k])
+    four = "[rate_per_s, hbm_frac, valu_issue_frac, traffic_over_algorithmic]"
+    for k, rate in (("stress", "solves_per_s"), ("stress_rough", "solves_per_s"), ("sturm_sweep", "sweeps_per_s"), ("scan_large", "solves_per_s")):
+        if k in out:
+            o.setdefault("legs_cols", four)
+            o[k] = _sig(_leg4(out[k], rate))
+    if "warm_rescan" in out:
+        w = out["warm_rescan"]
+        o["warm_rescan"] = _sig(dict(solves_per_s=w.get("solves_per_s"), sweeps_cold=w.get("sweeps_cold"), sweeps_warm=w.get("sweeps_warm")))
+    if "batch_scaling" in out:
+        b = out["batch_scaling"]
+        o["batch_scaling"] = _sig(dict(solves_per_launch=[r["solves_per_launch"] for r in b.get("one_launch", [])],
+                                       us_per_launch=[r["us_per_launch"] for r in b.get("one_launch", [])],
+                                       two_streams_us=(b.get("two_streams") or {}).get("us_per_launch")))
+    for k in ("ncsx_c3", "reference_batch"):
+        if k in out:
+            L = out[k]
+            gr, sr = L.get("geometry_roofline") or {}, L.get("roofline") or {}
+            o[k] = _sig(dict(geometry_ms=L.get("geometry_ms"), scan_ms=L.get("scan_ms"), argmax_ms=L.get("argmax_ms"),
+                             refine_ms=L.get("refine_ms"), scan_solves_per_s=L.get("scan_solves_per_s"),
+                             geometry_points_per_s=L.get("geometry_points_per_s"), nonconverged=L.get("nonconverged"),
+                             geometry_kernel=gr.get("kernel"), geometry_valu_issue_frac=(gr.get("valu_issue") or {}).get("frac"),
+                             scan_kernel=sr.get("kernel"), scan_valu_issue_frac=(sr.get("valu_issue") or {}).get("frac")))
+            o[k] = {a: b for a, b in o[k].items() if b is not None}
+    if "dropin_call_us" in out:
+        o["dropin_call_us"] = _sig(out["dropin_call_us"].get("us_per_call") if isinstance(out["dropin_call_us"], dict) else out["dropin_call_us"])
+    if "c4_adjoint_step" in out:
+        c = out["c4_adjoint_step"]
+        o["c4_adjoint_step"] = _sig({k: c.get(k) for k in ("total_ms", "total_ms_runs", "phases_ms", "refine_evaluations", "refine_rounds",
+                                                            "coarse_solves", "fobj", "max_abs_dgam_vs_oracle", "oracle_pairs", "parity_ok", "error")
+                                     if c.get(k) is not None})
+    if "c5_matrix" in out:
+        o["c5_matrix"] = _sig(compact_c5(out["c5_matrix"]), 4)
+    known = set(o) | {"config", "roofline"}
+    extra = []
+    for k, v in out.items():              # legs without a schema above (the N > 1 legs): numbers and flags, no prose
+        if k not in known:
+            o[k] = _sig(_strip_prose(v))
+            extra.append(k)
+    o["detail"] = os.path.basename(DETAIL_FILE) + " (+ one line on stderr)"
+    line = json.dumps(o, separators=(",", ":"))
+    dropped = []
+    while len(line) > limit and extra:    # over the limit: first the largest of the legs that have no schema here ...
+        k = max(extra, key=lambda k: len(json.dumps(o[k])))
+        if len(json.dumps(o[k])) < 600:
+            break
+        extra.remove(k)
+        del o[k]
+        dropped.append(k)
+        o["dropped_for_length"] = dropped
+        line = json.dumps(o, separators=(",", ":"))
+    for k in _DROP_ORDER:                 # ... then the side legs in a fixed order
+        if len(line) <= limit:
+            break
+        if k in o:
+            del o[k]
+            dropped.append(k)
+            o["dropped_for_length"] = dropped
+            line = json.dumps(o, separators=(",", ":"))
+    keep = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline", "parity_ok", "max_abs_dgam_vs_oracle", "detail", "dropped_for_length"}
+    while len(line) > limit and set(o) - keep:      # then whatever is largest among the keys the contract does not name
+        k = max(set(o) - keep, key=lambda k: len(json.dumps(o[k])))
+        del o[k]
+        dropped.append(k)
+        o["dropped_for_length"] = dropped
+        line = json.dumps(o, separators=(",", ":"))
+    if len(line) > limit:                 # last resort: the contract's keys, roofline and cpu_baseline only
+        o = {k: o[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data", "roofline", "cpu_baseline", "parity_ok") if k in o}
+        o["config"] = {"workload": cfg.get("workload")}
+        o["dropped_for_length"] = "everything but the contract's keys"
+        line = json.dumps(o, separators=(",", ":"))
+    return line
+
+
+def emit(out):
+    """rank 0's output: the full record to DETAIL_FILE and (one line) to stderr, the compact line to stdout -- last, alone"""
+    full = json.dumps(out)
+    try:
+        with open(DETAIL_FILE, "w") as fh:
+            fh.write(full + "\n")
+    except OSError as e:
+        print("bench.py: could not write %s (%s)" % (DETAIL_FILE, e), file=sys.stderr)
+    print("bench.py detail: " + full, file=sys.stderr, flush=True)
+    print(compact_line(out), flush=True)
 
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -208,7 +447,7 @@ def stress(ctx, device, n_sys, family, reps=3):
         lam = sh * (th[None] - t0) - al * (torch.sin(th)[None] - torch.sin(t0))
         g = 1 + lam ** 2
         c = al * (torch.cos(th)[None] + torch.sin(th)[None] * lam)
-        f = g
+        f = g.clone()          # its own array: the three rows of a system are three streams of HBM traffic
         del lam
     else:                       # iid per point inside the measured NCSX_op envelopes
         g = torch.exp(u(np.log(0.01), np.log(50.0), (n_sys, N)))
@@ -435,7 +674,7 @@ def c5_family(dev, family, n, N, seed):
         g = 1 + lam ** 2
         c = al * (torch.cos(th)[None] + torch.sin(th)[None] * lam)
         del lam
-        return h, g, c, g
+        return h, g, c, g.clone()      # f = g in value, its own array in HBM (priced at (3 N + 1) w bytes: all three rows move)
     g = torch.exp(u(np.log(0.01), np.log(50.0), (n, N)))
     c = u(-2.5, 3.5, (n, N))
     f = torch.exp(u(np.log(0.2), np.log(3e3), (n, N)))
@@ -522,9 +761,8 @@ def c5_matrix(ctx, device, n_sys=1 << 20, budget_s=75.0):
                 continue
             h, g, c, f = c5_family(device, family, n_sys, N, seed=20240 + nz)           # rng seed 20240 + N_zeta
             g32, c32 = g.float(), c.float()
-            f32 = g32 if family == "smooth" else f.float()
-            g64w, c64w = g32.double(), c32.double()
-            f64w = g64w if family == "smooth" else f32.double()
+            f32 = f.float()
+            g64w, c64w, f64w = g32.double(), c32.double(), f32.double()
             r64 = ctx.solve_gcf(h, g64w, c64w, f64w)        # the FP32-valued systems solved in FP64: the FP32 rows' reference
             nA = norm_a(h, g64w, c64w, f64w)
             del g64w, c64w, f64w
@@ -852,7 +1090,7 @@ class Watchdog:
                     if line is not None:
                         for _ in range(3):          # (the main thread may be adding a key to the line right now)
                             try:
-                                text = json.dumps(dict(line, aborted="phase '%s' did not finish within %d s" % (phase, seconds)))
+                                text = compact_line(dict(line, aborted="phase '%s' did not finish within %d s" % (phase, seconds)))
                                 break
                             except RuntimeError:
                                 time.sleep(0.05)
@@ -1092,6 +1330,8 @@ def main():
     # overruns (a rank that left a leg early while the others wait in its collective, a communicator that never comes up)
     # ends with rank 0 printing what it has and every rank leaving with status 5 (Watchdog.EXIT_CODE)
     dog = Watchdog(rank, lambda: out)
+    if use_dist and os.environ.get("IBS_BENCH_DIE_RANK") == str(rank) and os.environ.get("IBS_BENCH_DIE_AFTER") == "headline":
+        os._exit(17)           # test hook (tests/test_gpu_round5.py): a rank that dies while the others enter a collective
     if use_dist:
         for key, leg, label in (("ncsx_c2_sharded", lambda: c2_sharded_leg(ctx, device, rank, world, dist, fence, native=False),
                                  "configs[2] sharded, torch.distributed gather"),
@@ -1184,7 +1424,7 @@ def main():
             if out["c4_adjoint_step"].get("parity_ok") is False:
                 rc = 3
             out["c5_matrix"] = c5_matrix(ctx, device)
-        print(json.dumps(out), flush=True)
+        emit(out)
         if rc:
             print("bench.py: parity check FAILED: max |gam - oracle| = %g (bar 1e-8), flagged solves %d" % (
                 out["max_abs_dgam_vs_oracle"], nbad), file=sys.stderr, flush=True)

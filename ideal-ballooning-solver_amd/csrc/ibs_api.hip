@@ -97,6 +97,9 @@ struct ibs_ctx {
   int refine_hist_len = 0;
   long long refine_stats[4] = {0, 0, 0, 0};      // evaluations, forward sweeps, rounds, rounds enqueued
   bool refine_pending = false;                   // the last call's output kernel may still be running (device-pointer call)
+  // the device-resident mode-row tables last checked by geo_rows_fit (pointers + counts) and the verdict
+  struct RowsSeen { const void* r1 = nullptr; const void* r2 = nullptr; const void* xn = nullptr; const void* xnq = nullptr;
+                    int n1 = 0, n2 = 0, mn = 0, mnq = 0; double d1 = 0, d2 = 0; int verdict = 0; } rows_seen;
 };
 
 namespace {
@@ -333,7 +336,8 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     HIPCHK(hipMemcpyAsync(dg, g, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(dc, c, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(df, f, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    a.g = dg; a.c = dc; a.f = df; a.lam = dlam; a.gam = dgam; a.X = dX_; a.dX = ddX; a.info = d_info;
+    // (gam not asked for: the kernels then take their eigenvalue-only exits, as they do for device-pointer calls)
+    a.g = dg; a.c = dc; a.f = df; a.lam = dlam; a.gam = gam ? dgam : nullptr; a.X = dX_; a.dX = ddX; a.info = d_info;
     if (gh) {
       T* dgh = ar.take<T>(in_elems);
       HIPCHK(hipMemcpyAsync(dgh, gh, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
@@ -952,6 +956,55 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
   return 0;
 }
 
+// The mode rows a caller hands to the geometry entry points ({first mode, count} per row): 1 = every row lies inside the mode
+// list and none has more pair indices about its centre than the row kernels' table image holds (ibs::kGeoMaxPairs = 64: a
+// row of up to 129 modes centred on n = 0 -- VMEC's -ntor..ntor with ntor <= 64 -- or up to 65 modes otherwise; the centre
+// rule is k_geo_prepare's), 0 = valid but a row is longer (the call then runs on the one-sincos-per-mode kernel, which takes
+// any ordering), < 0 = a row outside the mode list (error set).  Host tables are checked on every call; device-resident
+// ones are copied back ONCE per (pointers, counts, steps) -- a synchronisation the first call with a table set pays.
+static int geo_rows_fit_host(const int32_t* rows, int nrows, int nmodes, const double* xn, double dn, const char* which) {
+  int fit = 1;
+  for (int r = 0; r < nrows; ++r) {
+    const int first = rows[2 * r], cnt = rows[2 * r + 1];
+    if (first < 0 || cnt < 1 || (long)first + cnt > nmodes) return fail(IBS_ERR_ARG, "%s[%d] = {%d, %d} lies outside the %d modes", which, r, first, cnt, nmodes);
+    if (cnt <= ibs::kGeoMaxPairs + 1) continue;
+    int k0 = 0;
+    if (dn != 0.0) {
+      const double n0 = xn[first], kz = -n0 / dn;
+      const int kr = (int)(kz + (kz >= 0 ? 0.5 : -0.5));
+      if (kr >= 0 && kr < cnt && std::fabs(n0 + kr * dn) <= 1e-9 * std::fabs(dn)) k0 = kr;
+    }
+    if (std::max(k0, cnt - 1 - k0) > ibs::kGeoMaxPairs) fit = 0;
+  }
+  return fit;
+}
+static int geo_rows_fit(ibs_ctx* ctx, int mnmax, int mnmax_nyq, const double* xn, const double* xn_nyq, int nrows_mn,
+                        const int32_t* rows_mn, int nrows_nyq, const int32_t* rows_nyq, double dn_mn, double dn_nyq, bool host) {
+  if (host) {
+    const int a = geo_rows_fit_host(rows_mn, nrows_mn, mnmax, xn, dn_mn, "rows_mn");
+    if (a < 0) return a;
+    const int b = geo_rows_fit_host(rows_nyq, nrows_nyq, mnmax_nyq, xn_nyq, dn_nyq, "rows_nyq");
+    return b < 0 ? b : a;            // (only the first list feeds the (P, Q) tables; the second one's pair tables hold one entry per mode)
+  }
+  auto& c = ctx->rows_seen;
+  if (c.r1 == rows_mn && c.r2 == rows_nyq && c.xn == xn && c.xnq == xn_nyq && c.n1 == nrows_mn && c.n2 == nrows_nyq && c.mn == mnmax &&
+      c.mnq == mnmax_nyq && c.d1 == dn_mn && c.d2 == dn_nyq) return c.verdict;
+  std::vector<int32_t> r1((size_t)2 * nrows_mn), r2((size_t)2 * nrows_nyq);
+  std::vector<double> x1(mnmax), x2(mnmax_nyq);
+  HIPCHK(hipMemcpyAsync(r1.data(), rows_mn, r1.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(r2.data(), rows_nyq, r2.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(x1.data(), xn, x1.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(x2.data(), xn_nyq, x2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int a = geo_rows_fit_host(r1.data(), nrows_mn, mnmax, x1.data(), dn_mn, "rows_mn");
+  if (a < 0) return a;
+  const int b = geo_rows_fit_host(r2.data(), nrows_nyq, mnmax_nyq, x2.data(), dn_nyq, "rows_nyq");
+  if (b < 0) return b;
+  c.r1 = rows_mn; c.r2 = rows_nyq; c.xn = xn; c.xnq = xn_nyq; c.n1 = nrows_mn; c.n2 = nrows_nyq; c.mn = mnmax; c.mnq = mnmax_nyq;
+  c.d1 = dn_mn; c.d2 = dn_nyq; c.verdict = a;
+  return c.verdict;
+}
+
 // workspace for the prepared table images of the geometry row kernels (ibs_geometry.hip): the set of the form `f`
 static size_t geo_img_bytes(const ibs::GeoArgs& a, int lpp) {
   return ibs::geo_rows_usable(a, lpp) ? pad256((size_t)a.n_surf * ibs::geo_image_doubles(a, lpp) * sizeof(double)) : 0;
@@ -974,7 +1027,12 @@ int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int3
   ibs::GeoArgs a{};
   a.n_surf = n_surf; a.mnmax = mnmax; a.mnmax_nyq = mnmax_nyq; a.n_lines = n_lines; a.N = N; a.ld = ld;
   a.lpp = ctx->opt.geo_lpp;
-  const bool rows = nrows_mn > 0 && nrows_nyq > 0;
+  bool rows = nrows_mn > 0 && nrows_nyq > 0;
+  if (rows) {
+    const int fit = geo_rows_fit(ctx, mnmax, mnmax_nyq, xn, xn_nyq, nrows_mn, rows_mn, nrows_nyq, rows_nyq, dn_mn, dn_nyq, mem == IBS_MEM_HOST);
+    if (fit < 0) return fit;
+    rows = fit == 1;
+  }
   if (rows) { a.nrows_mn = nrows_mn; a.nrows_nyq = nrows_nyq; a.dn_mn = dn_mn; a.dn_nyq = dn_nyq; }
   a.form = ibs::geo_pick_usable(a, n_lines, N, ctx->n_cu);
   const size_t img_bytes = geo_img_bytes(a, a.form.lpp);
@@ -1196,7 +1254,11 @@ int ibs_refine_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_ny
   ibs::GeoArgs ga{};
   ga.n_surf = n_surf; ga.mnmax = mnmax; ga.mnmax_nyq = mnmax_nyq; ga.n_lines = n_lines; ga.N = N; ga.ld = ld;
   ga.lpp = ctx->opt.geo_lpp;
-  if (nrows_mn > 0 && nrows_nyq > 0) { ga.nrows_mn = nrows_mn; ga.nrows_nyq = nrows_nyq; ga.dn_mn = dn_mn; ga.dn_nyq = dn_nyq; }
+  if (nrows_mn > 0 && nrows_nyq > 0) {
+    const int fit = geo_rows_fit(ctx, mnmax, mnmax_nyq, xn, xn_nyq, nrows_mn, rows_mn, nrows_nyq, rows_nyq, dn_mn, dn_nyq, host);
+    if (fit < 0) return fit;
+    if (fit == 1) { ga.nrows_mn = nrows_mn; ga.nrows_nyq = nrows_nyq; ga.dn_mn = dn_mn; ga.dn_nyq = dn_nyq; }
+  }
   size_t need = pad256(n_geo * 8) + pad256((size_t)n_lines * 4) + pad256((size_t)n_lines * 8) + 10 * pad256((size_t)n_pts * 16) +
                 pad256((size_t)n_pts * sizeof(RefineState)) + pad256((size_t)N * 8) + 8192;
   // the lanes-per-point forms the rounds can take as the batch shrinks (geo_pick_form is monotone in the batch size)

@@ -185,7 +185,7 @@ __host__ __device__ inline GeoImgLayout geo_layout(int mnmax, int nr1, int mnmax
     L.o_c0mn = L.o_lm;
     L.o_c0nq = L.o_c0mn + 10 * nr1;
     L.o_symn = L.o_c0nq + 10 * nr2;
-    L.total = L.o_symn + 32 * mnmax + 16 * mnmax_nyq + 64 * 16 * (nr1 > 12 ? 3 : 2);
+    L.total = L.o_symn + 32 * mnmax + 16 * mnmax_nyq + kGeoMaxPairs * 16 * (nr1 > 12 ? 3 : 2);
     return L;
   }
   L.s_lm = 2 * (L.T1c + 1);
@@ -319,10 +319,18 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
     const int S1 = so_s[0][nr1], S2 = so_s[1][nr2];
     const int NB = nr1 > 12 ? 3 : 2, Ts = tmax_s;
     const int o_synq = L.o_symn + 32 * S1, o_pq = o_synq + 16 * S2;
+    // The image reserves the root solve's (P, Q) tables for kGeoMaxPairs pair indices (geo_layout).  A row with more -- over
+    // 129 modes centred on n = 0, or over 65 uncentred: not a VMEC table, but rows are caller data at the C ABI -- would run
+    // past the image and past the LDS copy of it.  The host entry points check the rows (geo_rows_fit) and send such tables to
+    // k_fieldline_geometry; as a second line of defence the surface is flagged here (slot 15 = -2, used length = the header)
+    // and k_geo_rows writes NaN for its lines.
+    const bool too_long = Ts > kGeoMaxPairs;
     if (t == 0) {
-      I[13] = (double)(o_pq + 16 * NB * Ts); I[14] = (double)o_synq; I[15] = (double)Ts; I[16] = (double)any_s[0]; I[17] = (double)any_s[1];
+      I[13] = too_long ? (double)L.o_ri1 : (double)(o_pq + 16 * NB * Ts); I[14] = (double)o_synq; I[15] = too_long ? -2.0 : (double)Ts;
+      I[16] = (double)any_s[0]; I[17] = (double)any_s[1];
       I[18] = (double)o_pq;
     }
+    if (too_long) return;
     // value of column c of mode k:  mn  rmnc d_rmnc n*rmnc | zmns d_zmns n*zmns | lmns d_lmns n*lmns
     //                               nyq gmnc bmnc d_bmnc n*bmnc bsupv bsubs bsubu bsubv
     auto val_mn = [&](int k, int c) {
@@ -1014,6 +1022,8 @@ __global__ void __launch_bounds__(kGeoBlock) k_geo_rows(GeoArgs a, const double*
     // through an item in ~0.65 of its mate's time; with a fixed item per wave and unit it sat at the next re-staging barrier
     // (or had left the kernel) while the mate finished alone at the lone-wave issue rate.
     const int n_items = (int)(v - u) * WPB;
+    // (LPP = 1) a surface whose rows are too long for the image (k_geo_prepare)
+    const bool general = LPP == 1 && __builtin_amdgcn_readfirstlane((int)I[15]) < -1;
     for (;;) {
       int k = 0;
       if ((threadIdx.x & 63) == 0) k = atomicAdd(&claim, 1);
@@ -1024,6 +1034,15 @@ __global__ void __launch_bounds__(kGeoBlock) k_geo_rows(GeoArgs a, const double*
       const int item = (int)(uu - (long)line * upl) * WPB + (k % WPB);
       if (item < ipl) {
         GEO_PROBE_AT(1);
+        if constexpr (LPP == 1) {
+          if (general) {
+            // (the host entry points send such tables to k_fieldline_geometry; only device-resident rows rewritten in place
+            // behind the library's back get here: NaN, like every other invalid input -- never an out-of-bounds access)
+            for (int jj = item * PTS + (threadIdx.x & 63); jj < min(item * PTS + PTS, a.j_end); jj += 64)
+              for (int q = 0; q < 8; ++q) a.geo[q * a.plane + (size_t)line * a.ld + jj] = __builtin_nan("");
+            continue;
+          }
+        }
         geo_item<PPL, LPP, MAXR>(a, I, L, line, item * PTS);
       }
     }
@@ -1044,13 +1063,9 @@ __device__ __forceinline__ double geo_wave_sum(double v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
-__global__ void __launch_bounds__(256) k_fieldline_geometry_tail(GeoArgs a) {
+// grid point j of `line` by ONE WAVE, straight from the global tables (any mode ordering, any row lengths)
+__device__ __forceinline__ void geo_point_wave(const GeoArgs& a, int line, int j) {
   const int lane = threadIdx.x & 63;
-  const int r = a.j_end - a.j_begin;
-  const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= (long)(a.n_lines_dev ? min(*a.n_lines_dev, a.n_lines) : a.n_lines) * r) return;
-  const int line = (int)(w / r);
-  const int j = a.j_begin + (int)(w % r);
   const int js = min(max(a.line_surf[line], 0), a.n_surf - 1);
   const double* sc = a.scal + 6 * js;
   const double s = sc[0], iota = sc[1], diota = sc[2], dp = sc[3], phiedge = sc[4], L = sc[5];
@@ -1112,6 +1127,12 @@ __global__ void __launch_bounds__(256) k_fieldline_geometry_tail(GeoArgs a) {
   S.B_p = geo_wave_sum(S.B_p); S.Bsup_phi = geo_wave_sum(S.Bsup_phi); S.Bsub_s = geo_wave_sum(S.Bsub_s);
   S.Bsub_t = geo_wave_sum(S.Bsub_t); S.Bsub_p = geo_wave_sum(S.Bsub_p);
   if (lane == 0) geo_tail(a, line, j, phi, s, iota, diota, dp, phiedge, L, S);
+}
+__global__ void __launch_bounds__(256) k_fieldline_geometry_tail(GeoArgs a) {
+  const int r = a.j_end - a.j_begin;
+  const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= (long)(a.n_lines_dev ? min(*a.n_lines_dev, a.n_lines) : a.n_lines) * r) return;
+  geo_point_wave(a, (int)(w / r), a.j_begin + (int)(w % r));
 }
 
 // dPdrho of each line: -0.5 mean((cvdrift - gbdrift) bmag^2)   (ball_scan.py:262)

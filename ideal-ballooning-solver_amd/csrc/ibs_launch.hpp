@@ -44,6 +44,7 @@ struct GradArgs {
 
 // field-line geometry kernel (ibs_geometry.hip)
 struct GeoForm { int ppl, lpp; };   // grid points per lane, lanes per grid point (one of them is 1)
+constexpr int kGeoMaxPairs = 64;    // pair indices about a row's centre the one-lane-per-point table image holds for the root solve
 struct GeoArgs {
   int n_surf, mnmax, mnmax_nyq, n_lines, N;
   const double *xm, *xn, *xm_nyq, *xn_nyq;

@@ -66,6 +66,17 @@ class _Args:
             raise IbsError("mixing host (numpy) and device (torch.cuda) arrays in one call is not supported")
 
 
+
+def _device_key(device):
+    """'cuda:<index>' for every spelling of one device (torch.device('cuda'), 'cuda', 'cuda:0', a tensor's .device): the
+    key of the resident copies a table set keeps per device, so that an upload under one spelling is found under another"""
+    import torch
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
 class Context:
     def __init__(self, device=0):
         self._lib = _lib.lib()
@@ -360,7 +371,7 @@ class Context:
         """the surface/mode/row tables of `tables` resident on `device` (uploaded once, cached on the object)"""
         import torch
         cache = tables.__dict__.setdefault("_device_copies", {})
-        key = str(device)
+        key = _device_key(device)
         if key not in cache:
             host = [tables.xm, tables.xn, tables.xm_nyq, tables.xn_nyq, tables.tab_mn, tables.tab_nyq, tables.scal]
             cache[key] = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in host + [tables.rows_mn, tables.rows_nyq]]
@@ -372,7 +383,7 @@ class Context:
         For callers that fill a frame piece by piece while earlier pieces are already being worked on."""
         import torch
         cache = tables.__dict__.setdefault("_device_copies", {})
-        key = str(device)
+        key = _device_key(device)
         if key not in cache:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
             e = lambda a: torch.empty(a.shape, dtype=torch.float64, device=device)
@@ -413,7 +424,7 @@ class Context:
         # the grid and the point -> surface map rarely change between calls: their device copies are kept on the tables
         # object, keyed by content; the start points go up in one copy, the results come back in one
         cache = tables.__dict__.setdefault("_refine_inputs", {})
-        key = (str(device), th.tobytes(), ps.tobytes())
+        key = (_device_key(device), th.tobytes(), ps.tobytes())
         if key not in cache:
             cache.clear()
             cache[key] = (torch.from_numpy(ps).to(device), torch.from_numpy(th).to(device))

@@ -225,7 +225,11 @@ int ibs_hf_grad_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, const double* X, con
  *   dPdrho[n_lines] (optional): -0.5 mean((cvdrift - gbdrift) bmag^2), ball_scan.py:262.
  *   rows_mn [nrows_mn][2], rows_nyq [nrows_nyq][2] (optional, nrows = 0 to omit): {first mode, count} of each
  *   run of modes with equal m and n advancing by the common step dn_mn / dn_nyq (= nfp in VMEC's own
- *   ordering); enables the rotation-recurrence kernel (no sincos per mode).
+ *   ordering); enables the rotation-recurrence kernels (no sincos per mode).  Every row must lie inside its mode list
+ *   (else IBS_ERR_ARG).  The row kernels hold at most 64 pair indices about a row's centre -- the mode with n = 0 if the
+ *   row has one, else its first mode: rows of up to 129 modes n = -64 dn .. 64 dn, or up to 65 modes otherwise; tables
+ *   with a longer row in rows_mn are valid and run on the one-sincos-per-mode kernel (split such rows to stay on the fast
+ *   path: ibs_amd.geometry.mode_rows does).  Device-resident rows are copied back and checked once per table set.
  * The first seven planes of geo and dPdrho are exactly the inputs of ibs_gamma_scan_f64. */
 int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm,
                                const double* xn, const double* xm_nyq, const double* xn_nyq, const double* tab_mn,

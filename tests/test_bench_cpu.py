@@ -17,7 +17,7 @@ def test_pmc_counters_are_quoted_for_the_exact_kernel_and_batch_size_only(monkey
     """the headline quoted the counters of k_gamma_scan<double, 16> (first key with the prefix).  A leg may
     only quote the entry of EXACTLY its kernel whose launches held the leg's number of waves and were all alike."""
     import bench
-    table = {"_set": "test",
+    table = {"_set": "test", "_src_sha": bench.src_sha(),
              "ibs::k_gamma_scan<double, 16> @460800x256": _entry("ibs::k_gamma_scan<double, 16>", 1800, 1.35e7),
              "ibs::k_gamma_scan<double, 8> @65536x256": _entry("ibs::k_gamma_scan<double, 8>", 1024, 6.0e6),
              "ibs::k_gamma_scan<double, 8> @131072x256": _entry("ibs::k_gamma_scan<double, 8>", 2048, 1.2e7),
@@ -46,14 +46,101 @@ def test_pmc_counters_are_quoted_for_the_exact_kernel_and_batch_size_only(monkey
 
 
 def test_committed_pmc_file_serves_the_headline_kernel():
-    """profiles/pmc_current.json as committed: the headline kernel's entry is found by exact name at 1,024 waves, and its
-    traffic is within 2x of the algorithmic 3.69 MB (the round-3 line quoted 7.3 MB from another kernel)."""
+    """profiles/pmc_current.json as committed: if it was taken on THIS tree's kernel sources the headline kernel's entry is
+    found by exact name at 1,024 waves and its traffic is within 1.5x of the algorithmic 3.69 MB (the round-3 line quoted
+    7.3 MB from another kernel); if the sources have changed since, the lookup must say "stale" instead of serving it."""
+    import json
     import bench
-    if hasattr(bench._pmc_file, "cache"):
-        del bench._pmc_file.cache
+    for attr in ("cache",):
+        if hasattr(bench._pmc_file, attr):
+            delattr(bench._pmc_file, attr)
+    if hasattr(bench.src_sha, "tree"):
+        del bench.src_sha.tree
+    d = json.load(open(bench.PMC_FILE))
     e, why = bench.pmc_entry("ibs::k_gamma_scan<double, 8>", 1024)
-    assert why is None, why
-    assert 3.6e6 < e["hbm_bytes_per_launch"] < 5.5e6
+    if (d.get("_src_sha") or {}).get("solver") == bench.src_sha()["solver"]:
+        assert why is None, why
+        assert 3.6e6 < e["hbm_bytes_per_launch"] < 5.5e6
+    else:
+        assert e is None and why.startswith("stale"), why
+
+
+def test_stale_or_unattributed_counters_are_not_replayed(monkeypatch):
+    """VERDICT r4 weak 8 / ADVICE r4: a PMC set taken before the kernel sources changed is refused (`counters_error` "stale...",
+    `traffic` null -- per kernel group: a geometry edit does not stale the solver's entries), and a set whose byte passes could
+    not be matched launch by launch keeps its instruction counts but withholds `traffic`."""
+    import bench
+    sha = bench.src_sha()
+    assert set(sha) == {"geometry", "solver"} and all(len(v) == 16 for v in sha.values())
+    monkeypatch.setattr(bench.src_sha, "tree", sha, raising=False)
+    table = {"_set": "t", "_src_sha": dict(sha, geometry="0" * 16),
+             "ibs::k_gamma_scan<double, 8> @65536x256 #0": _entry("ibs::k_gamma_scan<double, 8>", 1024, 6.0e6),
+             "ibs::k_geo_rows<2, 1, 12> @131072x512 #0": _entry("ibs::k_geo_rows<2, 1, 12>", 2048, 1.6e8)}
+    monkeypatch.setattr(bench._pmc_file, "cache", table, raising=False)
+    assert bench.pmc_entry("ibs::k_gamma_scan<double, 8>", 1024)[1] is None
+    e, why = bench.pmc_entry("ibs::k_geo_rows<2, 1, 12>", 2048)
+    assert e is None and why.startswith("stale")
+    r = bench.hbm_roofline(1.0e6, 0.5, "valu_issue", "ibs::k_geo_rows<2, 1, 12>", 2048)
+    assert r["traffic"] is None and r["counters_error"].startswith("stale") and "valu_issue" not in r
+    assert bench.compact_roofline(r)["counters"] == "none:stale"
+    table["_src_sha"] = None                                   # a set from before the guard existed: stale as well
+    assert bench.pmc_entry("ibs::k_gamma_scan<double, 8>", 1024)[1].startswith("stale")
+    table["_src_sha"] = sha
+    table["_unmatched_launches_of_the_byte_passes"] = 3
+    r = bench.hbm_roofline(3686400, 0.025, "valu_issue", "ibs::k_gamma_scan<double, 8>", 1024)
+    assert r["traffic"] is None and "traffic_over_algorithmic" not in r and r["counters_error"].startswith("unmatched")
+    assert r["valu_issue"]["frac"] > 0 and "withheld" in bench.compact_roofline(r)["counters"]
+
+
+def test_the_stdout_line_fits_the_drivers_capture():
+    """the round-4 line was 40.5 KB, the driver keeps ~8 KB and BENCH_r04.json.parsed was null.  The line
+    assembled from a full recorded run (profiles/r04c_bench.json: every N = 1 leg) and from a 2-rank run stays under 6,000
+    bytes, is one line, parses, and still holds the contract's keys, `roofline`, `cpu_baseline` and one summary per leg."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04c_bench.json")))
+    assert len(json.dumps(full)) > 30000
+    line = bench.compact_line(full)
+    assert len(line) < bench.LINE_LIMIT == 6000 and "\n" not in line
+    o = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_reference_cost", "parity_ok", "max_abs_dgam_vs_oracle",
+              "stress", "stress_rough", "sturm_sweep", "scan_large", "ncsx_c3", "reference_batch", "c4_adjoint_step", "c5_matrix",
+              "dropin_call_us"):
+        assert k in o, k
+    assert o["value"] == full["value"] and o["ms_per_step"] == full["ms_per_step"]            # the headline is not rounded
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "valu_issue_frac", "counters"):
+        assert k in o["roofline"], k
+    assert set(o["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert "dropped_for_length" not in o
+    c5 = o["c5_matrix"]
+    assert len(c5["rows"]) == 24 and all(len(r) == len(c5["cols"]) for r in c5["rows"])
+    r0 = full["c5_matrix"]["rows"][0]
+    assert c5["rows"][0][:3] == [256, "s", "f64"] and abs(c5["rows"][0][3] / r0["solves_per_s"] - 1) < 1e-3
+    assert c5["kernels"][c5["rows"][0][7]] == r0["roofline"]["kernel"]
+    assert o["c4_adjoint_step"]["parity_ok"] is True and abs(o["c4_adjoint_step"]["total_ms"] / full["c4_adjoint_step"]["total_ms"] - 1) < 1e-4
+    # a 2-rank line (profiles/r04_rehearsal_2rank.json): the sharded legs keep their flags
+    two = next(json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r04_rehearsal_2rank.json")) if l.startswith("{"))
+    o2 = json.loads(bench.compact_line(two))
+    assert o2["config"]["ranks_in_collective"] == 2 and o2["ncsx_c2_sharded"]["checks_passed"] is True
+    assert o2["c4_adjoint_step_sharded"]["checks_passed"] is True and len(bench.compact_line(two)) < 6000
+    # whatever a future leg adds, the bound holds: legs are dropped in a stated order, the contract's keys never
+    fat = dict(full, future_leg={"rows": [{"x": float(i), "name": "k" * 40} for i in range(400)]})
+    fl = bench.compact_line(fat)
+    assert len(fl) <= 6000 and {"value", "roofline", "cpu_baseline", "c4_adjoint_step"} <= set(json.loads(fl))
+    assert json.loads(fl)["dropped_for_length"] == ["future_leg"] and "c5_matrix" in json.loads(fl)
+
+
+def test_emit_writes_detail_file_and_one_stdout_line(tmp_path, monkeypatch, capsys):
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04c_bench.json")))
+    monkeypatch.setattr(bench, "DETAIL_FILE", str(tmp_path / "bench_detail.json"))
+    bench.emit(full)
+    cap = capsys.readouterr()
+    assert cap.out.count("\n") == 1 and json.loads(cap.out)["value"] == full["value"]
+    assert json.load(open(tmp_path / "bench_detail.json")) == full
+    assert cap.err.startswith("bench.py detail: ") and json.loads(cap.err[len("bench.py detail: "):]) == full
 
 
 def test_pmc_summary_splits_launches_into_work_classes(tmp_path):

@@ -1,0 +1,157 @@
+"""GPU, round 5: the mode-row limit of the geometry row kernels at the C ABI, and the multi-rank code of the
+FINAL tree under the driver's `pytest -m gpu`: `bench.py --gpus 2` as fresh child processes sharing the one
+GPU of the box -- the sharded legs, the gather, the compact line -- and the watchdog when a rank dies."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ibs_amd
+    c = ibs_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _wout_with_a_long_row(nmax):
+    """the shipped equilibrium with its m = 0 row of the first mode list extended to n = 0 .. nmax nfp (small coefficients
+    on the added modes: a data manipulation for shape coverage, both sides evaluate the same formulas)"""
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    xm, xn = wout["xm"], wout["xn"]
+    nfp = int(np.min(np.abs(xn[xn != 0])))
+    have = set(zip(xm.astype(int).tolist(), xn.astype(int).tolist()))
+    extra = [(0, n * nfp) for n in range(nmax + 1) if (0, n * nfp) not in have]
+    em = np.array([e[0] for e in extra], dtype=float); en = np.array([e[1] for e in extra], dtype=float)
+    order = np.lexsort((np.concatenate([xn, en]), np.concatenate([xm, em])))
+    rng = np.random.default_rng(3)
+    prof = np.linspace(0, 1, wout["rmnc"].shape[1]) ** 2
+    w = dict(wout)
+    for k in ("rmnc", "zmns", "lmns"):
+        add = 1e-5 * np.abs(wout[k]).max() * rng.standard_normal((len(extra), 1)) * prof[None, :] / (1.0 + np.abs(en[:, None]) / nfp)
+        w[k] = np.concatenate([wout[k], add])[order]
+    w["xm"], w["xn"] = np.concatenate([xm, em])[order], np.concatenate([xn, en])[order]
+    return w
+
+
+def test_geometry_rows_longer_than_the_table_image(ctx):
+    """the one-lane-per-point image holds 64 pair indices for the root solve; a caller's row with more
+    (here: m = 0 with n = 0 .. 70 nfp as ONE row of 71 modes) used to write past the image.  Now: host tables and
+    device-resident tables with such a row run on the one-sincos-per-mode kernel and agree with the numpy oracle; the same
+    tables with the row split (mode_rows' default) stay on the row kernels; rows outside the mode list are an argument error;
+    and device-resident rows REWRITTEN IN PLACE behind the library's per-table check give NaN lines, not a fault."""
+    import torch
+    import ibs_amd
+    from ibs_amd.geometry import mode_rows
+    from oracle import geometry_oracle as go
+    w = _wout_with_a_long_row(70)
+    svals = np.array([0.4, 0.85])
+    otab = go.surface_tables_from_wout(w, svals)
+    dev = torch.device("cuda:0")
+    N = 513; th = ibs_amd.theta_grid(N)
+    surf = np.array([0, 1, 1, 0], dtype=np.int32); al = np.array([0.2, 1.4, 2.6, 3.1])
+    ref = np.stack([go.fieldline_geometry(otab, int(s), np.array([a]), th)[0] for s, a in zip(surf, al)])      # (lines, 8, N)
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    nl = 600                                                               # enough lines for a one-lane-per-point form
+    s2 = (np.arange(nl) % 2).astype(np.int32); a2 = np.linspace(0, np.pi, nl)
+    s2[:4] = surf; a2[:4] = al
+
+    split = ibs_amd.SurfaceTables.from_wout(w, svals)                      # rows of at most 64 modes: the fast path
+    assert split.rows_mn[:, 1].max() <= 64
+    r = ctx.fieldline_geometry(split, s2, a2, th, device=dev)
+    assert "k_geo_rows" in ctx.last_launch()[0], ctx.last_launch()
+    assert (np.abs(r["geo"][:, :4].cpu().numpy().transpose(1, 0, 2) - ref) / scale).max() < 1e-10
+
+    long_ = ibs_amd.SurfaceTables.from_wout(w, svals)
+    long_.rows_mn, long_.dn_mn = mode_rows(long_.xm, long_.xn, max_len=1000)
+    assert long_.rows_mn[:, 1].max() == 71
+    for device in (None, dev):                                             # host pointers, device pointers
+        r = ctx.fieldline_geometry(long_, surf, al, th, device=device)
+        assert ctx.last_launch()[0] == "ibs::k_fieldline_geometry", ctx.last_launch()
+        got = (r["geo"].cpu().numpy() if device is not None else r["geo"]).transpose(1, 0, 2)
+        assert (np.abs(got - ref) / scale).max() < 1e-10
+    # the refinement takes the same tables (its geometry goes through the same check)
+    xo, fo, ne, rounds = ctx.refine(long_, np.array([0, 1], dtype=np.int32), np.array([[1.0, 0.5], [2.0, 0.3]]), th, device=dev)
+    xs, fs, _, _ = ctx.refine(split, np.array([0, 1], dtype=np.int32), np.array([[1.0, 0.5], [2.0, 0.3]]), th, device=dev)
+    assert np.all(np.isfinite(fo)) and np.abs(fo - fs).max() < 1e-9
+
+    bad = ibs_amd.SurfaceTables.from_wout(w, svals)
+    bad.rows_mn = bad.rows_mn.copy(); bad.rows_mn[-1, 1] += 5              # runs past the end of the mode list
+    with pytest.raises(ibs_amd.IbsError, match="outside"):
+        ctx.fieldline_geometry(bad, surf, al, th)
+    with pytest.raises(ibs_amd.IbsError, match="outside"):
+        ctx.fieldline_geometry(bad, surf, al, th, device=dev)
+
+    # second line of defence: rows changed in place after the library has checked this table set
+    sneak = ibs_amd.SurfaceTables.from_wout(w, svals)
+    r = ctx.fieldline_geometry(sneak, s2, a2, th, device=dev)
+    name = ctx.last_launch()[0]
+    assert "k_geo_rows<2, 1," in name or "k_geo_rows<1, 1," in name, name
+    assert torch.isfinite(r["geo"]).all()
+    d_rows = ctx._device_tables(sneak, dev)[7]
+    merged = torch.from_numpy(np.ascontiguousarray(mode_rows(sneak.xm, sneak.xn, max_len=1000)[0]))
+    assert len(merged) < len(sneak.rows_mn)
+    keep = d_rows.clone()
+    d_rows[:len(merged)] = merged.to(dev)                                  # first row now 71 modes; the library is not told
+    d_rows[len(merged):, 0] = 0; d_rows[len(merged):, 1] = 1               # (surplus rows: valid one-mode rows)
+    r = ctx.fieldline_geometry(sneak, s2, a2, th, device=dev)
+    torch.cuda.synchronize()
+    assert torch.isnan(r["geo"][:, :, :512]).all()                        # flagged by k_geo_prepare, NaN from k_geo_rows
+    d_rows.copy_(keep)
+    r = ctx.fieldline_geometry(sneak, s2, a2, th, device=dev)
+    assert torch.isfinite(r["geo"]).all()
+
+
+def _bench(args, env_extra, timeout):
+    env = dict(os.environ, IBS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    return p, time.time() - t0
+
+
+def test_two_ranks_share_the_gpu_through_bench(tmp_path):
+    """`python bench.py --gpus 2` on the one-GPU box (IBS_BENCH_SHARE_GPU=1: both ranks on device 0, collectives through
+    gloo -- RCCL refuses two ranks on one device): the parent spawns fresh rank processes (this pytest process only waits),
+    the headline's per-step gather and the three sharded legs run on two ranks and check themselves against one rank, the
+    ONE stdout line parses, is under 6,000 bytes and says so."""
+    detail = tmp_path / "detail.json"
+    p, dt = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-stress"], {"IBS_BENCH_DETAIL": str(detail)}, 900)
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 6000
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["config"]["ranks_in_collective"] == 2 and o["config"]["allgather_roundtrip_ok"] is True
+    for leg in ("ncsx_c2_sharded", "ncsx_c2_sharded_refined", "c4_adjoint_step_sharded"):
+        assert o[leg]["checks_passed"] is True, (leg, o[leg])
+    assert o["ncsx_c2_sharded"]["gathered_equals_one_gpu_bitwise"] is True
+    assert o["value"] > 0 and "roofline" in o and "dropped_for_length" not in o
+    full = json.load(open(detail))
+    assert full["value"] == o["value"] and full["c4_adjoint_step_sharded"]["checks_passed"] is True
+    print("2 ranks on one GPU: %.0f s; c2 sharded %.2f ms / pass, c4 sharded %.2f ms / step" % (
+        dt, o["ncsx_c2_sharded"]["ms_per_pass"], o["c4_adjoint_step_sharded"]["ms_per_step"]))
+
+
+def test_a_dying_rank_ends_the_run_nonzero():
+    """rank 1 kills itself (IBS_BENCH_DIE_RANK / _AFTER: a test hook in bench.py) inside the first sharded leg, while rank 0
+    waits in that leg's collective: the parent notices the dead child, stops the other rank and leaves non-zero -- well
+    inside the watchdog period (300 s), not after a hang."""
+    p, dt = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-stress"],
+                   {"IBS_BENCH_DIE_RANK": "1", "IBS_BENCH_DIE_AFTER": "headline"}, 600)
+    assert p.returncode != 0, p.stdout[-1000:]
+    assert dt < 300, dt
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) <= 1                         # (rank 0 may or may not have got its headline line out; never two)

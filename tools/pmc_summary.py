@@ -87,9 +87,17 @@ for key, v in acc.items():
     out[key] = e
 out["_set"] = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(dst).replace("_pmc.json", "")
 out["_unmatched_launches_of_the_byte_passes"] = mismatch
+# the sources the counted kernels were compiled from (bench.src_sha): bench.py refuses to replay an entry once its kernel
+# group's sources differ from this ("stale"); IBS_PMC_SRC_ROOT = the csrc directory of the tree the passes ran on
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+out["_src_sha"] = bench.src_sha(os.environ.get("IBS_PMC_SRC_ROOT"))
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 for k in sorted(out):
     v = out[k]
-    if isinstance(v, dict):
+    if isinstance(v, dict) and not k.startswith("_"):
         print("%-72s n %3d waves %9.0f valu/wave %8.0f traffic %s" % (k, v.get("SQ_WAVES", {}).get("n", 0), v.get("SQ_WAVES", {}).get("mean", 0),
                                                                       v.get("valu_insts_per_wave", 0), v.get("hbm_bytes_per_launch")))
+if mismatch:
+    sys.exit("pmc_summary: %d launches of the byte passes could not be matched to the SQ pass's work classes; bench.py will "
+             "withhold `traffic` for this set" % mismatch)

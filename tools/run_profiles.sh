@@ -18,8 +18,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 cd $R
 cp $OUT/kt_refine/refine_kernel_stats.csv $OUT/${TAG}_kernel_stats_refine.csv
 python tools/kt_timeline.py $OUT/kt_refine > $OUT/${TAG}_refine_timeline.txt
-python tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc.json $TAG > /dev/null
-python tools/pmc_summary.py $OUT/pmc_refine $OUT/${TAG}_pmc_refine.json $TAG > /dev/null
+# (pmc_summary leaves non-zero when the byte passes could not be matched launch by launch: the set is written, bench.py withholds `traffic`)
+python tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc.json $TAG > $OUT/pmc_summary.txt || echo "pmc_summary: unmatched byte passes (see $OUT/pmc_summary.txt)"
+python tools/pmc_summary.py $OUT/pmc_refine $OUT/${TAG}_pmc_refine.json $TAG > /dev/null || true
 cp $OUT/kt/bench_kernel_stats.csv $OUT/${TAG}_kernel_stats_bench.csv
-timeout -k 10 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+# the plain run quotes the counters just taken: the new set becomes profiles/pmc_current.json for it (copy both into profiles/ to keep them)
+cp $OUT/${TAG}_pmc.json profiles/pmc_current.json
+IBS_BENCH_DETAIL=$OUT/${TAG}_bench_detail.json timeout -k 10 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+wc -c $OUT/${TAG}_bench.json
 head -12 $OUT/${TAG}_kernel_stats_bench.csv
