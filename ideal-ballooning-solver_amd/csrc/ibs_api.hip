@@ -62,6 +62,7 @@ struct ibs_options {
   int scan_chain = 0;     // theta0 values chained through one wave / group
   int geo_lpp = 0;        // lanes per grid point of the geometry kernel: 1 | 2 | 4
   int gcf_rows = -1;      // raw systems on long grids: -1 / 1 = row-streamed kernel, 0 = the 3-row staging of k_solve_gcf
+  int gcf_direct = -1;    // raw systems, one wave per system: rows read straight from global memory (k_solve_gcf_direct): -1 = by batch size, 0 = never, 1 = always
   int pack_mode = 0;      // hand-off of the fused scan + argmax: 1 = write-through + sc1 loads, 2 = release / acquire fences
   int f32_lam = 0;        // FP32 eigenvalue-only requests: 0 = by grid size, 1 = all-FP32 iteration + FP64 certificate, 2 = FP32 in HBM + FP64 solver
   int refine_tangent = -1; // refinement: alpha-tangent of a point staged in LDS (1) or read from global memory in the sums (0); -1 = by batch size
@@ -265,6 +266,18 @@ __global__ void k_scan_starts(int n_surf, int n_alpha, int n_theta0, const doubl
   if (sigma0) sigma0[s] = sg;
 }
 
+// One wave per system on a long grid: k_solve_gcf's three staged rows are 24.6 KB of LDS per wave at N = 1025 -- five waves
+// per CU where the registers admit eight.  A batch that fills the chip at more waves than the staging admits reads its rows
+// straight from global memory instead (k_solve_gcf_direct: no LDS).  Option gcf_direct: -1 = this rule, 0 = never, 1 = always.
+static bool use_direct(const ibs_ctx* ctx, int N, long n_sys, int M) {
+  if (ctx->opt.gcf_direct == 0) return false;
+  if (ctx->opt.gcf_direct == 1) return true;
+  // (measured, tools/bench_direct.py, 2^19 systems: 1.45-1.65 x the staged / row-streamed kernels at N_zeta = 768 .. 1536, 1.2-1.3 x at 2048)
+  const long staged_waves_per_cu = (long)(ctx->lds_per_block / ((size_t)3 * ibs::lds_pitch(N) * sizeof(double)));
+  (void)M;
+  return staged_waves_per_cu < 8 && n_sys > (staged_waves_per_cu > 4 ? staged_waves_per_cu : 4) * ctx->n_cu;
+}
+
 template <typename T>
 int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, const T* c, const T* f, int64_t ld,
                    T* lam, T* gam, T* X, T* dX, int32_t* info, int32_t mem,
@@ -305,6 +318,8 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
       } else {
         auto fr = ibs::launch_table().gcf_f32w_rows[M];
         if (fr && ctx->opt.gcf_rows != 0) { launch = fr; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(double); }
+        auto fd = ibs::launch_table().gcf_direct_f32w[M];
+        if (fd && use_direct(ctx, N, (long)n_sys, M)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(double); }
       }
     }
   }
@@ -313,6 +328,8 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     // 3-row staging of k_solve_gcf leaves two waves per CU at N_zeta = 2048 and five at 1024
     auto fr = ibs::launch_table().gcf_rows_f64[M];
     if (!gh && launch == table[M] && fr && ctx->opt.gcf_rows != 0) { launch = fr; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(T); }
+    auto fd = ibs::launch_table().gcf_direct_f64[M];
+    if (!gh && (launch == table[M] || launch == fr) && fd && use_direct(ctx, N, (long)n_sys, M)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(T); }
   }
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
@@ -466,6 +483,7 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   else if (n == "scan_chain") c->opt.scan_chain = reset ? c->opt_created.scan_chain : (int)value;
   else if (n == "geo_lpp") c->opt.geo_lpp = reset ? c->opt_created.geo_lpp : (int)value;
   else if (n == "gcf_rows") c->opt.gcf_rows = reset ? c->opt_created.gcf_rows : (int)value;
+  else if (n == "gcf_direct") c->opt.gcf_direct = reset ? c->opt_created.gcf_direct : (int)value;
   else if (n == "pack_mode") c->opt.pack_mode = reset ? c->opt_created.pack_mode : (int)value;
   else if (n == "f32_lam") c->opt.f32_lam = reset ? c->opt_created.f32_lam : (int)value;
   else if (n == "refine_tangent") c->opt.refine_tangent = reset ? c->opt_created.refine_tangent : (int)value;

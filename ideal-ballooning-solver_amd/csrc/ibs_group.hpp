@@ -509,9 +509,9 @@ struct GroupSolver {
     // keeps re-evaluating the frozen shift while the wave's other groups finish), so the forward solution is already in place; only
     // a wave that left on the iteration cap holds a shift it has not swept yet.  (Until round 4 every solve paid one more forward
     // sweep here: 1 of 11.)
-    // (it == 0: every group of the wave was flagged before the first sweep -- the sweep still runs once, so that the backward
+    // (guard == 0: every group of the wave was flagged before the first sweep -- the sweep still runs once, so that the backward
     // sweep and the outputs of such systems are built from written state and repeat bit for bit)
-    if (__any(!done) || it == 0) sweep_fwd<true>(sig);
+    if (__any(!done) || guard == 0) sweep_fwd<true>(sig);
     sweep_bwd(sig);
     const T rho = twisted(sig);
     iters_out = it;

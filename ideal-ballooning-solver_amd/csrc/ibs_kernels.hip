@@ -421,6 +421,53 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   }
 }
 
+// ---------------------------------------------------------------- raw (g, c, f) systems, rows straight from global memory
+// Large batches on long grids (round 5).  k_solve_gcf stages the three rows of its system in LDS: 24.6 KB per wave at
+// N_zeta = 1024, i.e. FIVE waves per CU where the registers (198 at M = 16) admit eight -- the FP64 pipe ran at 0.47 of
+// its issue rate.  Here every lane reads its own chunk of M consecutive rows of g, c, f directly (a lane's chunk is M x 8
+// contiguous bytes; the 64 chunks of a wave tile the row, so every fetched line is used in full, by the one lane that
+// owns it), once in setup() and once more in the growth-rate stage (L2 / Infinity Cache), like the sub-wave kernels do
+// at 32 / 16 lanes per system.  No LDS at all unless X / dX are requested (then one row per wave).
+// TI = float: FP32 in HBM, widened exactly as read, FP64 solver (the arithmetic of k_solve_gcf_wide).
+template <typename T, typename TI>
+struct SrcDirect {
+  static constexpr bool kHasGh = false;
+  const TI* gg; const TI* cg; const TI* fg;
+  __device__ __forceinline__ T g(int j) const { return (T)gg[j]; }
+  __device__ __forceinline__ T c(int j) const { return (T)cg[j]; }
+  __device__ __forceinline__ T f(int j) const { return (T)fg[j]; }
+  __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { g_ = (T)gg[j]; c_ = (T)cg[j]; f_ = (T)fg[j]; }
+};
+template <typename T, int M, typename TI>
+__global__ void __launch_bounds__(256) k_solve_gcf_direct(long n_sys, int N, T h, const TI* __restrict__ g,
+                                                          const TI* __restrict__ c, const TI* __restrict__ f, long ld,
+                                                          TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const long sys = (long)blockIdx.x * wpb + wave;
+  const bool valid = sys < n_sys;
+  const long sysc = valid ? sys : (n_sys - 1);
+  T* Xs = (X_out || dX_out) ? reinterpret_cast<T*>(smem_raw) + (size_t)wave * lds_pitch(N) : nullptr;
+  SrcDirect<T, TI> src{g + sysc * ld, c + sysc * ld, f + sysc * ld};
+  WaveSolver<T, M> ws;
+  SolveInfo inf{0, 0};
+  const bool bad = ws.template setup<SrcDirect<T, TI>, true>(src, N, h);
+  T lam = T(0);
+  if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
+  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  if (!gam_out && !X_out && !dX_out) {     // (kernel-uniform) eigenvalues only
+    if (lane == 0 && valid) {
+      if (lam_out) lam_out[sysc] = (TI)lam;
+      if (info_out) info_out[sysc] = inf.iters | (inf.status << 16);
+    }
+    return;
+  }
+  finish_chunk<T, M, SrcDirect<T, TI>, false, 1, TI>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                                     valid ? gam_out : nullptr, valid ? X_out : nullptr,
+                                                     valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
+}
+
 // FP32 systems whose growth rate (or eigenfunction) is wanted: FP32 in HBM, FP64 in the solver.  The FD4 / Simpson growth rate
 // subtracts two sums of size ||A|| ~ 4 / h^2, so an FP32 eigenvector's noise is multiplied by ~N^2 (usable at N_zeta <= 512,
 // noise above: round 2); the rows are therefore widened while they are staged -- exactly: every float is a double -- and the
@@ -1401,6 +1448,25 @@ static hipError_t launch_gcf_wide(const GcfArgs<float>& a, hipStream_t st) {
   note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_wide<%d>", IBS_M);
   return hipGetLastError();
 }
+template <typename TI>
+static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
+  if constexpr (IBS_M >= 9) {
+    const int wpb = 4;
+    const size_t lds = (a.X || a.dX) ? (size_t)wpb * lds_pitch(a.N) * sizeof(double) : 0;
+    const long nblk = (a.n_sys + wpb - 1) / wpb;
+    auto kern = k_solve_gcf_direct<double, IBS_M, TI>;
+    if (lds) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, (double)a.h, a.g, a.c, a.f, a.ld,
+                       a.lam, a.gam, a.X, a.dX, a.info);
+    note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_direct<double, %d, %s>", IBS_M, type_name<TI>());
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
 template <typename T>
 static hipError_t launch_gcf_rows(const GcfArgs<T>& a, hipStream_t st) {
   if constexpr (IBS_M >= 3) {
@@ -1518,6 +1584,13 @@ struct IBS_CAT(Registrar, IBS_M) {
     t.gcf_rows_f64[IBS_M] = &launch_gcf_rows<double>;
 #ifdef IBS_WITH_F32
     t.gcf_f32w_rows[IBS_M] = &launch_gcf_rows_wide;
+#endif
+#endif
+#if IBS_M >= 9
+    // N > 578: big batches read their rows straight from global memory (no LDS staging: occupancy is the registers')
+    t.gcf_direct_f64[IBS_M] = &launch_gcf_direct<double>;
+#ifdef IBS_WITH_F32
+    t.gcf_direct_f32w[IBS_M] = &launch_gcf_direct<float>;
 #endif
 #endif
     t.scan_f64[IBS_M] = &launch_scan<double>;

@@ -100,10 +100,11 @@ int ibs_comm_destroy(ibs_ctx* ctx);
  * name: "force_p" (lanes per system 64|32|16), "scan_chain" (theta0 values chained through one wave),
  * "chain_w1" / "chain_w2" (relative widths of the chain's warm starts), "geo_lpp" (lanes per grid point of the
  * geometry kernel 1|2|4|8, or -2 = two grid points per lane), "gcf_rows" (0: three-row staging instead of the row-streamed raw
- * kernel on long grids), "f32_lam" (FP32 eigenvalue-only requests: 1 = all-FP32 iteration + FP64 certificate, 2 = FP64 solver on
+ * kernel on long grids), "gcf_direct" (raw systems, one wave per system: rows read straight from global memory instead of staged in LDS; -1 = by
+ * batch size, 0 = never, 1 = always), "f32_lam" (FP32 eigenvalue-only requests: 1 = all-FP32 iteration + FP64 certificate, 2 = FP64 solver on
  * the FP32 arrays; 0 = by grid size), "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
  * staged in LDS, 1, or read from global memory by the sums, 0: two blocks per CU instead of one at N = 969; -1 = by batch size);
- * value 0 = automatic (refine_tangent: -1); value NaN = back to what ibs_create() read from the environment
+ * value 0 = automatic (refine_tangent, gcf_direct: -1); value NaN = back to what ibs_create() read from the environment
  * (IBS_FORCE_P, IBS_SCAN_CHAIN, IBS_CHAIN_W1, IBS_CHAIN_W2, IBS_GEO_LPP are read once, there); name "all" with NaN
  * resets every option.  Results never depend on these switches beyond rounding; only the kernel variant does. */
 int ibs_set_option(ibs_ctx* ctx, const char* name, double value);

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
+from bench import c5_family, norm_a  # noqa: E402  (the synthetic inputs of configs[4] live with the bench)
 
 
 @pytest.fixture(scope="module")
@@ -155,3 +156,73 @@ def test_a_dying_rank_ends_the_run_nonzero():
     assert dt < 300, dt
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) <= 1                         # (rank 0 may or may not have got its headline line out; never two)
+
+
+@pytest.mark.parametrize("N", [969, 1025, 2049, 643])
+def test_rows_straight_from_global_memory_agree_with_the_staged_kernels(ctx, N):
+    """k_solve_gcf_direct (round 5: one wave per system, every lane reads its chunk of g, c, f from global memory; no LDS, so the
+    registers set the occupancy) against the LDS-staged kernels it replaces for big batches on long grids: the same solver on
+    the same numbers -- lam agrees to the certified bracket, gam / X / dX of the smooth family to 1e-10 / 1e-7, FP64 and
+    FP32-with-growth-rate, eigenvalue-only calls, a flagged system included;
+    a sample against the C oracle (utils.py:1550-1624 restated)."""
+    import torch
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    n = 3000
+    h, g, c, f = c5_family(dev, "rough", n, N, seed=77 + N)
+    hs, gs, cs, fs = c5_family(dev, "smooth", n, N, seed=78 + N)
+    g = torch.cat([g, gs]); c = torch.cat([c, cs]); f = torch.cat([f, fs])
+    f[17, N // 2] = -1.0                                                   # an invalid system: flagged (status 2), neighbours untouched
+    out = {}
+    for direct in (0, 1):
+        ctx.set_option("gcf_direct", direct)
+        out[direct] = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
+        name = ctx.last_launch()[0]
+        assert ("k_solve_gcf_direct" in name) == (direct == 1), name
+        out[direct, "f32"] = ctx.solve_gcf(h, g.float(), c.float(), f.float(), want_info=True, dtype=np.float32)
+        assert ("k_solve_gcf_direct" in ctx.last_launch()[0]) == (direct == 1), ctx.last_launch()
+        out[direct, "lam"] = ctx.solve_gcf(h, g, c, f, want_gam=False)      # eigenvalues only
+    ctx.set_option("gcf_direct", None)
+    a, b = out[0], out[1]
+    ok = torch.ones(2 * n, dtype=torch.bool, device=dev); ok[17] = False
+    assert int((b["info"][17] >> 16)) == 2 and int(((b["info"][ok] >> 16) != 0).sum()) == 0
+    assert int((a["info"][17] >> 16)) == 2 and int(((a["info"][ok] >> 16) != 0).sum()) == 0
+    # Two compilations of one solver: the shift iterations agree to the certified bracket (4 x 64 eps ||A||), not bit for bit (the
+    # compiler contracts multiply-adds of the set-up differently around LDS reads and around global loads), and on the rough
+    # family the counts of the scan-form recurrence are certificates for a matrix perturbed by ~N eps (tests/test_gpu_configs.py).
+    nA_all = norm_a(h, g, c, torch.where(f > 0, f, torch.ones_like(f)))
+    smooth_rows = torch.arange(2 * n, device=dev) >= n
+    rel = (a["lam"] - b["lam"]).abs() / nA_all
+    print("N = %d: lam bitwise equal on %.1f %% of the systems, max |dlam| / ||A|| %.1e (smooth %.1e)" % (
+        N, 100.0 * float((a["lam"][ok] == b["lam"][ok]).double().mean()), float(rel[ok].max()), float(rel[ok & smooth_rows].max())))
+    assert float(rel[ok & smooth_rows].max()) < 1e-13 and float(rel[ok].max()) < max(1e-11, 1e-13 * N) * 2
+    assert float(((out[0, "lam"]["lam"] - b["lam"]).abs() / nA_all)[ok].max()) < max(1e-11, 1e-13 * N) * 2
+    assert float(((out[1, "lam"]["lam"] - b["lam"]).abs() / nA_all)[ok].max()) < max(1e-11, 1e-13 * N) * 2
+    sm = ok & smooth_rows                                                  # growth rate / eigenfunction: pinned on the smooth family (SURVEY H4)
+    assert float((a["gam"][sm] - b["gam"][sm]).abs().max()) < 1e-10
+    assert float((a["X"][sm] - b["X"][sm]).abs().max()) < 1e-7 and float((a["dX"][sm] - b["dX"][sm]).abs().max()) < 1e-6
+    a32, b32 = out[0, "f32"], out[1, "f32"]
+    assert float(((a32["lam"].double() - b32["lam"].double()).abs() / nA_all)[ok].max()) < 1e-6
+    assert float((a32["gam"][sm].double() - b32["gam"][sm].double()).abs().max()) < 1e-6
+    pick = np.array([0, 1, 5, 100, n - 1, n, n + 3, 2 * n - 1])
+    pk = torch.from_numpy(pick).to(dev)
+    gam_c, lam_c, _ = co.solve_gcf_batch(h, g[pk].cpu().numpy(), c[pk].cpu().numpy(), f[pk].cpu().numpy())
+    nA = norm_a(h, g[pk], c[pk], f[pk]).cpu().numpy()
+    assert (np.abs(b["lam"][pk].cpu().numpy() - lam_c) / nA).max() < 1e-11
+    smooth = pick >= n                                                     # (the growth rate is pinned on the smooth family: SURVEY H4)
+    assert np.abs(b["gam"][pk].cpu().numpy() - gam_c)[smooth].max() < 1e-8
+
+
+def test_direct_form_is_what_big_batches_on_long_grids_get(ctx):
+    """the dispatch rule (ibs_api.hip use_direct): N = 1025, one wave per system -- a batch beyond what the three-row staging holds
+    in flight (5 waves per CU) runs k_solve_gcf_direct, a small one keeps the staged kernel (coalesced staging = lower latency)"""
+    import torch
+    dev = torch.device("cuda:0")
+    N = 1025
+    h, g, c, f = c5_family(dev, "smooth", 8192, N, seed=5)
+    ctx.solve_gcf(h, g, c, f)
+    assert "k_solve_gcf_direct<double, 16, double>" in ctx.last_launch()[0], ctx.last_launch()
+    ctx.solve_gcf(h, g[:512], c[:512], f[:512])
+    assert "k_solve_gcf<double, 16>" in ctx.last_launch()[0], ctx.last_launch()
+    ctx.solve_gcf(h, g.float(), c.float(), f.float(), dtype=np.float32)
+    assert "k_solve_gcf_direct<double, 16, float>" in ctx.last_launch()[0], ctx.last_launch()
