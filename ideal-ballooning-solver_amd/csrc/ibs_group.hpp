@@ -254,15 +254,22 @@ struct GroupSolver {
     // (sign changes counted from ONE incoming pair per lane; the step into the next lane's first row belongs to that
     //  lane: see WaveSolver::sweep_fwd)
     const int ncount = (has_last ? M : M - 1) - (lg == P - 1 ? 0 : 1);
-    int count = sign_differs(u0, um) ? 1 : 0;                  // first lane of a group: (1, 0), no change
+    // The sign bits of um, u0, z_1 .. z_M are shifted into ONE word (v_alignbit: one instruction per row instead of the xor /
+    // compare / add of a per-row test); the sign changes are the set bits of bits ^ (bits >> 1) under the mask of the steps
+    // this lane counts: step i (z_i -> z_{i+1}) sits at bit M - 1 - i, the incoming pair (um -> u0; the first lane of a group
+    // holds (0, 1): no change) at bit M.  Steps M - 2 and M - 1 count only if i < ncount.
+    static_assert(M + 2 <= 32, "sign word");
+    unsigned bits = (unsigned)__builtin_amdgcn_alignbit(sign_word(um) >> 31, sign_word(u0), 31);
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const T t = xfma(-sig, Ph[i], D[i]);
       const bool act = (i < M - 1) || has_last;
       const T zn = xfma(-t, zc, -zp);
-      count += ((i < M - 2 || i < ncount) && sign_differs(zn, zc)) ? 1 : 0;
+      bits = (unsigned)__builtin_amdgcn_alignbit(bits, sign_word(zn), 31);     // (bits << 1) | sign(zn)
       if (act) { zp = zc; zc = zn; }
     }
+    const unsigned valid = ((1u << (M + 1)) - 1u) & ~((ncount < M ? 1u : 0u) | (ncount < M - 1 ? 2u : 0u));
+    const int count = __builtin_popcount((bits ^ (bits >> 1)) & valid);
     return GP::sum_i(count, lane);
   }
 

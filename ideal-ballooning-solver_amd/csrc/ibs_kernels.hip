@@ -841,6 +841,12 @@ __global__ void __launch_bounds__(scan_max_threads(M)) k_gamma_scan(int n_lines,
   SrcGeo<T> src{A1, A3, C0, C1, G0, G1, G2, th0, T(2) * th0, th0 * th0};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
+#ifdef IBS_PROBE_TWICE
+  // experiment (round 5, tools/scan_probe.py): the set-up executed twice, the first result discarded -- is its time the code's
+  // first execution (instruction fetch) or its dependent chains?  stamp 15 = end of the first execution.  (Answer: the chains.)
+  { int N2 = N; asm volatile("" : "+s"(N2)); WaveSolver<T, M> w0; (void)w0.template setup<SrcGeo<T>, true>(src, N2, h); asm volatile("" :: "v"(w0.kap), "v"(w0.D[0]), "v"(w0.Ph[M - 1]), "v"(w0.trial_rho)); }
+  IBS_PROBE_AT(15);
+#endif
   const bool bad = ws.template setup<SrcGeo<T>, true>(src, N, h);
   IBS_PROBE_AT(2);
   T lam = T(0);

@@ -62,6 +62,9 @@ __device__ __forceinline__ bool sign_differs(double a, double b) {
   return x < 0;
 }
 __device__ __forceinline__ bool sign_differs(float a, float b) { return (__float_as_int(a) ^ __float_as_int(b)) < 0; }
+// the 32-bit word that carries the sign bit (bit 31)
+__device__ __forceinline__ unsigned sign_word(double a) { return (unsigned)__double2hiint(a); }
+__device__ __forceinline__ unsigned sign_word(float a) { return (unsigned)__float_as_int(a); }
 __device__ __forceinline__ bool finite_of(double a) { return xabs(a) <= 1.7976931348623157e308; }
 __device__ __forceinline__ bool finite_of(float a) { return xabs(a) <= 3.4028234e38f; }
 

@@ -18,8 +18,12 @@ w = b[ok]                                        # (waves, 16)
 t0 = w[:, 0].min()
 us = lambda x: x * 0.01
 print("waves stamped: %d; kernel span (first start -> last end) %.2f us; start skew max %.2f us" % (len(w), us(w[:, 4].max() - t0), us(w[:, 0].max() - t0)))
-names = [("staging + barrier", 0, 1), ("set-up + trial vector", 1, 2), ("shift iteration", 2, 10), ("backward sweep", 10, 11),
-         ("twisted + polish", 11, 12), ("growth rate", 3, 4), ("whole wave", 0, 4)]
+twice = bool((w[:, 15] > 0).any())                 # (-DIBS_PROBE_TWICE build: the set-up ran twice, stamp 15 after the first)
+names = [("staging + barrier", 0, 1)] + ([("set-up, FIRST execution", 1, 15), ("set-up, second: rows", 15, 8), ("set-up, second: sums", 8, 9)] if twice else
+         [("set-up: row loop", 1, 8), ("set-up: bounds, trial sums", 8, 9)]) + [
+         ("set-up + trial vector", 15 if twice else 1, 2), ("shift iteration", 2, 10), ("backward sweep", 10, 11),
+         ("twisted + polish", 11, 12), ("growth: assemble, halo", 3, 13), ("growth: Simpson rows", 13, 14), ("growth: sums, division", 14, 4),
+         ("growth rate", 3, 4), ("whole wave", 0, 4)]
 for nm, a, c in names:
     d = us(w[:, c] - w[:, a])
     print("   %-24s median %6.2f  min %6.2f  max %6.2f us" % (nm, np.median(d), d.min(), d.max()))
