@@ -76,6 +76,10 @@ struct ibs_ctx {
   // staging workspace for IBS_MEM_HOST calls (grown on demand, reused)
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  // page-locked mirror of the first hs_bytes of ws: small host-pointer calls pack their inputs / outputs into it and move
+  // them with ONE copy each way (HostStage)
+  void* hs = nullptr;
+  size_t hs_bytes = 0;
   int lds_per_block = 160 * 1024;
   int n_cu = 256;
   // native RCCL communicator of this rank (ibs_comm_init), null = none
@@ -153,6 +157,61 @@ int ensure_ws(ibs_ctx* c, size_t bytes) {
   c->ws_bytes = bytes;
   return 0;
 }
+
+// Small host-pointer calls (the drop-in gamma_ball_full: one system, ~70 KB in, ~16 KB out) spent most of their 0.17-0.22 ms
+// in a dozen pageable hipMemcpyAsync of a few KB each (every one staged and waited for by the runtime).  HostStage mirrors the
+// device arena in page-locked host memory: up() copies a source into the mirror at its device offset, flush_in() moves the
+// whole input span with ONE copy; down() records an output, flush_out() brings the output span back with ONE copy, waits for
+// the stream and hands the pieces to the caller's buffers.  Calls whose arena exceeds kMaxBytes take the direct copies.
+struct HostStage {
+  static constexpr size_t kMaxBytes = 4u << 20;
+  ibs_ctx* c; bool on = false;
+  size_t in_lo = ~size_t(0), in_hi = 0, out_lo = ~size_t(0), out_hi = 0;
+  struct Piece { void* dst; size_t off, bytes; };
+  std::vector<Piece> outs;
+  HostStage(ibs_ctx* c_, size_t need) : c(c_) {
+    if (need > kMaxBytes) return;
+    if (c->hs_bytes < need) {
+      if (c->hs) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->hs); c->hs = nullptr; c->hs_bytes = 0; }
+      const size_t want = need < (256u << 10) ? (256u << 10) : need;
+      if (hipHostMalloc(&c->hs, want, hipHostMallocDefault) != hipSuccess) { c->hs = nullptr; (void)hipGetLastError(); return; }
+      c->hs_bytes = want;
+    }
+    on = true;
+  }
+  size_t off_of(const void* dev) const { return (size_t)(static_cast<const char*>(dev) - static_cast<const char*>(c->ws)); }
+  hipError_t up(const void* src, size_t bytes, void* dev) {
+    if (!on) return hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, c->stream);
+    const size_t o = off_of(dev);
+    std::memcpy(static_cast<char*>(c->hs) + o, src, bytes);
+    if (o < in_lo) in_lo = o;
+    if (o + bytes > in_hi) in_hi = o + bytes;
+    return hipSuccess;
+  }
+  hipError_t flush_in() {
+    if (!on || in_hi <= in_lo) return hipSuccess;
+    return hipMemcpyAsync(static_cast<char*>(c->ws) + in_lo, static_cast<char*>(c->hs) + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, c->stream);
+  }
+  hipError_t down(void* dst, const void* dev, size_t bytes) {
+    if (!on) return hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+    const size_t o = off_of(dev);
+    outs.push_back(Piece{dst, o, bytes});
+    if (o < out_lo) out_lo = o;
+    if (o + bytes > out_hi) out_hi = o + bytes;
+    return hipSuccess;
+  }
+  // ends with the stream synchronised and every recorded output in the caller's memory
+  hipError_t flush_out() {
+    if (on && out_hi > out_lo) {
+      hipError_t e = hipMemcpyAsync(static_cast<char*>(c->hs) + out_lo, static_cast<char*>(c->ws) + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, c->stream);
+      if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e;
+    for (const Piece& p : outs) std::memcpy(p.dst, static_cast<char*>(c->hs) + p.off, p.bytes);
+    return hipSuccess;
+  }
+};
 
 int check_grid(int32_t N, double h) {
   if (N < 66 || N > 64 * ibs::kMaxM + 2) return fail(IBS_ERR_UNSUPPORTED, "N=%d outside [66, %d]", N, 64 * ibs::kMaxM + 2);
@@ -346,31 +405,31 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
                   pad256(n_sys * sizeof(int)) + 4096;
     if (int r = ensure_ws(ctx, need)) return r;
     Arena ar(ctx);
+    HostStage hs(ctx, need);
     T* dg = ar.take<T>(in_elems); T* dc = ar.take<T>(in_elems); T* df = ar.take<T>(in_elems);
+    T* dgh = gh ? ar.take<T>(in_elems) : nullptr;
     T* dlam = ar.take<T>(n_sys); T* dgam = ar.take<T>(n_sys);
     T* dX_ = X ? ar.take<T>(out_elems) : nullptr; T* ddX = dX ? ar.take<T>(out_elems) : nullptr;
     d_info = ar.take<int>(n_sys); d_nbad = ar.take<int>(1);
-    HIPCHK(hipMemcpyAsync(dg, g, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dc, c, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(df, f, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hs.up(g, in_elems * sizeof(T), dg));
+    HIPCHK(hs.up(c, in_elems * sizeof(T), dc));
+    HIPCHK(hs.up(f, in_elems * sizeof(T), df));
+    if (gh) HIPCHK(hs.up(gh, in_elems * sizeof(T), dgh));
+    HIPCHK(hs.flush_in());
     // (gam not asked for: the kernels then take their eigenvalue-only exits, as they do for device-pointer calls)
     a.g = dg; a.c = dc; a.f = df; a.lam = dlam; a.gam = gam ? dgam : nullptr; a.X = dX_; a.dX = ddX; a.info = d_info;
-    if (gh) {
-      T* dgh = ar.take<T>(in_elems);
-      HIPCHK(hipMemcpyAsync(dgh, gh, in_elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-      a.gh = dgh;
-    }
+    if (gh) a.gh = dgh;
     HIPCHK(launch(a, ctx->stream));
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
-    if (lam) HIPCHK(hipMemcpyAsync(lam, dlam, n_sys * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    if (gam) HIPCHK(hipMemcpyAsync(gam, dgam, n_sys * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    if (X) HIPCHK(hipMemcpyAsync(X, dX_, out_elems * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    if (dX) HIPCHK(hipMemcpyAsync(dX, ddX, out_elems * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    if (info) HIPCHK(hipMemcpyAsync(info, d_info, n_sys * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (lam) HIPCHK(hs.down(lam, dlam, n_sys * sizeof(T)));
+    if (gam) HIPCHK(hs.down(gam, dgam, n_sys * sizeof(T)));
+    if (X) HIPCHK(hs.down(X, dX_, out_elems * sizeof(T)));
+    if (dX) HIPCHK(hs.down(dX, ddX, out_elems * sizeof(T)));
+    if (info) HIPCHK(hs.down(info, d_info, n_sys * sizeof(int)));
     int nbad = 0;
-    HIPCHK(hipMemcpyAsync(&nbad, d_nbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hs.down(&nbad, d_nbad, sizeof(int)));
+    HIPCHK(hs.flush_out());
     return nbad;
   }
   a.g = g; a.c = c; a.f = f; a.lam = lam; a.gam = gam; a.X = X; a.dX = dX; a.info = info; a.gh = gh;
@@ -465,6 +524,7 @@ int ibs_destroy(ibs_ctx* c) {
   if (c->ws) hipFree(c->ws);
   for (auto& sc : c->surf_counters) if (sc.buf) hipFree(sc.buf);
   if (c->refine_hist) hipHostFree(c->refine_hist);
+  if (c->hs) hipHostFree(c->hs);
   delete c;
   return 0;
 }
@@ -806,37 +866,37 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
                   2 * pad256(out_elems * 8) + pad256(n_sys * 4) + 8192;
     if (int r = ensure_ws(ctx, need)) return r;
     Arena ar(ctx);
+    HostStage hs(ctx, need);
     const double* src[7] = {bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22};
     double* dev[7];
     for (int k = 0; k < 7; ++k) {
       dev[k] = ar.take<double>(in_elems);
-      HIPCHK(hipMemcpyAsync(dev[k], src[k], in_elems * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hs.up(src[k], in_elems * 8, dev[k]));
     }
     double* ddP = ar.take<double>(n_lines); double* dt0 = ar.take<double>(n_t0_vals);
-    HIPCHK(hipMemcpyAsync(ddP, dPdrho, (size_t)n_lines * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dt0, theta0, n_t0_vals * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hs.up(dPdrho, (size_t)n_lines * 8, ddP));
+    HIPCHK(hs.up(theta0, n_t0_vals * 8, dt0));
+    double* dguess = lam_guess ? ar.take<double>(n_sys) : nullptr;
+    if (lam_guess) HIPCHK(hs.up(lam_guess, n_sys * 8, dguess));
+    HIPCHK(hs.flush_in());
     double* dgam = ar.take<double>(n_sys); double* dlam = ar.take<double>(n_sys); double* dd = ar.take<double>(n_sys);
     double* dX_ = X ? ar.take<double>(out_elems) : nullptr; double* ddX = dX ? ar.take<double>(out_elems) : nullptr;
     int* d_info = ar.take<int>(n_sys); int* d_nbad = ar.take<int>(1);
     a.bmag = dev[0]; a.gradpar = dev[1]; a.cvdrift = dev[2]; a.cvdrift0 = dev[3]; a.gds2 = dev[4]; a.gds21 = dev[5]; a.gds22 = dev[6];
     a.dPdrho = ddP; a.theta0 = dt0; a.gam = dgam; a.lam = dlam; a.X = dX_; a.dX = ddX; a.dth0 = dth0 ? dd : nullptr; a.info = d_info;
-    if (lam_guess) {
-      double* dguess = ar.take<double>(n_sys);
-      HIPCHK(hipMemcpyAsync(dguess, lam_guess, n_sys * 8, hipMemcpyHostToDevice, ctx->stream));
-      a.lam_guess = dguess; a.guess_width = guess_width;
-    }
+    if (lam_guess) { a.lam_guess = dguess; a.guess_width = guess_width; }
     HIPCHK(fn(a, ctx->stream));
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
-    if (gam) HIPCHK(hipMemcpyAsync(gam, dgam, n_sys * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (lam) HIPCHK(hipMemcpyAsync(lam, dlam, n_sys * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (dth0) HIPCHK(hipMemcpyAsync(dth0, dd, n_sys * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (X) HIPCHK(hipMemcpyAsync(X, dX_, out_elems * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (dX) HIPCHK(hipMemcpyAsync(dX, ddX, out_elems * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (info) HIPCHK(hipMemcpyAsync(info, d_info, n_sys * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (gam) HIPCHK(hs.down(gam, dgam, n_sys * 8));
+    if (lam) HIPCHK(hs.down(lam, dlam, n_sys * 8));
+    if (dth0) HIPCHK(hs.down(dth0, dd, n_sys * 8));
+    if (X) HIPCHK(hs.down(X, dX_, out_elems * 8));
+    if (dX) HIPCHK(hs.down(dX, ddX, out_elems * 8));
+    if (info) HIPCHK(hs.down(info, d_info, n_sys * 4));
     int nbad = 0;
-    HIPCHK(hipMemcpyAsync(&nbad, d_nbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hs.down(&nbad, d_nbad, sizeof(int)));
+    HIPCHK(hs.flush_out());
     return nbad;
   }
   a.bmag = bmag; a.gradpar = gradpar; a.cvdrift = cvdrift; a.cvdrift0 = cvdrift0; a.gds2 = gds2; a.gds21 = gds21; a.gds22 = gds22;
@@ -955,18 +1015,20 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
     double* dgeo = ar.take<double>(geo_elems); double* dt0 = ar.take<double>(n_pts);
     double* dval = ar.take<double>(n_pts); double* djac = ar.take<double>((size_t)2 * n_pts);
     int* d_nbad = ar.take<int>(1);
-    HIPCHK(hipMemcpyAsync(dgeo, geo, geo_elems * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dt0, theta0, (size_t)n_pts * 8, hipMemcpyHostToDevice, ctx->stream));
+    HostStage hs(ctx, need);
+    HIPCHK(hs.up(geo, geo_elems * 8, dgeo));
+    HIPCHK(hs.up(theta0, (size_t)n_pts * 8, dt0));
+    HIPCHK(hs.flush_in());
     a.geo = dgeo; a.theta0 = dt0; a.val = dval; a.jac = djac; a.info = d_info;
     HIPCHK(fn(a, ctx->stream));
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_pts, d_info, d_nbad);
-    HIPCHK(hipMemcpyAsync(val, dval, (size_t)n_pts * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(jac, djac, (size_t)n_pts * 16, hipMemcpyDeviceToHost, ctx->stream));
-    if (info) HIPCHK(hipMemcpyAsync(info, d_info, (size_t)n_pts * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hs.down(val, dval, (size_t)n_pts * 8));
+    HIPCHK(hs.down(jac, djac, (size_t)n_pts * 16));
+    if (info) HIPCHK(hs.down(info, d_info, (size_t)n_pts * 4));
     int nbad = 0;
-    HIPCHK(hipMemcpyAsync(&nbad, d_nbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hs.down(&nbad, d_nbad, sizeof(int)));
+    HIPCHK(hs.flush_out());
     return nbad;
   }
   a.geo = geo; a.theta0 = theta0; a.val = val; a.jac = jac; a.info = info ? info : d_info;
