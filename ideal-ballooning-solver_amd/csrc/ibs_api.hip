@@ -1006,7 +1006,7 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
   const size_t geo_elems = (size_t)n_pts * 3 * 8 * ld;
   const bool host = (mem == IBS_MEM_HOST);
   size_t need = 3 * pad256((size_t)n_pts * 8) + pad256((size_t)n_pts * 4) + 4096;
-  if (host) need += pad256(geo_elems * 8) + pad256((size_t)n_pts * 8) * 2 + pad256((size_t)n_pts * 16) + 4096;
+  if (host) need += pad256(geo_elems * 8) + pad256((size_t)n_pts * 8) * 2 + pad256((size_t)n_pts * 16) + pad256((size_t)n_pts * 4) + 4096;
   if (int r = ensure_ws(ctx, need)) return r;
   Arena ar(ctx);
   a.gam = ar.take<double>(n_pts); a.dalpha = ar.take<double>(n_pts); a.dth0 = ar.take<double>(n_pts);
@@ -1014,18 +1014,19 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
   if (host) {
     double* dgeo = ar.take<double>(geo_elems); double* dt0 = ar.take<double>(n_pts);
     double* dval = ar.take<double>(n_pts); double* djac = ar.take<double>((size_t)2 * n_pts);
+    int* d_info_h = ar.take<int>(n_pts);            // (behind the inputs: the outputs come back as one contiguous span)
     int* d_nbad = ar.take<int>(1);
     HostStage hs(ctx, need);
     HIPCHK(hs.up(geo, geo_elems * 8, dgeo));
     HIPCHK(hs.up(theta0, (size_t)n_pts * 8, dt0));
     HIPCHK(hs.flush_in());
-    a.geo = dgeo; a.theta0 = dt0; a.val = dval; a.jac = djac; a.info = d_info;
+    a.geo = dgeo; a.theta0 = dt0; a.val = dval; a.jac = djac; a.info = d_info_h;
     HIPCHK(fn(a, ctx->stream));
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_pts, d_info, d_nbad);
+    hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_pts, d_info_h, d_nbad);
     HIPCHK(hs.down(val, dval, (size_t)n_pts * 8));
     HIPCHK(hs.down(jac, djac, (size_t)n_pts * 16));
-    if (info) HIPCHK(hs.down(info, d_info, (size_t)n_pts * 4));
+    if (info) HIPCHK(hs.down(info, d_info_h, (size_t)n_pts * 4));
     int nbad = 0;
     HIPCHK(hs.down(&nbad, d_nbad, sizeof(int)));
     HIPCHK(hs.flush_out());
