@@ -56,7 +56,11 @@ def test_config5_fp64_one_million_systems(ctx, nz, family):
     #  non-monotone counts sit at the upper end of that)
     # measured on the worst (non-monotone) systems of the rough family: 1e-11 ||A|| up to N_zeta = 1024, 1.1e-10 ||A|| at 2048
     # (iid-random coefficients: ||A|| ~ 3e6 with lam ~ 2e-3, i.e. the problem itself is conditioned like 1e9)
-    tol = max(1e-11, 1e-13 * N)
+    # round 5: the same band holds for both one-wave-per-system forms (LDS-staged rows / rows straight from global memory:
+    # tests/tools/direct_vs_staged_accuracy.py, 2^18 rough systems at N_zeta = 1024: worst 5.1e-11 / 7.2e-11 ||A|| on the systems
+    # where the two differ most, 3e-14 / 7e-15 on a random sample); which system of 10^6 is the worst depends on the kernel, the
+    # first 64 non-monotone ones reached 1.5e-10 ||A|| with the direct form -> 2e-13 N
+    tol = max(1e-11, 2e-13 * N)
     assert (np.abs(lam[pk].cpu().numpy() - lam_c) / nA[pk].cpu().numpy()).max() < tol
     if family == "smooth":                  # well separated top eigenvalue: the growth rate is pinned too
         assert np.abs(r["gam"][pk].cpu().numpy() - gam_c).max() < 1e-8
