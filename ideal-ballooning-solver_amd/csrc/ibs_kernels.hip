@@ -439,9 +439,9 @@ struct SrcDirect {
   __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { g_ = (T)gg[j]; c_ = (T)cg[j]; f_ = (T)fg[j]; }
 };
 template <typename T, int M, typename TI>
-__global__ void __launch_bounds__(256) k_solve_gcf_direct(long n_sys, int N, T h, const TI* __restrict__ g,
-                                                          const TI* __restrict__ c, const TI* __restrict__ f, long ld,
-                                                          TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
+__device__ __forceinline__ void solve_gcf_direct_body(long n_sys, int N, T h, const TI* __restrict__ g, const TI* __restrict__ c,
+                                                      const TI* __restrict__ f, long ld, TI* lam_out, TI* gam_out, TI* X_out,
+                                                      TI* dX_out, int* info_out) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -466,6 +466,24 @@ __global__ void __launch_bounds__(256) k_solve_gcf_direct(long n_sys, int N, T h
   finish_chunk<T, M, SrcDirect<T, TI>, false, 1, TI>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                                      valid ? gam_out : nullptr, valid ? X_out : nullptr,
                                                      valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
+}
+template <typename T, int M, typename TI>
+__global__ void __launch_bounds__(256) k_solve_gcf_direct(long n_sys, int N, T h, const TI* __restrict__ g,
+                                                          const TI* __restrict__ c, const TI* __restrict__ f, long ld,
+                                                          TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
+  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out);
+}
+// The same kernel held to two waves per SIMD (256 registers).  The allocator left to itself takes AGPRs from M = 21 on (one wave
+// per SIMD, `valu_issue` 0.39-0.53); capped, M = 21 .. 28 spill 12-232 B per lane and still gain: FP64 rows 1.17-1.5x (N_zeta =
+// 1344 .. 1792), FP32 rows 1.5x up to M = 30.  Beyond that the spills cost more than the second wave brings (N_zeta = 2048: 384 B
+// of scratch, 0.77x; with the backward solution moved to LDS to relieve the tail: 0.66x -- the spills are the shift iteration's,
+// not the tail's), so M = 29+ (FP32 rows: 31+) keep one wave per SIMD.   tools/bench_direct.py, docs/EXPERIMENTS.md R5.6
+constexpr bool direct_two_waves(int M, bool f32_rows) { return M >= 21 && M <= (f32_rows ? 30 : 28); }
+template <typename T, int M, typename TI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_solve_gcf_direct_w2(long n_sys, int N, T h, const TI* __restrict__ g, const TI* __restrict__ c, const TI* __restrict__ f, long ld,
+                      TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
+  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out);
 }
 
 // FP32 systems whose growth rate (or eigenfunction) is wanted: FP32 in HBM, FP64 in the solver.  The FD4 / Simpson growth rate
@@ -1460,14 +1478,17 @@ static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
     const int wpb = 4;
     const size_t lds = (a.X || a.dX) ? (size_t)wpb * lds_pitch(a.N) * sizeof(double) : 0;
     const long nblk = (a.n_sys + wpb - 1) / wpb;
-    auto kern = k_solve_gcf_direct<double, IBS_M, TI>;
+    constexpr bool w2 = direct_two_waves(IBS_M, sizeof(TI) == 4);
+    void (*kern)(long, int, double, const TI*, const TI*, const TI*, long, TI*, TI*, TI*, TI*, int*);
+    if constexpr (w2) kern = k_solve_gcf_direct_w2<double, IBS_M, TI>;      // (only the form that runs is instantiated)
+    else kern = k_solve_gcf_direct<double, IBS_M, TI>;
     if (lds) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, (double)a.h, a.g, a.c, a.f, a.ld,
                        a.lam, a.gam, a.X, a.dX, a.info);
-    note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_direct<double, %d, %s>", IBS_M, type_name<TI>());
+    note_launch(nblk, wpb * 64, w2 ? "ibs::k_solve_gcf_direct_w2<double, %d, %s>" : "ibs::k_solve_gcf_direct<double, %d, %s>", IBS_M, type_name<TI>());
     return hipGetLastError();
   } else {
     return hipErrorInvalidValue;

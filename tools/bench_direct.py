@@ -16,7 +16,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 19
 dev = torch.device("cuda", 0)
 ctx = ibs_amd.Context(0)
 print("%6s %-7s %-7s | %-44s %9s | %-44s %9s | ratio  max|dlam| max|dgam|" % ("N_zeta", "family", "mode", "staged kernel", "solves/s", "direct kernel", "solves/s"))
-for nz in (768, 1024, 1536, 2048):
+for nz in [int(v) for v in os.environ.get("IBS_NZ", "768,1024,1536,2048").split(",")]:
     N = nz + 1
     for family in ("smooth", "rough"):
         h, g, c, f = bench.c5_family(dev, family, n, N, seed=20240 + nz)
