@@ -380,6 +380,10 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
         auto fd = ibs::launch_table().gcf_direct_f32w[M];
         if (fd && use_direct(ctx, N, (long)n_sys, M)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(double); }
       }
+    } else {
+      // eigenvalues only, all-FP32 iteration + FP64 certificate: big batches on long grids read their rows from global memory
+      auto fl = ibs::launch_table().gcf_direct_f32lam[M];
+      if (!gh && fl && use_direct(ctx, N, (long)n_sys, M)) launch = fl;
     }
   }
   if constexpr (sizeof(T) == 8) {

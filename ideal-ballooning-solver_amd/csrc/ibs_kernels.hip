@@ -486,6 +486,62 @@ k_solve_gcf_direct_w2(long n_sys, int N, T h, const TI* __restrict__ g, const TI
   solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out);
 }
 
+// FP32 eigenvalues only, rows straight from global memory: the all-FP32 shift iteration of k_solve_gcf<float, M> and its FP64
+// certificate (count 0 at lam32 + n eps32 ||A||, >= 1 at lam32 - n eps32 ||A||; a system that fails it is solved in FP64,
+// informational status bit 2), every lane reading its own chunk of the three FP32 rows -- once for the FP32 set-up, once more
+// (widened, exactly) for the certificate's.  No LDS: k_solve_gcf<float, M> stages 27.7 KB per wave at N_zeta = 2048.
+template <int M>
+__device__ __forceinline__ void solve_gcf_f32lam_direct_body(long n_sys, int N, float h, const float* __restrict__ g,
+                                                             const float* __restrict__ c, const float* __restrict__ f, long ld,
+                                                             float* lam_out, int* info_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const long sys = (long)blockIdx.x * wpb + wave;
+  const bool valid = sys < n_sys;
+  const long sysc = valid ? sys : (n_sys - 1);
+  SolveInfo inf{0, 0};
+  float lam = 0.0f;
+  bool bad;
+  {
+    SrcDirect<float, float> src{g + sysc * ld, c + sysc * ld, f + sysc * ld};
+    WaveSolver<float, M> ws;
+    bad = ws.template setup<SrcDirect<float, float>, false>(src, N, h);
+    if (!bad) lam = ws.solve(inf);
+    else inf.status = 2;
+  }
+  if (!bad) {
+    SrcDirect<double, float> srcw{g + sysc * ld, c + sysc * ld, f + sysc * ld};
+    WaveSolver<double, M> wd;
+    const bool bad2 = wd.template setup<SrcDirect<double, float>, true>(srcw, N, (double)h);
+    const double tolc = (double)(N - 2) * (double)Eps<float>::v * wd.normA;
+    bool ok = !bad2 && wd.sweep_fwd((double)lam + tolc) == 0;
+    if (ok) ok = wd.sweep_fwd((double)lam - tolc) >= 1;
+    if (!ok && !bad2) {                                  // (wave-uniform)
+      SolveInfo inf2{0, 0};
+      double g_, w_;
+      wd.trial_guess(g_, w_);
+      lam = (float)wd.solve(inf2, true, g_, w_);
+      inf.iters += inf2.iters + 2; inf.status |= inf2.status | 4;
+    } else inf.iters += 2;
+  }
+  if (lane == 0 && valid) {
+    if (lam_out) lam_out[sysc] = lam;
+    if (info_out) info_out[sysc] = inf.iters | (inf.status << 16);
+  }
+}
+template <int M>
+__global__ void __launch_bounds__(256) k_solve_gcf_f32lam_direct(long n_sys, int N, float h, const float* __restrict__ g,
+                                                                 const float* __restrict__ c, const float* __restrict__ f, long ld,
+                                                                 float* lam_out, int* info_out) {
+  solve_gcf_f32lam_direct_body<M>(n_sys, N, h, g, c, f, ld, lam_out, info_out);
+}
+template <int M>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_solve_gcf_f32lam_direct_w2(long n_sys, int N, float h, const float* __restrict__ g, const float* __restrict__ c,
+                             const float* __restrict__ f, long ld, float* lam_out, int* info_out) {
+  solve_gcf_f32lam_direct_body<M>(n_sys, N, h, g, c, f, ld, lam_out, info_out);
+}
+
 // FP32 systems whose growth rate (or eigenfunction) is wanted: FP32 in HBM, FP64 in the solver.  The FD4 / Simpson growth rate
 // subtracts two sums of size ||A|| ~ 4 / h^2, so an FP32 eigenvector's noise is multiplied by ~N^2 (usable at N_zeta <= 512,
 // noise above: round 2); the rows are therefore widened while they are staged -- exactly: every float is a double -- and the
@@ -1494,6 +1550,25 @@ static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
     return hipErrorInvalidValue;
   }
 }
+#ifdef IBS_WITH_F32
+// the occupancy cap pays where the allocator would otherwise take AGPRs (one wave per SIMD): checked per M in the resource table
+constexpr bool f32lam_two_waves(int M) { return M >= 21 && M <= 30; }   // (M = 32: 4.4 against 5.7e7 solves/s capped against free, rough family; tools/bench_f32lam.py)
+static hipError_t launch_gcf_f32lam_direct(const GcfArgs<float>& a, hipStream_t st) {
+  if constexpr (IBS_M >= 9) {
+    const int wpb = 4;
+    const long nblk = (a.n_sys + wpb - 1) / wpb;
+    constexpr bool w2 = f32lam_two_waves(IBS_M);
+    void (*kern)(long, int, float, const float*, const float*, const float*, long, float*, int*);
+    if constexpr (w2) kern = k_solve_gcf_f32lam_direct_w2<IBS_M>;
+    else kern = k_solve_gcf_f32lam_direct<IBS_M>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), 0, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld, a.lam, a.info);
+    note_launch(nblk, wpb * 64, w2 ? "ibs::k_solve_gcf_f32lam_direct_w2<%d>" : "ibs::k_solve_gcf_f32lam_direct<%d>", IBS_M);
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+#endif
 template <typename T>
 static hipError_t launch_gcf_rows(const GcfArgs<T>& a, hipStream_t st) {
   if constexpr (IBS_M >= 3) {
@@ -1618,6 +1693,7 @@ struct IBS_CAT(Registrar, IBS_M) {
     t.gcf_direct_f64[IBS_M] = &launch_gcf_direct<double>;
 #ifdef IBS_WITH_F32
     t.gcf_direct_f32w[IBS_M] = &launch_gcf_direct<float>;
+    t.gcf_direct_f32lam[IBS_M] = &launch_gcf_f32lam_direct;
 #endif
 #endif
     t.scan_f64[IBS_M] = &launch_scan<double>;

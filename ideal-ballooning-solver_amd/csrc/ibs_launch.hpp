@@ -88,6 +88,7 @@ struct LaunchTable {
   hipError_t (*gcf_rows_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);   // row-streamed form (k_solve_gcf_rows)
   hipError_t (*gcf_direct_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);  // rows straight from global memory (k_solve_gcf_direct)
   hipError_t (*gcf_direct_f32w[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);  // the same on FP32 arrays (FP64 solver)
+  hipError_t (*gcf_direct_f32lam[kMaxM + 1])(const GcfArgs<float>&, hipStream_t); // FP32 eigenvalues only: all-FP32 iteration + FP64 certificate, rows from global memory
   hipError_t (*gcf_f32[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);
   hipError_t (*gcf_f32_wide[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);   // FP32 in HBM, FP64 in the solver (gam / X wanted)
   hipError_t (*gcf_f32w_rows[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);  // the same, row-streamed (long grids)

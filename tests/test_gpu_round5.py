@@ -182,6 +182,10 @@ def test_rows_straight_from_global_memory_agree_with_the_staged_kernels(ctx, N):
         out[direct, "f32"] = ctx.solve_gcf(h, g.float(), c.float(), f.float(), want_info=True, dtype=np.float32)
         assert ("k_solve_gcf_direct" in ctx.last_launch()[0]) == (direct == 1), ctx.last_launch()
         out[direct, "lam"] = ctx.solve_gcf(h, g, c, f, want_gam=False)      # eigenvalues only
+        ctx.set_option("f32_lam", 1)                                        # FP32 eigenvalues only: all-FP32 iteration + FP64 certificate
+        out[direct, "lam32"] = ctx.solve_gcf(h, g.float(), c.float(), f.float(), want_gam=False, want_info=True, dtype=np.float32)
+        assert ("k_solve_gcf_f32lam_direct" in ctx.last_launch()[0]) == (direct == 1), ctx.last_launch()
+        ctx.set_option("f32_lam", None)
     ctx.set_option("gcf_direct", None)
     a, b = out[0], out[1]
     ok = torch.ones(2 * n, dtype=torch.bool, device=dev); ok[17] = False
@@ -204,6 +208,14 @@ def test_rows_straight_from_global_memory_agree_with_the_staged_kernels(ctx, N):
     a32, b32 = out[0, "f32"], out[1, "f32"]
     assert float(((a32["lam"].double() - b32["lam"].double()).abs() / nA_all)[ok].max()) < 1e-6
     assert float((a32["gam"][sm].double() - b32["gam"][sm].double()).abs().max()) < 1e-6
+    # FP32 eigenvalues alone: every result of both forms within (N_zeta + 4) eps32 ||A|| of the FP64 solve of the same FP32-valued systems
+    g32w, c32w, f32w = g.float().double(), c.float().double(), f.float().double()
+    r64 = ctx.solve_gcf(h, g32w, c32w, f32w, want_gam=False)["lam"]
+    nA32 = norm_a(h, g32w, c32w, torch.where(f32w > 0, f32w, torch.ones_like(f32w)))
+    for d in (0, 1):
+        el = ((out[d, "lam32"]["lam"].double() - r64).abs() / nA32 / 1.1920929e-07)[ok]
+        assert float(el.max()) <= N - 1 + 4, (d, float(el.max()))
+        assert int((((out[d, "lam32"]["info"][ok] >> 16) & 3) != 0).sum()) == 0
     pick = np.array([0, 1, 5, 100, n - 1, n, n + 3, 2 * n - 1])
     pk = torch.from_numpy(pick).to(dev)
     gam_c, lam_c, _ = co.solve_gcf_batch(h, g[pk].cpu().numpy(), c[pk].cpu().numpy(), f[pk].cpu().numpy())
