@@ -33,19 +33,19 @@ struct Grp {
   }
   template <typename T>
   __device__ __forceinline__ static T sum(T v, int lane) {
-    v += dpp_t<0x111, 0xF>(T(0), v);
-    v += dpp_t<0x112, 0xF>(T(0), v);
-    v += dpp_t<0x114, 0xF>(T(0), v);
-    v += dpp_t<0x118, 0xF>(T(0), v);
+    v += dppz_t<0x111, 0xF>(v);
+    v += dppz_t<0x112, 0xF>(v);
+    v += dppz_t<0x114, 0xF>(v);
+    v += dppz_t<0x118, 0xF>(v);
     if constexpr (P >= 32) v += dpp_t<0x142, 0xA>(T(0), v);
     if constexpr (P == 64) v += dpp_t<0x143, 0xC>(T(0), v);
     return bcast_last(v, lane);
   }
   __device__ __forceinline__ static int sum_i(int v, int lane) {
-    v += dpp_i<0x111, 0xF>(0, v);
-    v += dpp_i<0x112, 0xF>(0, v);
-    v += dpp_i<0x114, 0xF>(0, v);
-    v += dpp_i<0x118, 0xF>(0, v);
+    v += dppz_i<0x111, 0xF>(v);
+    v += dppz_i<0x112, 0xF>(v);
+    v += dppz_i<0x114, 0xF>(v);
+    v += dppz_i<0x118, 0xF>(v);
     if constexpr (P >= 32) v += dpp_i<0x142, 0xA>(0, v);
     if constexpr (P == 64) v += dpp_i<0x143, 0xC>(0, v);
     return bcast_last_i(v, lane);

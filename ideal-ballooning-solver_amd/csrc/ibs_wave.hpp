@@ -156,14 +156,25 @@ __device__ __forceinline__ double readlane_t(double v, int l) {
 }
 __device__ __forceinline__ float readlane_t(float v, int l) { return __int_as_float(readlane_i(__float_as_int(v), l)); }
 
+// fetch with zero fill (bound_ctrl): a lane whose source lies outside its row reads 0; with all rows enabled no previous value
+// has to be set up in the destination (the form with an `old` operand costs a v_mov per dword and step)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dppz_i(int src) { return __builtin_amdgcn_update_dpp(0, src, CTRL, ROWMASK, 0xF, true); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dppz_t(double src) {
+  return __hiloint2double(dppz_i<CTRL, ROWMASK>(__double2hiint(src)), dppz_i<CTRL, ROWMASK>(__double2loint(src)));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dppz_t(float src) { return __int_as_float(dppz_i<CTRL, ROWMASK>(__float_as_int(src))); }
+
 // wave-wide reductions on the VALU (DPP row_shr / row_bcast: no LDS round trips); the result is
 // read from lane 63 into SGPRs, i.e. it is wave-uniform.
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
-  v += dpp_t<0x111, 0xF>(T(0), v);
-  v += dpp_t<0x112, 0xF>(T(0), v);
-  v += dpp_t<0x114, 0xF>(T(0), v);
-  v += dpp_t<0x118, 0xF>(T(0), v);
+  v += dppz_t<0x111, 0xF>(v);
+  v += dppz_t<0x112, 0xF>(v);
+  v += dppz_t<0x114, 0xF>(v);
+  v += dppz_t<0x118, 0xF>(v);
   v += dpp_t<0x142, 0xA>(T(0), v);
   v += dpp_t<0x143, 0xC>(T(0), v);
   return readlane_t(v, 63);
@@ -233,14 +244,6 @@ __device__ __forceinline__ M2<T> mul(const M2<T>& A, const M2<T>& B) {
 }
 // neighbour fetch for the scans: lanes without a valid source receive garbage/zero and are masked
 // out by the caller (the product is applied under `if (valid)`), so no identity has to be built.
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int dppz_i(int src) { return __builtin_amdgcn_update_dpp(0, src, CTRL, ROWMASK, 0xF, true); }
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dppz_t(double src) {
-  return __hiloint2double(dppz_i<CTRL, ROWMASK>(__double2hiint(src)), dppz_i<CTRL, ROWMASK>(__double2loint(src)));
-}
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dppz_t(float src) { return __int_as_float(dppz_i<CTRL, ROWMASK>(__float_as_int(src))); }
 template <typename T, int CTRL, int ROWMASK>
 __device__ __forceinline__ M2<T> dpp_fetch(const M2<T>& s) {
   M2<T> r;
