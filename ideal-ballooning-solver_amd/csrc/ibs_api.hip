@@ -328,12 +328,11 @@ __global__ void k_scan_starts(int n_surf, int n_alpha, int n_theta0, const doubl
 // One wave per system on a long grid: k_solve_gcf's three staged rows are 24.6 KB of LDS per wave at N = 1025 -- five waves
 // per CU where the registers admit eight.  A batch that fills the chip at more waves than the staging admits reads its rows
 // straight from global memory instead (k_solve_gcf_direct: no LDS).  Option gcf_direct: -1 = this rule, 0 = never, 1 = always.
-static bool use_direct(const ibs_ctx* ctx, int N, long n_sys, int M) {
+static bool use_direct(const ibs_ctx* ctx, int N, long n_sys) {
   if (ctx->opt.gcf_direct == 0) return false;
   if (ctx->opt.gcf_direct == 1) return true;
   // (measured, tools/bench_direct.py, 2^19 systems: 1.45-1.65 x the staged / row-streamed kernels at N_zeta = 768 .. 1536, 1.2-1.3 x at 2048)
   const long staged_waves_per_cu = (long)(ctx->lds_per_block / ((size_t)3 * ibs::lds_pitch(N) * sizeof(double)));
-  (void)M;
   return staged_waves_per_cu < 8 && n_sys > (staged_waves_per_cu > 4 ? staged_waves_per_cu : 4) * ctx->n_cu;
 }
 
@@ -378,12 +377,12 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
         auto fr = ibs::launch_table().gcf_f32w_rows[M];
         if (fr && ctx->opt.gcf_rows != 0) { launch = fr; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(double); }
         auto fd = ibs::launch_table().gcf_direct_f32w[M];
-        if (fd && use_direct(ctx, N, (long)n_sys, M)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(double); }
+        if (fd && use_direct(ctx, N, (long)n_sys)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(double); }
       }
     } else {
       // eigenvalues only, all-FP32 iteration + FP64 certificate: big batches on long grids read their rows from global memory
       auto fl = ibs::launch_table().gcf_direct_f32lam[M];
-      if (!gh && fl && use_direct(ctx, N, (long)n_sys, M)) launch = fl;
+      if (!gh && fl && use_direct(ctx, N, (long)n_sys)) launch = fl;
     }
   }
   if constexpr (sizeof(T) == 8) {
@@ -392,7 +391,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     auto fr = ibs::launch_table().gcf_rows_f64[M];
     if (!gh && launch == table[M] && fr && ctx->opt.gcf_rows != 0) { launch = fr; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(T); }
     auto fd = ibs::launch_table().gcf_direct_f64[M];
-    if (!gh && (launch == table[M] || launch == fr) && fd && use_direct(ctx, N, (long)n_sys, M)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(T); }
+    if (!gh && (launch == table[M] || launch == fr) && fd && use_direct(ctx, N, (long)n_sys)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(T); }
   }
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
