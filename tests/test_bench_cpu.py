@@ -119,6 +119,12 @@ def test_the_stdout_line_fits_the_drivers_capture():
     assert c5["rows"][0][:3] == [256, "s", "f64"] and abs(c5["rows"][0][3] / r0["solves_per_s"] - 1) < 1e-3
     assert c5["kernels"][c5["rows"][0][7]] == r0["roofline"]["kernel"]
     assert o["c4_adjoint_step"]["parity_ok"] is True and abs(o["c4_adjoint_step"]["total_ms"] / full["c4_adjoint_step"]["total_ms"] - 1) < 1e-4
+    # this round's full record (profiles/r05b_bench_detail.json: the direct / two-wave kernels' names in c5_matrix)
+    full5 = json.load(open(os.path.join(ROOT, "profiles", "r05b_bench_detail.json")))
+    line5 = bench.compact_line(full5)
+    o5 = json.loads(line5)
+    assert len(line5) < 6000 and "dropped_for_length" not in o5 and o5["value"] == full5["value"]
+    assert len(o5["c5_matrix"]["rows"]) == 24 and any("k_solve_gcf_direct" in k for k in o5["c5_matrix"]["kernels"])
     # a 2-rank line (profiles/r04_rehearsal_2rank.json): the sharded legs keep their flags
     two = next(json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r04_rehearsal_2rank.json")) if l.startswith("{"))
     o2 = json.loads(bench.compact_line(two))
