@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import c5_family, norm_a, emulated_equilibria, ncsx_boundary_dofs  # noqa: E402,F401
 
 
-@pytest.mark.parametrize("nz", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("nz", [256, 512, 1024, 1536, 2048])      # (1536: the two-waves-per-SIMD direct form, round 5)
 @pytest.mark.parametrize("family", ["rough", "smooth"])
 def test_config5_fp64_one_million_systems(ctx, nz, family):
     """10^6 systems per (N_zeta, family), FP64: nothing flagged; the Sturm count is 0 just above the returned eigenvalue and
