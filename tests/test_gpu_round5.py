@@ -239,3 +239,17 @@ def test_direct_form_is_what_big_batches_on_long_grids_get(ctx):
     assert "k_solve_gcf<double, 16>" in ctx.last_launch()[0], ctx.last_launch()
     ctx.solve_gcf(h, g.float(), c.float(), f.float(), dtype=np.float32)
     assert "k_solve_gcf_direct<double, 16, float>" in ctx.last_launch()[0], ctx.last_launch()
+    # ragged batch: a system count that is not a multiple of the waves per block -- the last block's spare waves must not write,
+    # and every system's result must not depend on the batch it is solved in (same kernel: bit for bit)
+    full = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
+    for n_r in (8191, 4097, 1283):
+        part = ctx.solve_gcf(h, g[:n_r], c[:n_r], f[:n_r], want_X=True, want_info=True)
+        assert "k_solve_gcf_direct" in ctx.last_launch()[0]
+        for k in ("lam", "gam", "X", "dX", "info"):
+            assert torch.equal(part[k], full[k][:n_r]), (n_r, k)
+    lam32 = ctx.solve_gcf(h, g.float()[:4097], c.float()[:4097], f.float()[:4097], dtype=np.float32, want_gam=False)["lam"]
+    ctx.set_option("f32_lam", 1)
+    lam32b = ctx.solve_gcf(h, g.float()[:4097], c.float()[:4097], f.float()[:4097], dtype=np.float32, want_gam=False)["lam"]
+    assert "k_solve_gcf_f32lam_direct" in ctx.last_launch()[0] and lam32b.shape == (4097,) and torch.isfinite(lam32b).all()
+    ctx.set_option("f32_lam", None)
+    assert float((lam32.double() - lam32b.double()).abs().max()) < 1e-4
