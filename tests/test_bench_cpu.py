@@ -130,6 +130,14 @@ def test_the_stdout_line_fits_the_drivers_capture():
     o2 = json.loads(bench.compact_line(two))
     assert o2["config"]["ranks_in_collective"] == 2 and o2["ncsx_c2_sharded"]["checks_passed"] is True
     assert o2["c4_adjoint_step_sharded"]["checks_passed"] is True and len(bench.compact_line(two)) < 6000
+    # the line of an N = 8 RCCL run as the driver's SCALE tier would get it: the three gather modes and the native sharded leg on top
+    eight = dict(two, n_gpus=8, gather_modes={m: dict(ms_per_step=0.05, solves_per_s=1.6e8, allgather_roundtrip_ok=True, ranks_in_collective=8)
+                                              for m in ("torch_in_stream", "native_in_stream", "native_overlapped")},
+                 ncsx_c2_sharded_native=dict(two["ncsx_c2_sharded"], workload="x" * 300))
+    l8 = bench.compact_line(eight)
+    o8 = json.loads(l8)
+    assert len(l8) < 6000 and "dropped_for_length" not in o8 and set(o8["gather_modes"]) == {"torch_in_stream", "native_in_stream", "native_overlapped"}
+    assert "workload" not in o8["ncsx_c2_sharded_native"] and o8["ncsx_c2_sharded_native"]["checks_passed"] is True
     # whatever a future leg adds, the bound holds: legs are dropped in a stated order, the contract's keys never
     fat = dict(full, future_leg={"rows": [{"x": float(i), "name": "k" * 40} for i in range(400)]})
     fl = bench.compact_line(fat)
