@@ -362,9 +362,16 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     // FP64 solver -- in the same three forms as the FP64 entry point (sub-wave for large batches of short grids, row-streamed
     // for long grids, else one wave per system with the three rows staged).  lam alone stays with the all-FP32 kernel, whose
     // result is certified by an FP64 count pair (k_solve_gcf<float, M>).
-    // lam alone: the all-FP32 iteration with its FP64 certificate pays on long grids; where the sub-wave forms exist
-    // (N <= 642) the FP64 solver on FP32 bytes, without the growth-rate stage, is faster (option f32_lam overrides)
-    const bool wide_lam = ctx->opt.f32_lam == 2 || (ctx->opt.f32_lam == 0 && pick_lanes(ctx, N, (long)n_sys) != 64);
+    // lam alone: the all-FP32 iteration with its FP64 certificate.  A batch that would get the 32-lane sub-wave form takes it with
+    // the rows read straight from global memory (k_solve_gcf_f32lam_direct: 1.12-1.15 x the FP64 sub-wave solver on FP32 bytes on
+    // smooth coefficients, 2.1 x on rough ones; 2,048 ... 10^6 systems, N_zeta = 256 ... 640, tools/bench_forms.py).  Where the
+    // 16-lane form runs (N <= 258, big batches) the FP64 sub-wave solver without its growth-rate stage stays: 1.5 x the all-FP32
+    // form on smooth coefficients, 0.83 x on rough ones.  Also where the direct form is not built or gcf_direct = 0; option
+    // f32_lam overrides.
+    const int P_lam = pick_lanes(ctx, N, (long)n_sys);
+    const auto fl = ibs::launch_table().gcf_direct_f32lam[M];
+    const bool fl_ok = fl && ctx->opt.gcf_direct != 0;
+    const bool wide_lam = ctx->opt.f32_lam == 2 || (ctx->opt.f32_lam == 0 && (P_lam == 16 || (P_lam == 32 && !fl_ok)));
     if (gam || X || dX || wide_lam) {
       auto fw = ibs::launch_table().gcf_f32_wide[M];
       if (fw) { launch = fw; per_wave = (size_t)3 * ibs::lds_pitch(N) * sizeof(double); }
@@ -380,9 +387,8 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
         if (fd && use_direct(ctx, N, (long)n_sys)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(double); }
       }
     } else {
-      // eigenvalues only, all-FP32 iteration + FP64 certificate: big batches on long grids read their rows from global memory
-      auto fl = ibs::launch_table().gcf_direct_f32lam[M];
-      if (!gh && fl && use_direct(ctx, N, (long)n_sys)) launch = fl;
+      // eigenvalues only, all-FP32 iteration + FP64 certificate: big batches read their rows from global memory
+      if (!gh && fl_ok && (P_lam != 64 || use_direct(ctx, N, (long)n_sys))) launch = fl;
     }
   }
   if constexpr (sizeof(T) == 8) {

@@ -14,6 +14,15 @@
 #ifndef IBS_M
 #error "compile with -DIBS_M=<rows per lane>"
 #endif
+// fewest rows per lane for which the read-from-global-memory forms are built: k_solve_gcf_direct (FP64 solver) pays where the
+// staging limits the occupancy (N > 578; below, the sub-wave forms are faster: tools/bench_forms.py), the all-FP32 eigenvalue-only
+// form k_solve_gcf_f32lam_direct on every big batch
+#ifndef IBS_DIRECT_MIN_M
+#define IBS_DIRECT_MIN_M 9
+#endif
+#ifndef IBS_F32LAM_DIRECT_MIN_M
+#define IBS_F32LAM_DIRECT_MIN_M 3
+#endif
 
 namespace ibs {
 
@@ -1530,7 +1539,7 @@ static hipError_t launch_gcf_wide(const GcfArgs<float>& a, hipStream_t st) {
 }
 template <typename TI>
 static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
-  if constexpr (IBS_M >= 9) {
+  if constexpr (IBS_M >= IBS_DIRECT_MIN_M) {
     const int wpb = 4;
     const size_t lds = (a.X || a.dX) ? (size_t)wpb * lds_pitch(a.N) * sizeof(double) : 0;
     const long nblk = (a.n_sys + wpb - 1) / wpb;
@@ -1554,7 +1563,7 @@ static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
 // the occupancy cap pays where the allocator would otherwise take AGPRs (one wave per SIMD): checked per M in the resource table
 constexpr bool f32lam_two_waves(int M) { return M >= 21 && M <= 30; }   // (M = 32: 4.4 against 5.7e7 solves/s capped against free, rough family; tools/bench_f32lam.py)
 static hipError_t launch_gcf_f32lam_direct(const GcfArgs<float>& a, hipStream_t st) {
-  if constexpr (IBS_M >= 9) {
+  if constexpr (IBS_M >= IBS_F32LAM_DIRECT_MIN_M) {
     const int wpb = 4;
     const long nblk = (a.n_sys + wpb - 1) / wpb;
     constexpr bool w2 = f32lam_two_waves(IBS_M);
@@ -1688,13 +1697,15 @@ struct IBS_CAT(Registrar, IBS_M) {
     t.gcf_f32w_rows[IBS_M] = &launch_gcf_rows_wide;
 #endif
 #endif
-#if IBS_M >= 9
+#if IBS_M >= IBS_DIRECT_MIN_M
     // N > 578: big batches read their rows straight from global memory (no LDS staging: occupancy is the registers')
     t.gcf_direct_f64[IBS_M] = &launch_gcf_direct<double>;
 #ifdef IBS_WITH_F32
     t.gcf_direct_f32w[IBS_M] = &launch_gcf_direct<float>;
-    t.gcf_direct_f32lam[IBS_M] = &launch_gcf_f32lam_direct;
 #endif
+#endif
+#if defined(IBS_WITH_F32) && IBS_M >= IBS_F32LAM_DIRECT_MIN_M
+    t.gcf_direct_f32lam[IBS_M] = &launch_gcf_f32lam_direct;
 #endif
     t.scan_f64[IBS_M] = &launch_scan<double>;
     t.scan_chain_f64[IBS_M] = &launch_scan_chain<double>;

@@ -102,7 +102,7 @@ int ibs_comm_destroy(ibs_ctx* ctx);
  * geometry kernel 1|2|4|8, or -2 = two grid points per lane), "gcf_rows" (0: three-row staging instead of the row-streamed raw
  * kernel on long grids), "gcf_direct" (raw systems, one wave per system: rows read straight from global memory instead of staged in LDS; -1 = by
  * batch size, 0 = never, 1 = always), "f32_lam" (FP32 eigenvalue-only requests: 1 = all-FP32 iteration + FP64 certificate, 2 = FP64 solver on
- * the FP32 arrays; 0 = by grid size), "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
+ * the FP32 arrays; 0 = form 2 where the 16-lane sub-wave kernels run, else form 1), "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
  * staged in LDS, 1, or read from global memory by the sums, 0: two blocks per CU instead of one at N = 969; -1 = by batch size);
  * value 0 = automatic (refine_tangent, gcf_direct: -1); value NaN = back to what ibs_create() read from the environment
  * (IBS_FORCE_P, IBS_SCAN_CHAIN, IBS_CHAIN_W1, IBS_CHAIN_W2, IBS_GEO_LPP are read once, there); name "all" with NaN
