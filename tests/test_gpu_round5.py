@@ -253,3 +253,42 @@ def test_direct_form_is_what_big_batches_on_long_grids_get(ctx):
     assert "k_solve_gcf_f32lam_direct" in ctx.last_launch()[0] and lam32b.shape == (4097,) and torch.isfinite(lam32b).all()
     ctx.set_option("f32_lam", None)
     assert float((lam32.double() - lam32b.double()).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("N", [131, 321, 513, 641])
+def test_fp32_eigenvalues_alone_on_short_grids(ctx, N):
+    """FP32 eigenvalue-only requests where the sub-wave forms exist (ibs_api.hip, `wide_lam`): a batch that would get the 32-lane
+    form runs the all-FP32 iteration + FP64 certificate with its rows read from global memory (k_solve_gcf_f32lam_direct, built
+    from 3 rows per lane), the 16-lane regime (N <= 258, big batches) keeps the FP64 sub-wave solver; both within
+    (N_zeta + 4) eps32 ||A|| of the FP64 solve on EVERY system, the only status the informational bit 2; ragged batches included."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 40003                                                              # (not a multiple of the four waves of a block)
+    M = (N - 2 + 63) // 64
+    for family in ("smooth", "rough"):
+        h, g, c, f = c5_family(dev, family, n, N, seed=77 + N)
+        r64 = ctx.solve_gcf(h, g, c, f)
+        nA = norm_a(h, g, c, f)
+        g32, c32, f32 = g.float(), c.float(), f.float()
+        r = ctx.solve_gcf(h, g32, c32, f32, want_info=True, dtype=np.float32, want_gam=False)
+        name = ctx.last_launch()[0]
+        if N <= 258:
+            assert "k_solve_gcf_g<double, %d, 16, float>" % ((N - 2 + 15) // 16) in name, name
+        else:
+            assert "k_solve_gcf_f32lam_direct<%d>" % M in name, name
+        st = r["info"] >> 16
+        assert int(((st & ~4) != 0).sum()) == 0
+        el = (r["lam"].double() - r64["lam"]).abs() / nA
+        assert float(el.max()) <= (N + 3) * 1.1920929e-07, (family, float(el.max()) / 1.1920929e-07)
+        # forced: the all-FP32 direct form in the 16-lane regime as well; a small batch keeps the staged all-FP32 kernel
+        ctx.set_option("f32_lam", 1)
+        r1 = ctx.solve_gcf(h, g32, c32, f32, want_info=True, dtype=np.float32, want_gam=False)
+        assert "k_solve_gcf_f32lam_direct<%d>" % M in ctx.last_launch()[0], ctx.last_launch()
+        rs = ctx.solve_gcf(h, g32[:300], c32[:300], f32[:300], want_info=True, dtype=np.float32, want_gam=False)
+        assert "k_solve_gcf<float, %d>" % M in ctx.last_launch()[0], ctx.last_launch()
+        ctx.set_option("f32_lam", None)
+        e1 = (r1["lam"].double() - r64["lam"]).abs() / nA
+        assert float(e1.max()) <= (N + 3) * 1.1920929e-07 and int((((r1["info"] >> 16) & ~4) != 0).sum()) == 0
+        # the same all-FP32 arithmetic from LDS and from global memory: within the certificate's tolerance of each other
+        es = (rs["lam"].double() - r1["lam"][:300].double()).abs() / nA[:300]
+        assert float(es.max()) <= 2 * (N + 3) * 1.1920929e-07
