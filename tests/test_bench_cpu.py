@@ -190,3 +190,12 @@ def test_pmc_summary_splits_launches_into_work_classes(tmp_path):
     assert d[k0]["SQ_WAVES"]["n"] == 3 and d[k1]["SQ_WAVES"]["n"] == 2 and d["_unmatched_launches_of_the_byte_passes"] == 0
     assert d[k0]["hbm_bytes_per_launch"] == (2 * 100.0 + 10.0) * 1024 and d[k1]["hbm_bytes_per_launch"] == (2 * 300.0 + 10.0) * 1024
     assert d[k0]["work_class"] == 0 and d[k1]["work_class"] == 1 and d[k0]["valu_spread"] < 1.01
+
+
+def test_every_tool_is_in_the_tools_index():
+    """tools/ holds the measurement scripts of five rounds: each one is named in tools/README.md (what it measures, which round)"""
+    tdir = os.path.join(ROOT, "tools")
+    text = open(os.path.join(tdir, "README.md")).read()
+    missing = [f for f in sorted(os.listdir(tdir)) if os.path.isfile(os.path.join(tdir, f)) and f != "README.md" and f not in text]
+    assert not missing, missing
+    assert not [f for f in os.listdir(tdir) if ".bin" in f or f.endswith((".o", ".so"))], "build products in tools/"
