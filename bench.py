@@ -1249,6 +1249,16 @@ def main():
         torch.cuda.synchronize()
         return int(len(set(int(v) for v in allr.cpu().tolist())))
 
+    def spin_on(mine):
+        """N > 1: every step holds a collective, so every rank must take the SAME number of them -- a rank that read its own clock
+        a few microseconds past the mark while its neighbour did not would leave the others inside 64 all-gathers it never joins.
+        The ranks agree (all continue only while all want to)."""
+        if not use_dist:
+            return mine
+        t = torch.tensor([1.0 if mine else 0.0], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() == 1.0)
+
     for k in range(args.warmup):
         step(k)
     # clocks: whatever --warmup says, at least 150 ms of untimed steps run before the timed region (a 20-step driver
@@ -1256,7 +1266,7 @@ def main():
     torch.cuda.synchronize()
     t_spin = time.perf_counter()
     n_spin = 0
-    while time.perf_counter() - t_spin < 0.15:
+    while spin_on(time.perf_counter() - t_spin < 0.15):
         for k in range(64):
             step(k)
         torch.cuda.synchronize()
