@@ -87,11 +87,11 @@ struct ibs_ctx {
   int comm_rank = 0, comm_n = 1;
   // overlapped gathers (ibs_comm_allgather_start_f64): the communicator's own stream, "inputs written" marker of the
   // compute stream, one completion event per slot
-  static constexpr int kCommSlots = 4;
+  static constexpr int kCommSlots = 16;
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ready = nullptr;
-  hipEvent_t comm_done[kCommSlots] = {nullptr, nullptr, nullptr, nullptr};
-  bool comm_pending[kCommSlots] = {false, false, false, false};
+  hipEvent_t comm_done[kCommSlots] = {};
+  bool comm_pending[kCommSlots] = {};
   // per-surface arrival counters of the fused scan + argmax kernel (zero between launches; the last arriver resets its
   // word).  One buffer PER STREAM the context has been used on: two plans of one context run under different streams may
   // have their fused kernels in flight at the same time, and shared counters would mix their arrivals.

@@ -79,7 +79,7 @@ int ibs_lbfgsb2_result(const void* state, double* x, double* f, int32_t* counter
  *   ibs_comm_allgather_start_f64(ctx, send, recv, count, slot, then_wait_slot)   the same gather, ordered after everything enqueued so
  *                            far on the context's stream but run on the communicator's OWN stream: the next scan does not
  *                            wait for the ranks to meet (the reference has nothing to overlap: its Gather is blocking).
- *                            slot in [0, 4) names the gather; then_wait_slot >= 0 (another slot) additionally does
+ *                            slot in [0, 16) names the gather; then_wait_slot >= 0 (another slot) additionally does
  *                            ibs_comm_wait(ctx, then_wait_slot) in the same call, -1 = nothing, -2 - s = wait for slot s
  *                            on the HOST instead (event query; blocks only if that gather is still running) so that the
  *                            context's stream carries no wait at all -- for callers running several slots ahead;
