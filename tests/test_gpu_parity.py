@@ -960,7 +960,7 @@ def test_native_rccl_allgather_single_rank():
     assert torch.equal(recvs[0].cpu(), torch.arange(48, dtype=torch.float64) + 10)
     assert torch.equal(recvs[1].cpu(), torch.arange(48, dtype=torch.float64) + 11)
     with pytest.raises(ibs_amd.IbsError):
-        c.allgather_start(sends[0], recvs[0], 7)                                 # slot out of range
+        c.allgather_start(sends[0], recvs[0], 16)                                # slot out of range (16 slots)
     with pytest.raises(ibs_amd.IbsError):
         c.allgather_start(sends[0], recvs[0], 1, then_wait=1)                    # a gather cannot wait for itself
     for k in range(6):                                                           # the one-call form bench.py uses
