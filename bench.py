@@ -456,7 +456,7 @@ def stress(ctx, device, n_sys, family, reps=3):
     h = 8 * np.pi / (N - 1)
     r = ctx.solve_gcf(h, g, c, f, want_info=True)                  # warm-up + correctness word
     torch.cuda.synchronize()
-    nbad = int(((r["info"] >> 16) != 0).sum().item())
+    nbad = int((((r["info"] >> 16) & 3) != 0).sum().item())
     sweeps = float((r["info"] & 0xffff).double().mean().item())
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in evs:
@@ -1184,7 +1184,10 @@ def main():
     # start of the process and the number.  The library's own ncclAllGather (in-stream, and overlapped with the next scans
     # on the communicator's stream) is timed AFTERWARDS as extra legs, under a watchdog (`gather_modes`).
     gathered = torch.empty((n_ranks * N_SURF, 2), dtype=torch.float64, device=coll_dev) if use_dist else None
-    gathered3 = [gathered, torch.empty_like(gathered), torch.empty_like(gathered)] if use_dist else None
+    # (the library's own gathers work on device buffers whatever torch.distributed's backend is: with the shared-memory stand-in
+    #  for librccl, IBS_RCCL_LIB, they also run in the one-GPU rehearsal, where torch.distributed goes through gloo)
+    gath_nat = (gathered if backend == "nccl" else torch.empty((n_ranks * N_SURF, 2), dtype=torch.float64, device=device)) if use_dist else None
+    gathered3 = [gath_nat, torch.empty_like(gath_nat), torch.empty_like(gath_nat)] if use_dist else None
     n_issued = [0]                       # steps issued so far (the slot rotation must not depend on the caller's k)
     mode = ["torch" if use_dist else "none"]       # "none" | "torch" | "native" | "overlap"
 
@@ -1204,7 +1207,7 @@ def main():
             ctx.allgather_start(plan.packs[slot], gathered3[slot], slot, same_stream=True, host_wait=(n_issued[0] + 1) % 3)
             n_issued[0] += 1
         elif mode[0] == "native":
-            ctx.allgather(plan.pack, gathered)
+            ctx.allgather(plan.pack, gath_nat)
         elif mode[0] == "torch":
             dist.all_gather_into_tensor(gathered, plan.pack if backend == "nccl" else plan.pack.cpu())
 
@@ -1233,15 +1236,16 @@ def main():
     def roundtrip_ok():
         """every rank holds every rank's maxima of the last step; its own row must be what it sent"""
         last = (n_issued[0] - 1) % 3 if mode[0] == "overlap" else 0
-        got = (gathered3[last] if mode[0] == "overlap" else gathered)[rank * N_SURF:(rank + 1) * N_SURF].to(device)
+        buf = gathered3[last] if mode[0] == "overlap" else (gath_nat if mode[0] == "native" else gathered)
+        got = buf[rank * N_SURF:(rank + 1) * N_SURF].to(device)
         okt = torch.tensor([1.0 if torch.equal(got, plan.packs[last]) else 0.0], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)       # (reported, not raised: no rank may leave the others in a collective)
         return bool(okt.item() == 1.0)
 
     def ranks_seen(native):
         """the number of distinct ranks counted INSIDE the collective: every rank contributes its id to one all-gather"""
-        mine = torch.full((1,), float(rank), dtype=torch.float64, device=coll_dev)
-        allr = torch.empty((n_ranks,), dtype=torch.float64, device=coll_dev)
+        mine = torch.full((1,), float(rank), dtype=torch.float64, device=device if native else coll_dev)
+        allr = torch.empty((n_ranks,), dtype=torch.float64, device=device if native else coll_dev)
         if native:
             ctx.allgather(mine, allr)
         else:
@@ -1359,13 +1363,13 @@ def main():
         dog.disarm()
 
     # ---- the library's own collective, as extra legs
-    if use_dist and backend == "nccl" and os.environ.get("IBS_BENCH_NATIVE_COLL", "1") != "0":
+    if use_dist and (backend == "nccl" or os.environ.get("IBS_RCCL_LIB")) and os.environ.get("IBS_BENCH_NATIVE_COLL", "1") != "0":
         modes = {"torch_in_stream": {"ms_per_step": dt / args.steps * 1e3, "solves_per_s": n_ranks * n_solves * args.steps / dt,
                                      "allgather_roundtrip_ok": gather_ok, "ranks_in_collective": seen}}
         if out is not None:
             out["gather_modes"] = modes
         dog.arm("ncclCommInitRank of the library's communicator", 90)
-        flag = torch.ones(1, dtype=torch.float64, device=device)
+        flag = torch.ones(1, dtype=torch.float64, device=coll_dev)
         try:
             ctx.comm_init(dist, rank, n_ranks)
         except Exception as e:

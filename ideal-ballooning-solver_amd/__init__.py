@@ -5,7 +5,7 @@ valid Python identifier).
 """
 from ._lib import IbsError, LIB_PATH, MEM_DEVICE, MEM_HOST, SYMBOLS  # noqa: F401
 from .solver import Context, ScanPlan, default_context  # noqa: F401
-from .operators import gamma_ball_full, dPdrho_of, uniform_spacing, make_obj_w_grad, theta_grid  # noqa: F401
+from .operators import gamma_ball_full, dPdrho_of, uniform_spacing, make_obj_w_grad, theta_grid, NearestSigmaWarning  # noqa: F401
 from .scan import BallooningScan, shard_surfaces, gather_surfaces, gather_rows_tensor, pick_start, append_history, GEO_ORDER  # noqa: F401
 from .geometry import SurfaceTables  # noqa: F401
 from .config import ScanConfig, load_params_dict, theta_grid_for, create_history_placeholders, PARAMS_KEYS  # noqa: F401

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,8 @@ struct ibs_options {
   int gcf_direct = -1;    // raw systems, one wave per system: rows read straight from global memory (k_solve_gcf_direct): -1 = by batch size, 0 = never, 1 = always
   int pack_mode = 0;      // hand-off of the fused scan + argmax: 1 = write-through + sc1 loads, 2 = release / acquire fences
   int f32_lam = 0;        // FP32 eigenvalue-only requests: 0 = by grid size, 1 = all-FP32 iteration + FP64 certificate, 2 = FP32 in HBM + FP64 solver
+  double sigma0 = std::numeric_limits<double>::quiet_NaN();   // not NaN: solves that return lam AND info flag lam_max >= sigma0 (informational status bit 4: utils.py:1597 would have taken the eigenpair nearest sigma0)
+  int reclose = 1;        // FP64 raw systems: 1 = a solve whose closing bracket fails its consistency checks is re-closed in division form, 2 = only marked, 0 = off
   int refine_tangent = -1; // refinement: alpha-tangent of a point staged in LDS (1) or read from global memory in the sums (0); -1 = by batch size
   double chain_w1 = 0.25, chain_w2 = 1.0;   // relative widths of the chain's warm starts
 };
@@ -80,6 +83,9 @@ struct ibs_ctx {
   // them with ONE copy each way (HostStage)
   void* hs = nullptr;
   size_t hs_bytes = 0;
+  // workspace of the long-grid path (N > 2050: ibs_long.hip), grown on demand
+  void* long_ws = nullptr;
+  size_t long_ws_bytes = 0;
   int lds_per_block = 160 * 1024;
   int n_cu = 256;
   // native RCCL communicator of this rank (ibs_comm_init), null = none
@@ -150,6 +156,15 @@ struct Arena {  // carve device buffers out of the context workspace
 };
 size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
 
+int ensure_long_ws(ibs_ctx* c, size_t bytes) {
+  if (bytes <= c->long_ws_bytes) return 0;
+  if (c->long_ws) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->long_ws)); c->long_ws = nullptr; c->long_ws_bytes = 0; }
+  HIPCHK(hipMalloc(&c->long_ws, bytes));
+  c->long_ws_bytes = bytes;
+  return 0;
+}
+int long_waves(const ibs_ctx* c, long n_sys) { const long cap = 8L * c->n_cu; return (int)(n_sys < cap ? n_sys : cap); }
+
 int ensure_ws(ibs_ctx* c, size_t bytes) {
   if (bytes <= c->ws_bytes) return 0;
   if (c->ws) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
@@ -213,8 +228,11 @@ struct HostStage {
   }
 };
 
-int check_grid(int32_t N, double h) {
-  if (N < 66 || N > 64 * ibs::kMaxM + 2) return fail(IBS_ERR_UNSUPPORTED, "N=%d outside [66, %d]", N, 64 * ibs::kMaxM + 2);
+// long_ok: the entry point has the generic long-grid path behind it (ibs_long.hip)
+bool is_long(int N) { return N > 64 * ibs::kMaxM + 2; }
+int check_grid(int32_t N, double h, bool long_ok = false) {
+  const int n_max = long_ok ? ibs::kMaxLongN : 64 * ibs::kMaxM + 2;
+  if (N < 66 || N > n_max) return fail(IBS_ERR_UNSUPPORTED, "N=%d outside [66, %d]", N, n_max);
   if ((N & 1) == 0) return fail(IBS_ERR_UNSUPPORTED, "N=%d is even: the reference's Simpson rule is restated for odd N only", N);
   if (!(h > 0)) return fail(IBS_ERR_ARG, "h must be > 0");
   return 0;
@@ -252,6 +270,21 @@ __global__ void k_count_status(long n, const int* info, int* out) {
   int bad = (i < n) && (((info[i] >> 16) & 3) != 0);      // (status bit 2 is informational: an FP32 result re-solved in FP64)
   unsigned long long m = __ballot(bad);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+
+// Nearest-sigma report (option "sigma0"): the reference takes the eigenpair NEAREST sigma0 (eigs(..., sigma=sigma0), utils.py:1597;
+// sigma0 = 1.0 in the coarse scan, 1.3 |gam| + 0.05 in the refinement, 0.42 in the final solve: ball_scan.py:230, 289, 337); this
+// library always returns lam_max.  The two are the same eigenpair whenever lam_max < sigma0 -- true of every equilibrium seen so
+// far -- and only then.  A solve with lam_max >= sigma0 carries the informational status bit 4.
+template <typename T>
+__global__ void k_flag_sigma(long n, const T* lam, int* info, double sigma0) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (double)lam[i] >= sigma0) info[i] |= 16 << 16;
+}
+template <typename T>
+static void flag_sigma(const ibs_ctx* ctx, long n, const T* lam, int* info) {
+  if (!(ctx->opt.sigma0 == ctx->opt.sigma0) || !lam || !info || n <= 0) return;
+  hipLaunchKernelGGL(k_flag_sigma<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, lam, info, ctx->opt.sigma0);
 }
 
 static inline int argmax_threads(int n_per) { const int t = ((n_per + 63) / 64) * 64; return t > 256 ? 256 : t; }
@@ -342,22 +375,35 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
                    hipError_t (*const* table)(const ibs::GcfArgs<T>&, hipStream_t), const T* gh = nullptr) {
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
   if (n_sys < 0 || !g || !c || !f || ld < N) return fail(IBS_ERR_ARG, "bad arguments (n_sys=%lld ld=%lld N=%d)", (long long)n_sys, (long long)ld, N);
-  if (int r = check_grid(N, (double)h)) return r;
+  if (int r = check_grid(N, (double)h, true)) return r;
   if (n_sys == 0) return 0;
-  int M = rows_per_lane(N);
+  // grids beyond 2050 points: the generic division-form path (ibs_long.hip), FP64 arithmetic on either element type
+  const bool lng = is_long(N);
+  int M = lng ? 1 : rows_per_lane(N);
   if (!table[M]) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   ON_DEVICE(ctx);
   auto launch = table[M];
-  size_t per_wave = (size_t)3 * ibs::lds_pitch(N) * sizeof(T);
+  size_t per_wave = (size_t)3 * ibs::lds_pitch(lng ? 66 : N) * sizeof(T);
+  auto launch_it = [&](const ibs::GcfArgs<T>& a) -> int {
+    if (!lng) { HIPCHK(launch(a, ctx->stream)); return 0; }
+    const int nw = long_waves(ctx, (long)a.n_sys);
+    if (int r = ensure_long_ws(ctx, (size_t)nw * 3 * (size_t)N * sizeof(double))) return r;
+    ibs::LongGcfArgs la{};
+    la.n_sys = a.n_sys; la.N = N; la.h = (double)a.h; la.g = a.g; la.c = a.c; la.f = a.f; la.gh = a.gh; la.f32 = sizeof(T) == 4;
+    la.ld = a.ld; la.lam = a.lam; la.gam = a.gam; la.X = a.X; la.dX = a.dX; la.info = a.info;
+    la.work = static_cast<double*>(ctx->long_ws); la.n_waves = nw;
+    HIPCHK(ibs::launch_gcf_long(la, ctx->stream));
+    return 0;
+  };
   if constexpr (sizeof(T) == 8) {
-    const int P = gh ? 64 : pick_lanes(ctx, N, (long)n_sys);
+    const int P = (gh || lng) ? 64 : pick_lanes(ctx, N, (long)n_sys);
     if (P != 64) {
       const int Mg = (N - 2 + P - 1) / P;
       auto fn = ibs::launch_table().gcf_f64_g[P == 32 ? 0 : 1][Mg];
       if (fn) { launch = fn; M = Mg; per_wave = (size_t)(64 / P) * ibs::lds_pitch(N) * sizeof(T); }
     }
   }
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (sizeof(T) == 4) if (!lng) {
     // FP32 systems whose growth rate or eigenfunction is wanted: FP32 in HBM, widened to FP64 as they are read, solved by the
     // FP64 solver -- in the same three forms as the FP64 entry point (sub-wave for large batches of short grids, row-streamed
     // for long grids, else one wave per system with the three rows staged).  lam alone stays with the all-FP32 kernel, whose
@@ -391,7 +437,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
       if (!gh && fl_ok && (P_lam != 64 || use_direct(ctx, N, (long)n_sys))) launch = fl;
     }
   }
-  if constexpr (sizeof(T) == 8) {
+  if constexpr (sizeof(T) == 8) if (!lng) {
     // long grids, one wave per system: stream the three rows through ONE LDS row per wave (k_solve_gcf_rows) -- the
     // 3-row staging of k_solve_gcf leaves two waves per CU at N_zeta = 2048 and five at 1024
     auto fr = ibs::launch_table().gcf_rows_f64[M];
@@ -406,6 +452,7 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d needs %zu B of LDS per wave", N, per_wave);
   ibs::GcfArgs<T> a{};
   a.n_sys = n_sys; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
+  a.flags = ctx->opt.reclose == 1 ? 1 : (ctx->opt.reclose == 2 ? 2 : 0);
   int* d_info = nullptr;
   int* d_nbad = nullptr;
   if (mem == IBS_MEM_HOST) {
@@ -428,7 +475,8 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     // (gam not asked for: the kernels then take their eigenvalue-only exits, as they do for device-pointer calls)
     a.g = dg; a.c = dc; a.f = df; a.lam = dlam; a.gam = gam ? dgam : nullptr; a.X = dX_; a.dX = ddX; a.info = d_info;
     if (gh) a.gh = dgh;
-    HIPCHK(launch(a, ctx->stream));
+    if (int r = launch_it(a)) return r;
+    flag_sigma<T>(ctx, (long)n_sys, a.lam, a.info);
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
     if (lam) HIPCHK(hs.down(lam, dlam, n_sys * sizeof(T)));
@@ -442,7 +490,8 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     return nbad;
   }
   a.g = g; a.c = c; a.f = f; a.lam = lam; a.gam = gam; a.X = X; a.dX = dX; a.info = info; a.gh = gh;
-  HIPCHK(launch(a, ctx->stream));
+  if (int r = launch_it(a)) return r;
+  flag_sigma<T>(ctx, (long)n_sys, a.lam, a.info);
   return 0;
 }
 
@@ -531,6 +580,7 @@ int ibs_destroy(ibs_ctx* c) {
   (void)ibs_comm_destroy(c);
   DeviceGuard g(c->device);
   if (c->ws) hipFree(c->ws);
+  if (c->long_ws) hipFree(c->long_ws);
   for (auto& sc : c->surf_counters) if (sc.buf) hipFree(sc.buf);
   if (c->refine_hist) hipHostFree(c->refine_hist);
   if (c->hs) hipHostFree(c->hs);
@@ -555,6 +605,8 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   else if (n == "gcf_direct") c->opt.gcf_direct = reset ? c->opt_created.gcf_direct : (int)value;
   else if (n == "pack_mode") c->opt.pack_mode = reset ? c->opt_created.pack_mode : (int)value;
   else if (n == "f32_lam") c->opt.f32_lam = reset ? c->opt_created.f32_lam : (int)value;
+  else if (n == "reclose") c->opt.reclose = reset ? c->opt_created.reclose : (int)value;
+  else if (n == "sigma0") c->opt.sigma0 = reset ? c->opt_created.sigma0 : value;
   else if (n == "refine_tangent") c->opt.refine_tangent = reset ? c->opt_created.refine_tangent : (int)value;
   else if (n == "chain_w1") c->opt.chain_w1 = reset ? c->opt_created.chain_w1 : value;
   else if (n == "chain_w2") c->opt.chain_w2 = reset ? c->opt_created.chain_w2 : value;
@@ -743,6 +795,44 @@ int ibs_solve_gcf_f32(ibs_ctx* ctx, int64_t n_sys, int32_t N, float h, const flo
   return solve_gcf_impl<float>(ctx, n_sys, N, h, g, c, f, ld, lam, gam, X, dX, info, mem, ibs::launch_table().gcf_f32);
 }
 
+// Geometry-fed scan on a grid beyond 2050 points: the (g, c, f) rows of every (line, theta0) system -- and their theta0 tangents when
+// dgam/dtheta0 is wanted -- are written out (k_assemble_gcf_long: the arithmetic the scan kernels do while staging), solved by the
+// generic long-grid kernel, and the Hellmann-Feynman sums (utils.py:1676-1680) taken by k_hf_grad.  Warm-start guesses are not
+// used (they only ever steer).  The context travels in a thread-local: the launch table's signature has no room for it.
+static thread_local ibs_ctx* g_long_ctx = nullptr;
+static hipError_t launch_scan_long(const ibs::ScanArgs<double>& a, hipStream_t st) {
+  ibs_ctx* ctx = g_long_ctx;
+  const size_t n_sys = (size_t)a.n_lines * a.n_theta0, N = (size_t)a.N;
+  const bool hf = a.dth0 != nullptr;
+  const int nw = long_waves(ctx, (long)n_sys);
+  const size_t rows = n_sys * N;
+  size_t need = (size_t)nw * 3 * N + (hf ? 6 : 3) * rows + 256;
+  if (hf) need += (a.X ? 0 : rows) + (a.dX ? 0 : rows) + (a.gam ? 0 : n_sys);
+  if (ensure_long_ws(ctx, need * sizeof(double)) != 0) return hipErrorOutOfMemory;
+  double* w = static_cast<double*>(ctx->long_ws);
+  double* work = w; w += (size_t)nw * 3 * N;
+  double* g = w; w += rows; double* c = w; w += rows; double* f = w; w += rows;
+  double *gt = nullptr, *ct = nullptr, *ft = nullptr, *Xw = a.X, *dXw = a.dX, *gamw = a.gam;
+  if (hf) {
+    gt = w; w += rows; ct = w; w += rows; ft = w; w += rows;
+    if (!Xw) { Xw = w; w += rows; }
+    if (!dXw) { dXw = w; w += rows; }
+    if (!gamw) { gamw = w; w += n_sys; }
+  }
+  hipError_t e = ibs::launch_assemble_long(a, g, c, f, gt, ct, ft, st);
+  if (e != hipSuccess) return e;
+  ibs::LongGcfArgs la{};
+  la.n_sys = (long)n_sys; la.N = a.N; la.h = a.h; la.g = g; la.c = c; la.f = f; la.gh = nullptr; la.f32 = 0; la.ld = (long)N;
+  la.lam = a.lam; la.gam = gamw; la.X = Xw; la.dX = dXw; la.info = a.info; la.work = work; la.n_waves = nw;
+  e = ibs::launch_gcf_long(la, st);
+  if (e != hipSuccess) return e;
+  if (hf) {
+    hipLaunchKernelGGL(k_hf_grad, dim3((unsigned)((n_sys + 3) / 4)), dim3(256), 0, st, (long)n_sys, a.N, (long)N, Xw, dXw, f, gt, ct, ft, gamw, a.dth0);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
 static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int32_t N, double h,
                            const double* bmag, const double* gradpar, const double* cvdrift, const double* cvdrift0,
                            const double* gds2, const double* gds21, const double* gds22, int64_t ld,
@@ -757,15 +847,22 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   if (n_lines < 0 || n_theta0 < 0 || !bmag || !gradpar || !cvdrift || !cvdrift0 || !gds2 || !gds21 || !gds22 ||
       !dPdrho || !theta0 || ld < N)
     return fail(IBS_ERR_ARG, "bad arguments (n_lines=%d n_theta0=%d ld=%lld N=%d)", n_lines, n_theta0, (long long)ld, N);
-  if (int r = check_grid(N, h)) return r;
+  if (int r = check_grid(N, h, true)) return r;
   if (n_lines == 0 || n_theta0 == 0) return 0;
-  int M = rows_per_lane(N);
+  const bool lng = is_long(N);                 // grids beyond 2050 points: launch_scan_long
+  int M = lng ? 1 : rows_per_lane(N);
   auto fn = ibs::launch_table().scan_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   ON_DEVICE(ctx);
+  ibs::ScanArgs<double> a{};
+  a.n_lines = n_lines; a.n_theta0 = n_theta0; a.N = N; a.h = h; a.ld = ld; a.wpb = 1;
+  a.t0_stride = t0_per_line ? 1 : 0;
+  int G = 1;
+  if (lng) { fn = &launch_scan_long; g_long_ctx = ctx; }
+  else {
   const size_t per_arr = (size_t)ibs::lds_pitch(N) * sizeof(double);
   if (8 * per_arr > (size_t)ctx->lds_per_block) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);
-  int G = 1, cap = ibs::scan_max_threads(M) / 64;
+  int cap = ibs::scan_max_threads(M) / 64;
   decltype(fn) fn_g_chain = nullptr;     // chained / warm-started sub-wave kernel of the same (P, M)
   {
     const int P = t0_per_line ? 64 : pick_lanes(ctx, N, (long)n_lines * n_theta0);
@@ -793,9 +890,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
   // balance the waves over the blocks of a line
   const int nblk = (waves_per_line + wpb - 1) / wpb;
   wpb = (waves_per_line + nblk - 1) / nblk;
-  ibs::ScanArgs<double> a{};
-  a.n_lines = n_lines; a.n_theta0 = n_theta0; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;
-  a.t0_stride = t0_per_line ? 1 : 0;
+  a.wpb = wpb;
   // A chain shortens the blocks (a line's waves = theta0 slots / chain) while every block still stages the whole line:
   // the LDS then limits the waves per CU.  Shorten the chain until the blocks that fit a CU hold as many waves as the
   // registers allow (tools/batch_sweep.py, 8 theta0 per line, N = 513, 65,536 solves: chain 4 = one wave per block =
@@ -867,6 +962,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
       }
     }
   }
+  }   // (!lng)
   const size_t n_sys = (size_t)n_lines * n_theta0;
   if (mem == IBS_MEM_HOST) {
     const size_t in_elems = (size_t)n_lines * ld, out_elems = n_sys * N;
@@ -895,6 +991,7 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
     a.dPdrho = ddP; a.theta0 = dt0; a.gam = dgam; a.lam = dlam; a.X = dX_; a.dX = ddX; a.dth0 = dth0 ? dd : nullptr; a.info = d_info;
     if (lam_guess) { a.lam_guess = dguess; a.guess_width = guess_width; }
     HIPCHK(fn(a, ctx->stream));
+    flag_sigma<double>(ctx, (long)n_sys, a.lam, a.info);
     HIPCHK(hipMemsetAsync(d_nbad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_count_status, dim3((unsigned)((n_sys + 255) / 256)), dim3(256), 0, ctx->stream, (long)n_sys, d_info, d_nbad);
     if (gam) HIPCHK(hs.down(gam, dgam, n_sys * 8));
@@ -930,9 +1027,11 @@ static int gamma_scan_impl(ibs_ctx* ctx, int32_t n_lines, int32_t n_theta0, int3
       if (ctx->opt.pack_mode == 1) a.pack_mode = 1;
     }
     HIPCHK(fn(a, ctx->stream));
+    flag_sigma<double>(ctx, (long)n_sys, a.lam, a.info);
     return 0;
   }
   HIPCHK(fn(a, ctx->stream));
+  flag_sigma<double>(ctx, (long)n_sys, a.lam, a.info);
   if (pack) {                                    // chained / sub-wave scan kernels: the reduction is a second launch
     const int n_per = (n_lines / n_surf) * n_theta0;
     hipLaunchKernelGGL(k_surface_argmax, dim3(n_surf), dim3(argmax_threads(n_per)), 0, ctx->stream, n_per, gam, (int*)nullptr, (double*)nullptr, pack);
@@ -1054,9 +1153,16 @@ int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const d
 // ones are copied back ONCE per (pointers, counts, steps) -- a synchronisation the first call with a table set pays.
 static int geo_rows_fit_host(const int32_t* rows, int nrows, int nmodes, const double* xn, double dn, const char* which) {
   int fit = 1;
+  // (rows must not overlap: the table images of the row kernels are sized for ONE pair / group entry per mode -- 24 rows of
+  //  {0, 65} over 65 modes would each be "inside the list" and together write 24 times the image)
+  std::vector<char> taken((size_t)nmodes, 0);
   for (int r = 0; r < nrows; ++r) {
     const int first = rows[2 * r], cnt = rows[2 * r + 1];
     if (first < 0 || cnt < 1 || (long)first + cnt > nmodes) return fail(IBS_ERR_ARG, "%s[%d] = {%d, %d} lies outside the %d modes", which, r, first, cnt, nmodes);
+    for (int k = first; k < first + cnt; ++k) {
+      if (taken[k]) return fail(IBS_ERR_ARG, "%s[%d] = {%d, %d} overlaps an earlier row at mode %d: every mode may belong to one row only", which, r, first, cnt, k);
+      taken[k] = 1;
+    }
     if (cnt <= ibs::kGeoMaxPairs + 1) continue;
     int k0 = 0;
     if (dn != 0.0) {
@@ -1213,15 +1319,16 @@ int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const 
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
   if (n_sys < 0 || !g || !c || !f || !shift || !count || ld < N) return fail(IBS_ERR_ARG, "bad arguments");
   // the Sturm count itself has no Simpson stage: even N is fine here
-  if (N < 66 || N > 64 * ibs::kMaxM + 2) return fail(IBS_ERR_UNSUPPORTED, "N=%d outside [66, %d]", N, 64 * ibs::kMaxM + 2);
+  if (N < 66 || N > ibs::kMaxLongN) return fail(IBS_ERR_UNSUPPORTED, "N=%d outside [66, %d]", N, ibs::kMaxLongN);
   if (!(h > 0)) return fail(IBS_ERR_ARG, "h must be > 0");
   if (n_sys == 0) return 0;
-  const int M = rows_per_lane(N);
-  auto fn = ibs::launch_table().sturm_f64[M];
+  const bool lng = is_long(N);                 // (grids beyond 2050 points: division-form count, one wave per system: ibs_long.hip)
+  const int M = lng ? 1 : rows_per_lane(N);
+  auto fn = lng ? &ibs::launch_sturm_long : ibs::launch_table().sturm_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   ON_DEVICE(ctx);
   const size_t per_wave = (size_t)N * sizeof(double);
-  int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
+  int wpb = lng ? 1 : (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
   if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d needs %zu B of LDS per wave", N, per_wave);
   ibs::SturmArgs<double> a{};

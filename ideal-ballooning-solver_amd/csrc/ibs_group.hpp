@@ -211,6 +211,7 @@ struct GroupSolver {
       trial_rho = T(0); trial_del = T(-1);
     }
     trial_mrg = T(8 + N / 2) * Eps<T>::v * normA;
+    chk_slack = T(N < 256 ? 2 * N : 512) * Eps<T>::v * normA;        // min(8 tol, 2 N eps ||A||)   (solve<true>)
     return GP::sum_i(bad ? 1 : 0, lane) != 0;   // per group
   }
 
@@ -413,6 +414,12 @@ struct GroupSolver {
   // Optional warm start per group (see WaveSolver::solve): `guess` = eigenvalue of a nearby problem, `width` its
   // expected error (both group-replicated).  The first shift is guess + width and walks up geometrically until a
   // count certifies an upper bound; the next one is guess - width.  Certified exactly like the cold solve.
+  // CHK: the closing bracket's consistency check of WaveSolver::solve<true> (read its comment), per group
+  bool suspect;
+  int why;
+  T rho_last;
+  T chk_slack;     // (set by setup())
+  template <bool CHK = false>
   __device__ __forceinline__ T solve(bool bad, int& iters_out, int& status_out, bool warm = false, T guess = T(0),
                                      T width = T(0)) {
     using WS = WaveSolver<T, M>;
@@ -524,6 +531,15 @@ struct GroupSolver {
     iters_out = it;
     status_out = bad ? 2 : (done ? 0 : 1);
     lam = done ? ((finite_of(rho) && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi)) : sig;
+    if constexpr (CHK) {
+      const bool rho_in = finite_of(rho) && rho >= lo - chk_slack && rho <= hi + chk_slack;
+      suspect = done && !bad && !rho_in;
+      rho_last = rho;
+      lam = (done && rho_in) ? xmin(xmax(rho, lo), hi) : lam;
+      const T dist = xmax(xmax(lo - rho, rho - hi), T(0));
+      int bk = dist > T(0) ? expo_of(dist) - expo_of(tol) + 8 : 0;
+      why = (!done || bad) ? 0 : (finite_of(rho) ? (bk < 1 ? (dist > T(0) ? 1 : 0) : (bk > 63 ? 63 : bk)) : 63);
+    }
     return lam;
   }
 };

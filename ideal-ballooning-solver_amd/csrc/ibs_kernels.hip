@@ -349,6 +349,50 @@ __device__ __forceinline__ void finish_chunk(WaveSolver<T, M>& ws, Src& src, int
   }
 }
 
+// rows of one raw system straight from global memory (k_solve_gcf_direct; the division-form re-close of every raw kernel)
+template <typename T, typename TI>
+struct SrcDirect {
+  static constexpr bool kHasGh = false;
+  const TI* gg; const TI* cg; const TI* fg;
+  __device__ __forceinline__ T g(int j) const { return (T)gg[j]; }
+  __device__ __forceinline__ T c(int j) const { return (T)cg[j]; }
+  __device__ __forceinline__ T f(int j) const { return (T)fg[j]; }
+  __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { g_ = (T)gg[j]; c_ = (T)cg[j]; f_ = (T)fg[j]; }
+};
+template <typename T>
+struct SrcDirectH {      // ... with a caller-supplied half-grid g (ibs_solve_gcfh_f64)
+  static constexpr bool kHasGh = true;
+  const T* gg; const T* cg; const T* fg; const T* ghg;
+  __device__ __forceinline__ T g(int j) const { return gg[j]; }
+  __device__ __forceinline__ T c(int j) const { return cg[j]; }
+  __device__ __forceinline__ T f(int j) const { return fg[j]; }
+  __device__ __forceinline__ T gh(int k) const { return ghg[k]; }
+};
+
+// ---------------------------------------------------------------- FP64 raw systems: re-close of a suspect solve (round 6)
+// After WaveSolver::solve<true>: a solve whose closing bracket failed the consistency checks is closed again by division-form
+// multisection on the original rows `rows` (reclose_division: a few eps ||A||, independent of N).  flags (GcfArgs::flags,
+// ibs_set_option "reclose"): bit 0 = re-close, bit 1 = only mark (diagnostics); a suspect system carries the informational status
+// bit 3 either way.  Returns true when lam was replaced: the caller then repeats the eigenvector stage at it (redo_vector_at).
+template <typename T, int M, class Rows>
+__device__ __forceinline__ bool reclose_suspect(const WaveSolver<T, M>& ws, SolveInfo& inf, const Rows& rows, int N, T h, int flags,
+                                                T& lam) {
+  if (!(flags & 1)) {                                      // mark-only (diagnostics): every polish outside the bracket, and how far
+    if (flags != 0 && ws.why != 0) inf.status |= 8 | (ws.why << 5);
+    return false;
+  }
+  if (!ws.suspect) return false;                           // (wave-uniform)
+  inf.status |= 8;
+  int passes;
+  T l2;
+  const T center = WaveSolver<T, M>::U(finite_of(ws.rho_last)) ? ws.rho_last : lam;
+  const bool ok = reclose_division<T, Rows>(rows, N, h, center, ws.normA, ws.lane, l2, passes);
+  inf.iters += passes;
+  if (!ok) { inf.status |= 1; return false; }
+  lam = l2;
+  return true;
+}
+
 // ---------------------------------------------------------------- raw (g, c, f) systems
 // block = WPB waves, one system per wave; dynamic LDS = WPB * 3N * sizeof(T): (g, c, f) staged once
 // through LDS for the chunked register load; afterwards the eigenfunction X reuses f's slot and the
@@ -357,7 +401,7 @@ template <typename T, int M>
 __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const T* __restrict__ g,
                                                    const T* __restrict__ c, const T* __restrict__ f, long ld,
                                                    T* lam_out, T* gam_out, T* X_out, T* dX_out, int* info_out,
-                                                   const T* __restrict__ gh) {
+                                                   const T* __restrict__ gh, int flags) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -369,6 +413,7 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   T* gs = smem + (size_t)wave * 3 * P;
   T* cs = gs + P; T* fs = cs + P; T* Xs = fs;
   const T* gg = g + sysc * ld; const T* cg = c + sysc * ld; const T* fg = f + sysc * ld;
+  const bool want_vec = gam_out || X_out || dX_out;     // (kernel-uniform)
   for (int j = lane; j < N; j += kWave) { const int q = lpos(j); gs[q] = gg[j]; cs[q] = cg[j]; fs[q] = fg[j]; }
   wave_lds_sync();   // the staging rows are private to this wave
   SrcGCF<T> src{gs, cs, fs};
@@ -383,9 +428,16 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
   else bad = ws.template setup<SrcGCF<T>, kTrial>(src, N, h);
   wave_lds_sync();   // every lane has taken its f chunk: the (wave-private) slot can be reused for X
   T lam = T(0);
+  bool redo = false;   // the solve was re-closed in division form: the eigenvector stage is repeated at the end (FP64 only)
   if (!bad) {
-    if constexpr (kTrial) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
-    else lam = ws.solve(inf);
+    if constexpr (kTrial) {
+      T g_, w_;
+      ws.trial_guess(g_, w_);
+      lam = ws.template solve<true>(inf, true, g_, w_);
+      // (a suspect solve is closed again in division form on the rows in global memory)
+      if (gh) { const SrcDirectH<T> sd{gg, cg, fg, gh + sysc * ld}; redo = reclose_suspect<T, M>(ws, inf, sd, N, h, flags, lam); }
+      else { const SrcDirect<T, T> sd{gg, cg, fg}; redo = reclose_suspect<T, M>(ws, inf, sd, N, h, flags, lam); }
+    } else lam = ws.solve(inf);
   } else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   if constexpr (sizeof(T) == 4) {
     // FP64 CERTIFICATE of the all-FP32 result.  FP32 Sturm counts are good to ~eps32 ||A||; between two close eigenvalues a
@@ -409,7 +461,7 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
       } else inf.iters += 2;
     }
   }
-  if (!gam_out && !X_out && !dX_out) {     // (kernel-uniform) eigenvalues only: no eigenvector, no Simpson sums
+  if (!want_vec) {                         // (kernel-uniform) eigenvalues only: no eigenvector, no Simpson sums
     if (lane == 0 && valid) {
       if (lam_out) lam_out[sysc] = lam;
       if (info_out) info_out[sysc] = inf.iters | (inf.status << 16);
@@ -428,6 +480,30 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
                                    nullptr, valid ? info_out : nullptr, static_cast<const NoTangent*>(nullptr), nullptr,
                                    gh ? gh + sysc * ld : nullptr);
   }
+  if constexpr (kTrial) {
+    if (redo) {                            // (wave-uniform, rare) eigenvector stage once more, at the re-closed eigenvalue
+      wave_lds_sync();
+      for (int j = lane; j < N; j += kWave) fs[lpos(j)] = fg[j];     // (X / dX went through f's slot)
+      wave_lds_sync();
+      WaveSolver<T, M> w2;
+      if (gh) { SrcGCFH<T> srch{gs, cs, fs, gh + sysc * ld}; (void)w2.template setup<SrcGCFH<T>, false>(srch, N, h); }
+      else (void)w2.template setup<SrcGCF<T>, false>(src, N, h);
+      wave_lds_sync();
+      w2.sweep(lam); w2.twisted(lam);
+      if constexpr (M >= 3) {
+        finish_chunk<T, M, SrcGCF<T>, false>(w2, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                             valid ? gam_out : nullptr, valid ? X_out : nullptr,
+                                             valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr,
+                                             gh ? gh + sysc * ld : nullptr);
+      } else {
+        const SrcGCFG<T> srcf{gs, cs, fg};
+        finish<T, M, SrcGCFG<T>, false>(w2, srcf, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                       valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                       nullptr, valid ? info_out : nullptr, static_cast<const NoTangent*>(nullptr), nullptr,
+                                       gh ? gh + sysc * ld : nullptr);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- raw (g, c, f) systems, rows straight from global memory
@@ -438,19 +514,10 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
 // owns it), once in setup() and once more in the growth-rate stage (L2 / Infinity Cache), like the sub-wave kernels do
 // at 32 / 16 lanes per system.  No LDS at all unless X / dX are requested (then one row per wave).
 // TI = float: FP32 in HBM, widened exactly as read, FP64 solver (the arithmetic of k_solve_gcf_wide).
-template <typename T, typename TI>
-struct SrcDirect {
-  static constexpr bool kHasGh = false;
-  const TI* gg; const TI* cg; const TI* fg;
-  __device__ __forceinline__ T g(int j) const { return (T)gg[j]; }
-  __device__ __forceinline__ T c(int j) const { return (T)cg[j]; }
-  __device__ __forceinline__ T f(int j) const { return (T)fg[j]; }
-  __device__ __forceinline__ void gcf(int j, T& g_, T& c_, T& f_) const { g_ = (T)gg[j]; c_ = (T)cg[j]; f_ = (T)fg[j]; }
-};
 template <typename T, int M, typename TI>
 __device__ __forceinline__ void solve_gcf_direct_body(long n_sys, int N, T h, const TI* __restrict__ g, const TI* __restrict__ c,
                                                       const TI* __restrict__ f, long ld, TI* lam_out, TI* gam_out, TI* X_out,
-                                                      TI* dX_out, int* info_out) {
+                                                      TI* dX_out, int* info_out, int flags) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -461,11 +528,17 @@ __device__ __forceinline__ void solve_gcf_direct_body(long n_sys, int N, T h, co
   SrcDirect<T, TI> src{g + sysc * ld, c + sysc * ld, f + sysc * ld};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
+  const bool want_vec = gam_out || X_out || dX_out;     // (kernel-uniform)
   const bool bad = ws.template setup<SrcDirect<T, TI>, true>(src, N, h);
   T lam = T(0);
-  if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
-  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
-  if (!gam_out && !X_out && !dX_out) {     // (kernel-uniform) eigenvalues only
+  bool redo = false;   // the solve was re-closed in division form: the eigenvector stage is repeated at the end
+  if (!bad) {
+    T g_, w_;
+    ws.trial_guess(g_, w_);
+    lam = ws.template solve<true>(inf, true, g_, w_);
+    redo = reclose_suspect<T, M>(ws, inf, src, N, h, flags, lam);
+  } else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  if (!want_vec) {                         // (kernel-uniform) eigenvalues only
     if (lane == 0 && valid) {
       if (lam_out) lam_out[sysc] = (TI)lam;
       if (info_out) info_out[sysc] = inf.iters | (inf.status << 16);
@@ -475,12 +548,21 @@ __device__ __forceinline__ void solve_gcf_direct_body(long n_sys, int N, T h, co
   finish_chunk<T, M, SrcDirect<T, TI>, false, 1, TI>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                                      valid ? gam_out : nullptr, valid ? X_out : nullptr,
                                                      valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
+  if (redo) {                              // (wave-uniform, rare) eigenvector stage once more, at the re-closed eigenvalue
+    if (Xs) wave_lds_sync();
+    WaveSolver<T, M> w2;
+    (void)w2.template setup<SrcDirect<T, TI>, false>(src, N, h);
+    w2.sweep(lam); w2.twisted(lam);
+    finish_chunk<T, M, SrcDirect<T, TI>, false, 1, TI>(w2, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                                       valid ? gam_out : nullptr, valid ? X_out : nullptr,
+                                                       valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
+  }
 }
 template <typename T, int M, typename TI>
 __global__ void __launch_bounds__(256) k_solve_gcf_direct(long n_sys, int N, T h, const TI* __restrict__ g,
                                                           const TI* __restrict__ c, const TI* __restrict__ f, long ld,
-                                                          TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
-  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out);
+                                                          TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags) {
+  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out, flags);
 }
 // The same kernel held to two waves per SIMD (256 registers).  The allocator left to itself takes AGPRs from M = 21 on (one wave
 // per SIMD, `valu_issue` 0.39-0.53); capped, M = 21 .. 28 spill 12-232 B per lane and still gain: FP64 rows 1.17-1.5x (N_zeta =
@@ -491,8 +573,8 @@ constexpr bool direct_two_waves(int M, bool f32_rows) { return M >= 21 && M <= (
 template <typename T, int M, typename TI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_solve_gcf_direct_w2(long n_sys, int N, T h, const TI* __restrict__ g, const TI* __restrict__ c, const TI* __restrict__ f, long ld,
-                      TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
-  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out);
+                      TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags) {
+  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out, flags);
 }
 
 // FP32 eigenvalues only, rows straight from global memory: the all-FP32 shift iteration of k_solve_gcf<float, M> and its FP64
@@ -568,7 +650,7 @@ template <int M>
 __global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float h, const float* __restrict__ g,
                                                         const float* __restrict__ c, const float* __restrict__ f, long ld,
                                                         float* lam_out, float* gam_out, float* X_out, float* dX_out,
-                                                        int* info_out) {
+                                                        int* info_out, int flags) {
   using T = double;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -586,12 +668,19 @@ __global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float
   SrcGCF<T> src{gs, cs, fs};
   WaveSolver<T, M> ws;
   SolveInfo inf{0, 0};
+  const bool want_vec = gam_out || X_out || dX_out;     // (kernel-uniform)
   const bool bad = ws.template setup<SrcGCF<T>, true>(src, N, (T)h);
   wave_lds_sync();
   T lam = T(0);
-  if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
-  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
-  if (!gam_out && !X_out && !dX_out) {     // (kernel-uniform) eigenvalues only
+  bool redo = false;   // the solve was re-closed in division form: the eigenvector stage is repeated at the end
+  if (!bad) {
+    T g_, w_;
+    ws.trial_guess(g_, w_);
+    lam = ws.template solve<true>(inf, true, g_, w_);
+    const SrcDirect<T, float> sd{gg, cg, fg};
+    redo = reclose_suspect<T, M>(ws, inf, sd, N, (T)h, flags, lam);
+  } else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  if (!want_vec) {                         // (kernel-uniform) eigenvalues only
     if (lane == 0 && valid) {
       if (lam_out) lam_out[sysc] = (float)lam;
       if (info_out) info_out[sysc] = inf.iters | (inf.status << 16);
@@ -608,6 +697,25 @@ __global__ void __launch_bounds__(256) k_solve_gcf_wide(long n_sys, int N, float
     finish<T, M, SrcGCFW, false, NoTangent, float>(ws, srcf, N, (T)h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                                 valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
                                                 nullptr, valid ? info_out : nullptr);
+  }
+  if (redo) {                              // (wave-uniform, rare) eigenvector stage once more, at the re-closed eigenvalue
+    wave_lds_sync();
+    for (int j = lane; j < N; j += kWave) fs[lpos(j)] = (T)fg[j];     // (X / dX went through f's slot)
+    wave_lds_sync();
+    WaveSolver<T, M> w2;
+    (void)w2.template setup<SrcGCF<T>, false>(src, N, (T)h);
+    wave_lds_sync();
+    w2.sweep(lam); w2.twisted(lam);
+    if constexpr (M >= 3) {
+      finish_chunk<T, M, SrcGCF<T>, false, 1, float>(w2, src, N, (T)h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                                      valid ? gam_out : nullptr, valid ? X_out : nullptr,
+                                                      valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
+    } else {
+      const SrcGCFW srcf{gs, cs, fg};
+      finish<T, M, SrcGCFW, false, NoTangent, float>(w2, srcf, N, (T)h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
+                                                  valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                                  nullptr, valid ? info_out : nullptr);
+    }
   }
 }
 
@@ -774,6 +882,7 @@ __device__ __forceinline__ bool setup_rows(WaveSolver<T, M>& ws, SrcRows<T, M, T
   ws.trial_rho = wave_sum(tCx - tE) / wave_sum(tB);
   ws.trial_del = T(-1);                                  // (set by the caller)
   ws.trial_mrg = T(8 + N / 2) * Eps<T>::v * ws.normA;
+  ws.chk_slack = T(N < 256 ? 2 * N : 512) * Eps<T>::v * ws.normA;
   return __any(bad) != 0;
 }
 
@@ -819,7 +928,7 @@ __device__ __forceinline__ T trial_del_sampled(const TI* gq, const TI* cq, const
 template <typename T, int M, typename TI = T>
 __global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, const TI* __restrict__ g,
                                                         const TI* __restrict__ c, const TI* __restrict__ f, long ld,
-                                                        TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
+                                                        TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags) {
   static_assert(M >= 3, "long grids only");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -841,8 +950,14 @@ __global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, 
   ws.trial_del = t_del;
   IBS_PROBE_AT(2);
   T lam = T(0);
-  if (!bad) { T g_, w_; ws.trial_guess(g_, w_); lam = ws.solve(inf, true, g_, w_); }
-  else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
+  bool redo = false;   // the solve was re-closed in division form: the eigenvector stage is repeated at the end
+  if (!bad) {
+    T g_, w_;
+    ws.trial_guess(g_, w_);
+    lam = ws.template solve<true>(inf, true, g_, w_);
+    const SrcDirect<T, TI> sd{src.gg, src.cg, src.fg};
+    redo = reclose_suspect<T, M>(ws, inf, sd, N, h, flags, lam);
+  } else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   IBS_PROBE_AT(3);
   // (the first batch of the next row requested while the current row is worked on -- to hide one of the two exposed memory
   //  latencies per staged row, 33 of this kernel's 63 us -- was built and measured: the 34 registers it keeps live cost more in
@@ -859,6 +974,15 @@ __global__ void __launch_bounds__(256) k_solve_gcf_rows(long n_sys, int N, T h, 
                                                       valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
                                                       nullptr, valid ? info_out : nullptr);
   IBS_PROBE_AT(4);
+  if (redo) {                              // (wave-uniform, rare) eigenvector stage once more, at the re-closed eigenvalue
+    WaveSolver<T, M> w2;
+    (void)setup_rows<T, M, TI>(w2, src, N, h);
+    w2.sweep(lam); w2.twisted(lam);
+    src.hold(0);
+    finish_chunk<T, M, SrcRows<T, M, TI>, false, 3, TI>(w2, src, N, h, row, lam, inf, sysc, valid ? lam_out : nullptr,
+                                                        valid ? gam_out : nullptr, valid ? X_out : nullptr, valid ? dX_out : nullptr,
+                                                        nullptr, valid ? info_out : nullptr);
+  }
 }
 
 // ---------------------------------------------------------------- geometry-fed theta0 scan
@@ -1521,7 +1645,7 @@ static hipError_t launch_gcf(const GcfArgs<T>& a, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
-                     a.lam, a.gam, a.X, a.dX, a.info, a.gh);
+                     a.lam, a.gam, a.X, a.dX, a.info, a.gh, a.flags);
   note_launch(nblk, wpb * 64, "ibs::k_solve_gcf<%s, %d>", type_name<T>(), IBS_M);
   return hipGetLastError();
 }
@@ -1533,7 +1657,7 @@ static hipError_t launch_gcf_wide(const GcfArgs<float>& a, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
-                     a.lam, a.gam, a.X, a.dX, a.info);
+                     a.lam, a.gam, a.X, a.dX, a.info, a.flags);
   note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_wide<%d>", IBS_M);
   return hipGetLastError();
 }
@@ -1544,7 +1668,7 @@ static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
     const size_t lds = (a.X || a.dX) ? (size_t)wpb * lds_pitch(a.N) * sizeof(double) : 0;
     const long nblk = (a.n_sys + wpb - 1) / wpb;
     constexpr bool w2 = direct_two_waves(IBS_M, sizeof(TI) == 4);
-    void (*kern)(long, int, double, const TI*, const TI*, const TI*, long, TI*, TI*, TI*, TI*, int*);
+    void (*kern)(long, int, double, const TI*, const TI*, const TI*, long, TI*, TI*, TI*, TI*, int*, int);
     if constexpr (w2) kern = k_solve_gcf_direct_w2<double, IBS_M, TI>;      // (only the form that runs is instantiated)
     else kern = k_solve_gcf_direct<double, IBS_M, TI>;
     if (lds) {
@@ -1552,7 +1676,7 @@ static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, (double)a.h, a.g, a.c, a.f, a.ld,
-                       a.lam, a.gam, a.X, a.dX, a.info);
+                       a.lam, a.gam, a.X, a.dX, a.info, a.flags);
     note_launch(nblk, wpb * 64, w2 ? "ibs::k_solve_gcf_direct_w2<double, %d, %s>" : "ibs::k_solve_gcf_direct<double, %d, %s>", IBS_M, type_name<TI>());
     return hipGetLastError();
   } else {
@@ -1588,7 +1712,7 @@ static hipError_t launch_gcf_rows(const GcfArgs<T>& a, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
-                       a.lam, a.gam, a.X, a.dX, a.info);
+                       a.lam, a.gam, a.X, a.dX, a.info, a.flags);
     note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_rows<%s, %d, %s>", type_name<T>(), IBS_M, type_name<T>());
     return hipGetLastError();
   } else {
@@ -1605,7 +1729,7 @@ static hipError_t launch_gcf_rows_wide(const GcfArgs<float>& a, hipStream_t st) 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, (double)a.h, a.g, a.c, a.f, a.ld,
-                       a.lam, a.gam, a.X, a.dX, a.info);
+                       a.lam, a.gam, a.X, a.dX, a.info, a.flags);
     note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_rows<double, %d, float>", IBS_M);
     return hipGetLastError();
   } else {

@@ -8,12 +8,14 @@
 namespace ibs {
 
 constexpr int kMaxM = 32;   // rows per lane: N - 2 <= 64 * kMaxM  (N <= 2050)
+constexpr int kMaxLongN = 65537;   // longer grids, up to this many points, run on the generic division-form path (ibs_long.hip)
 
 template <typename T>
 struct GcfArgs {
   long n_sys; int N; T h; const T* g; const T* c; const T* f; long ld;
   T* lam; T* gam; T* X; T* dX; int* info; int wpb;
   const T* gh;      // optional half-grid g [n_sys][ld] (N-1 used); null = mean of neighbouring g
+  int flags;        // FP64 solvers: bit 0 = re-close suspect systems in division form, bit 1 = only mark them (reclose_if_suspect)
 };
 template <typename T>
 struct ScanArgs {
@@ -41,6 +43,18 @@ struct GradArgs {
   T *val, *jac, *gam, *dalpha, *dth0; int* info; int wpb;
   long arr_stride, line_stride;   // 0 = the [n_pts][3][8][ld] layout (ld, 8 ld); see k_obj_w_grad
 };
+
+// grids beyond 64 * kMaxM + 2 points (ibs_long.hip): one wave per system, division form throughout
+struct LongGcfArgs {
+  long n_sys; int N; double h;
+  const void *g, *c, *f, *gh; int f32;      // f32: the arrays (inputs and outputs) are float; the arithmetic is FP64 either way
+  long ld; void *lam, *gam, *X, *dX; int* info;
+  double* work; int n_waves;                // n_waves * 3 * N doubles of workspace; the grid is min(n_sys, n_waves) waves
+};
+hipError_t launch_gcf_long(const LongGcfArgs& a, hipStream_t st);
+hipError_t launch_sturm_long(const SturmArgs<double>& a, hipStream_t st);
+template <typename T> struct ScanArgs;
+hipError_t launch_assemble_long(const ScanArgs<double>& a, double* g, double* c, double* f, double* gt, double* ct, double* ft, hipStream_t st);
 
 // field-line geometry kernel (ibs_geometry.hip)
 struct GeoForm { int ppl, lpp; };   // grid points per lane, lanes per grid point (one of them is 1)

@@ -1,0 +1,256 @@
+// Grids beyond the register-resident kernels (N > 64 * kMaxM + 2 = 2050 points, up to kMaxLongN): the generic path that keeps the
+// drop-in from refusing what the reference computes -- utils.py:1556-1624 accepts any length, and the reference's own grid rule
+// N = 2 mpol ntor 4 + 1 (ball_scan.py:201-208) passes 2050 from mpol ntor > 256 on.  Correctness first, speed second.
+//
+// One wavefront per system, everything in DIVISION form on the original rows (no scaled rows, nothing register-resident):
+//   1. bounds        lam_max <= max c/f (Gershgorin), lam_max >= max d/f (unit vectors), ||A||; data checks
+//   2. eigenvalue    64-way multisection on division-form Sturm counts (ibs_wave.hpp: count_above_div / multisect_division --
+//                    the recurrence of SURVEY Appendix A / LAPACK dstebz), ~9 passes from the Gershgorin bracket to eps ||A||
+//   3. eigenvector   twisted factorisation N_k D_k N_k^T of T - lam F (the getvec step of MRRR): forward pivots D+ (lane 0) and
+//                    backward pivots D- (lane 1) in one serial pass, gamma_r = D+_r + D-_r - (d_r - lam f_r) in parallel, twist row
+//                    k = argmin |gamma_r|, then z_k = 1, z_{r-1} = -e_r z_r / D+_{r-1} downwards (lane 0) and
+//                    z_{r+1} = -e_{r+1} z_r / D-_{r+1} upwards (lane 1)
+//   4. growth rate   X = z / max |z| with zero end points, FD2/FD4 derivative, composite Simpson quotient: the arithmetic of
+//                    finish() in ibs_kernels.hip, i.e. utils.py:1601-1621
+// Per-wave workspace in global memory: 3 N doubles (D+, D-, d - lam f; the last becomes z).  The grid is persistent: a fixed
+// number of waves, each taking systems blockIdx.x, blockIdx.x + gridDim.x, ...
+#include "ibs_wave.hpp"
+#include "ibs_launch.hpp"
+
+namespace ibs {
+
+template <typename TI, bool HAS_GH>
+struct SrcLong {
+  static constexpr bool kHasGh = HAS_GH;
+  const TI* gg; const TI* cg; const TI* fg; const TI* ghg;
+  __device__ __forceinline__ double g(int j) const { return (double)gg[j]; }
+  __device__ __forceinline__ double c(int j) const { return (double)cg[j]; }
+  __device__ __forceinline__ double f(int j) const { return (double)fg[j]; }
+  __device__ __forceinline__ double gh(int k) const { return (double)ghg[k]; }
+  // e_k = half-grid g between grid points k and k + 1, over h^2 (utils.py:1574-1576, 1584-1592)
+  __device__ __forceinline__ double e(int k, double ih2) const {
+    if constexpr (HAS_GH) return (double)ghg[k] * ih2;
+    else return 0.5 * ((double)gg[k] + (double)gg[k + 1]) * ih2;
+  }
+};
+
+__device__ __forceinline__ void long_fence() {      // stores of two lanes, read by all lanes of the same wave afterwards
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+template <typename TI, bool HAS_GH>
+__device__ __forceinline__ void solve_long_one(const SrcLong<TI, HAS_GH>& src, int N, double h, long sys, double* work, TI* lam_out,
+                                               TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
+  constexpr double pivmin = 2.2250738585072014e-292;
+  const int lane = threadIdx.x & 63;
+  const int n = N - 2;
+  const double ih2 = 1.0 / (h * h);
+  // ---- 1. bounds and data checks (lanes strided over the rows)
+  double vhi = -1e300, vlo = -1e300, vna = 0.0;
+  bool bad = false;
+  for (int r = lane; r < n; r += kWave) {
+    const int j = r + 1;
+    const double e_lo = src.e(r, ih2), e_hi = src.e(j, ih2);
+    const double cj = src.c(j), fj = src.f(j), gj = src.g(j);
+    const double d = cj - (e_lo + e_hi);
+    const double rf = 1.0 / fj;
+    vhi = xmax(vhi, cj * rf); vlo = xmax(vlo, d * rf); vna = xmax(vna, (xabs(d) + e_lo + e_hi) * rf);
+    bad = bad || !(fj > 0.0) || !(gj > 0.0) || !(e_lo > 0.0) || !(e_hi > 0.0) || !finite_of(cj) || !finite_of(fj) || !finite_of(e_lo + e_hi);
+  }
+  if (lane == 0) bad = bad || !(src.g(0) > 0.0) || !(src.g(N - 1) > 0.0);
+  const double normA = uniform(wave_max(vna));
+  double hi = uniform(wave_max(vhi)) + 8.0 * Eps<double>::v * normA;
+  double lo = uniform(wave_max(vlo)) - 8.0 * Eps<double>::v * normA;
+  int status = 0, passes = 0;
+  double lam = 0.0;
+  const bool want_vec = gam_out || X_out || dX_out;        // (kernel-uniform)
+  if (__any(bad) || !finite_of(normA)) {
+    status = 2;
+    lam = __builtin_nan("");
+  } else {
+    // ---- 2. eigenvalue
+    if (!multisect_division<double>(src, N, h, lo, hi, normA, lane, lam, passes)) status = 1;
+  }
+  double gam = __builtin_nan("");
+  if (want_vec && status == 0) {
+    double* Dp = work; double* Dm = work + N; double* A = work + 2 * (size_t)N;     // A[r] = d_r - lam f_r, later z_r
+    // ---- 3a. pivots: lane 0 walks the rows upwards (D+), lane 1 downwards (D-)
+    if (lane < 2) {
+      const bool fw = lane == 0;
+      double q = 1.0;
+      for (int s = 0; s < n; ++s) {
+        const int r = fw ? s : n - 1 - s;
+        const int j = r + 1;
+        const double e_lo = src.e(r, ih2), e_hi = src.e(j, ih2);
+        const double a = xfma(-lam, src.f(j), src.c(j) - (e_lo + e_hi));
+        const double ec = fw ? e_lo : e_hi;                 // the coupling to the row this lane comes from
+        q = s == 0 ? a : a - (ec * ec) / q;
+        q = xabs(q) < pivmin ? -pivmin : q;
+        if (fw) { Dp[r] = q; A[r] = a; } else Dm[r] = q;
+      }
+    }
+    long_fence();
+    // ---- 3b. twist row: the smallest |gamma_r|
+    double best = 1e300;
+    int bi = 0;
+    for (int r = lane; r < n; r += kWave) {
+      const double gm = xabs(Dp[r] + Dm[r] - A[r]);
+      if (gm < best) { best = gm; bi = r; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const double b2 = __shfl_xor(best, d);
+      const int i2 = __shfl_xor(bi, d);
+      if (b2 < best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
+    }
+    const int k = __builtin_amdgcn_readfirstlane(bi);
+    long_fence();                                           // (A is overwritten by z below: every lane has read it)
+    // ---- 3c. eigenvector from the twist row outwards
+    if (lane < 2) {
+      const bool dn = lane == 0;
+      double z = 1.0;
+      if (dn) A[k] = 1.0;
+      const int steps = dn ? k : n - 1 - k;
+      for (int s = 0; s < steps; ++s) {
+        const int r = dn ? k - s : k + s;                   // row whose z is known
+        // downwards: z_{r-1} = -e_r z_r / D+_{r-1};  upwards: z_{r+1} = -e_{r+1} z_r / D-_{r+1}
+        const double ec = dn ? src.e(r, ih2) : src.e(r + 1, ih2);
+        const int t = dn ? r - 1 : r + 1;
+        z = -(ec * z) / (dn ? Dp[t] : Dm[t]);
+        A[t] = z;
+      }
+    }
+    long_fence();
+    // ---- 4. growth rate (utils.py:1601-1621; the arithmetic of finish() in ibs_kernels.hip)
+    double m = 0.0;
+    for (int r = lane; r < n; r += kWave) m = xmax(m, xabs(A[r]));
+    m = uniform(wave_max(m));
+    const double rm = 1.0 / m;
+    auto Xat = [&](int j) { return (j <= 0 || j >= N - 1) ? 0.0 : A[j - 1] * rm; };     // utils.py:1605, 1607-1608
+    const double ih = 1.0 / h;
+    const double A_in = (2.0 / 3.0) * ih, B_in = -ih / 12.0, A_e1 = 0.5 * ih, A_e0 = 2.0 * ih, B_e0 = -0.5 * ih;
+    double y0 = 0.0, y1 = 0.0;
+    for (int j0 = 0; j0 < N; j0 += kWave) {
+      const int j = j0 + lane;
+      const bool in = j < N;
+      const int jc = in ? j : N - 1;
+      const int jm1 = jc > 0 ? jc - 1 : 0, jm2 = jc > 1 ? jc - 2 : 0;
+      const int jp1 = jc < N - 1 ? jc + 1 : N - 1, jp2 = jc < N - 2 ? jc + 2 : N - 1;
+      const double X = Xat(jc);
+      const double d1 = Xat(jp1) - Xat(jm1), d2 = Xat(jp2) - Xat(jm2);
+      const bool end0 = (jc == 0) || (jc == N - 1), end1 = (jc == 1) || (jc == N - 2);
+      const double Ac = end0 ? A_e0 : (end1 ? A_e1 : A_in), Bc = end0 ? B_e0 : (end1 ? 0.0 : B_in);
+      const double dX = xfma(Ac, d1, Bc * d2);                                       // utils.py:1610-1616
+      const double w = in ? (end0 ? 1.0 : ((jc & 1) ? 4.0 : 2.0)) : 0.0;             // Simpson weights (the 1/3 cancels)
+      const double X2 = w * (X * X), dX2 = w * (dX * dX);
+      y0 += src.c(jc) * X2 - src.g(jc) * dX2;                                        // utils.py:1618
+      y1 = xfma(src.f(jc), X2, y1);                                                  // utils.py:1619
+      if (X_out && in) X_out[sys * N + j] = (TI)X;
+      if (dX_out && in) dX_out[sys * N + j] = (TI)dX;
+    }
+    y0 = wave_sum(y0); y1 = wave_sum(y1);
+    gam = y0 / y1;                                                                   // utils.py:1621
+  }
+  if (lane == 0) {
+    if (lam_out) lam_out[sys] = (TI)lam;
+    if (gam_out) gam_out[sys] = (TI)gam;
+    if (info_out) info_out[sys] = passes | (status << 16);
+  }
+}
+
+template <typename TI>
+__global__ void __launch_bounds__(64) k_solve_gcf_long(long n_sys, int N, double h, const TI* __restrict__ g, const TI* __restrict__ c,
+                                                       const TI* __restrict__ f, const TI* __restrict__ gh, long ld, TI* lam_out,
+                                                       TI* gam_out, TI* X_out, TI* dX_out, int* info_out, double* work) {
+  double* my = work + (size_t)blockIdx.x * 3 * (size_t)N;
+  for (long sys = blockIdx.x; sys < n_sys; sys += gridDim.x) {
+    if (gh) {
+      const SrcLong<TI, true> src{g + sys * ld, c + sys * ld, f + sys * ld, gh + sys * ld};
+      solve_long_one<TI, true>(src, N, h, sys, my, lam_out, gam_out, X_out, dX_out, info_out);
+    } else {
+      const SrcLong<TI, false> src{g + sys * ld, c + sys * ld, f + sys * ld, nullptr};
+      solve_long_one<TI, false>(src, N, h, sys, my, lam_out, gam_out, X_out, dX_out, info_out);
+    }
+    long_fence();                                           // (the workspace is reused by this wave's next system)
+  }
+}
+
+// eigenvalues of (T, F) above shift[sys]: one wave per system, every lane the same shift (division form: exact for a pencil a few
+// ulp away, whatever N).  Replaces check_ball's verdict (bishop_ball_s-alpha.py:20-115) on grids beyond 2050 points.
+__global__ void __launch_bounds__(64) k_sturm_count_long(long n_sys, int N, double h, const double* __restrict__ g,
+                                                         const double* __restrict__ c, const double* __restrict__ f, long ld,
+                                                         const double* __restrict__ shift, int* count_out) {
+  const double ih2 = 1.0 / (h * h);
+  for (long sys = blockIdx.x; sys < n_sys; sys += gridDim.x) {
+    const SrcLong<double, false> src{g + sys * ld, c + sys * ld, f + sys * ld, nullptr};
+    const int cnt = count_above_div<double>(src, N, ih2, shift[sys]);
+    if ((threadIdx.x & 63) == 0) count_out[sys] = cnt;
+  }
+}
+
+// (g, c, f) of every (line, theta0) system of a geometry-fed scan, and their theta0 tangents, written out as rows: the long-grid
+// form of the staging the scan kernels do in LDS -- the same expressions in the same order (k_gamma_scan, SrcGeo), i.e.
+// ball_scan.py:267-268 + utils.py:1560-1562 and utils.py:1669-1673.
+__global__ void __launch_bounds__(256) k_assemble_gcf_long(int n_lines, int n_theta0, int N, const double* __restrict__ bmag,
+                                                           const double* __restrict__ gradpar, const double* __restrict__ cvdrift,
+                                                           const double* __restrict__ cvdrift0, const double* __restrict__ gds2,
+                                                           const double* __restrict__ gds21, const double* __restrict__ gds22, long ld,
+                                                           const double* __restrict__ dPdrho, const double* __restrict__ theta0,
+                                                           int t0_stride, double* g, double* c, double* f, double* gt, double* ct,
+                                                           double* ft) {
+  const long n_sys = (long)n_lines * n_theta0;
+  for (long sys = blockIdx.y; sys < n_sys; sys += gridDim.y) {
+    const int line = (int)(sys / n_theta0), it0 = (int)(sys - (long)line * n_theta0);
+    const double th0 = theta0[(long)line * t0_stride + it0], two_th0 = 2.0 * th0, th0sq = th0 * th0;
+    const double mdP = -dPdrho[line];
+    const long off = (long)line * ld;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+      const double B = bmag[off + j], gp = xabs(gradpar[off + j]);
+      const double inv = 1.0 / (gp * B);
+      const double A1 = gp / B, A3 = inv / (B * B);
+      const double C0 = mdP * cvdrift[off + j] * inv, C1 = mdP * cvdrift0[off + j] * inv;
+      const double G0 = gds2[off + j], G1 = gds21[off + j], G2 = gds22[off + j];
+      const double d = G0 + two_th0 * G1 + th0sq * G2;
+      const long o = sys * N + j;
+      g[o] = A1 * d; c[o] = C0 + th0 * C1; f[o] = A3 * d;
+      if (gt) { const double dp = 2.0 * G1 + two_th0 * G2; gt[o] = A1 * dp; ct[o] = C1; ft[o] = A3 * dp; }
+    }
+  }
+}
+
+hipError_t launch_gcf_long(const LongGcfArgs& a, hipStream_t st) {
+  const unsigned grid = (unsigned)(a.n_sys < a.n_waves ? a.n_sys : a.n_waves);
+  if (a.f32) {
+    hipLaunchKernelGGL(k_solve_gcf_long<float>, dim3(grid), dim3(64), 0, st, a.n_sys, a.N, a.h, (const float*)a.g, (const float*)a.c,
+                       (const float*)a.f, (const float*)a.gh, a.ld, (float*)a.lam, (float*)a.gam, (float*)a.X, (float*)a.dX, a.info, a.work);
+    note_launch(grid, 64, "ibs::k_solve_gcf_long<float>");
+  } else {
+    hipLaunchKernelGGL(k_solve_gcf_long<double>, dim3(grid), dim3(64), 0, st, a.n_sys, a.N, a.h, (const double*)a.g, (const double*)a.c,
+                       (const double*)a.f, (const double*)a.gh, a.ld, (double*)a.lam, (double*)a.gam, (double*)a.X, (double*)a.dX, a.info,
+                       a.work);
+    note_launch(grid, 64, "ibs::k_solve_gcf_long<double>");
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_sturm_long(const SturmArgs<double>& a, hipStream_t st) {
+  const long cap = 16384;
+  const unsigned grid = (unsigned)(a.n_sys < cap ? a.n_sys : cap);
+  hipLaunchKernelGGL(k_sturm_count_long, dim3(grid), dim3(64), 0, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld, a.shift, a.count);
+  note_launch(grid, 64, "ibs::k_sturm_count_long");
+  return hipGetLastError();
+}
+
+hipError_t launch_assemble_long(const ScanArgs<double>& a, double* g, double* c, double* f, double* gt, double* ct, double* ft,
+                                hipStream_t st) {
+  const long n_sys = (long)a.n_lines * a.n_theta0;
+  int bx = (a.N + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(k_assemble_gcf_long, dim3((unsigned)bx, (unsigned)(n_sys < 32768 ? n_sys : 32768)), dim3(256), 0, st, a.n_lines, a.n_theta0, a.N, a.bmag,
+                     a.gradpar, a.cvdrift, a.cvdrift0, a.gds2, a.gds21, a.gds22, a.ld, a.dPdrho, a.theta0, a.t0_stride, g, c, f, gt, ct, ft);
+  return hipGetLastError();
+}
+
+}  // namespace ibs

@@ -318,6 +318,74 @@ __device__ __forceinline__ M2<T> scan_bwd(M2<T> Q, int lane) {
   return Q;
 }
 
+// ---------------------------------------------------------------- division-form re-close (round 6)
+// The matrix whose top eigenvalue is meant is utils.py:1584-1597; the recurrence is SURVEY.md Appendix A's / LAPACK dstebz's
+//   q_0 = d_0 - sig f_1,   q_r = (d_r - sig f_{r+1}) - e_r^2 / q_{r-1},   |q| < pivmin -> -pivmin,
+// #(q_r > 0) = eigenvalues of (T, F) above sig.  Every step is one rounded operation on the ORIGINAL entries, so the count is exact
+// for a pencil whose entries differ by a few ulp each: its error in sig is a few eps ||A||, independent of N (the prefix-product
+// sweeps of WaveSolver are exact for a perturbation that can reach ~N^2 eps ||A||).  It is serial in the rows, so the wave runs it
+// for 64 SHIFTS at once: lane L walks ALL rows of the one system at its own shift (the loads are wave-uniform: one request each).
+// Src: g(j), c(j), f(j) [and gh(k)] for grid point j of that system, the same for every lane.
+template <typename T, class Src>
+__device__ __forceinline__ int count_above_div(const Src& src, int N, T ih2, T sig) {
+  constexpr T pivmin = T(2.2250738585072014e-292);      // DBL_MIN * 1e16
+  const int n = N - 2;
+  T gcur = T(0), e_lo;
+  if constexpr (Src::kHasGh) e_lo = src.gh(0) * ih2;
+  else { const T g0 = src.g(0); gcur = src.g(1); e_lo = T(0.5) * (g0 + gcur) * ih2; }
+  T q = T(1);
+  int cnt = 0;
+#pragma unroll 4
+  for (int r = 0; r < n; ++r) {          // (unrolled: the loads of the next rows are in flight while the divisions of these retire)
+    const int j = r + 1;
+    T e_hi;
+    if constexpr (Src::kHasGh) e_hi = src.gh(j) * ih2;
+    else { const T gnext = src.g(j + 1); e_hi = T(0.5) * (gcur + gnext) * ih2; gcur = gnext; }
+    const T d = src.c(j) - (e_lo + e_hi);                // the diagonal exactly as WaveSolver::setup forms it (utils.py:1584-1592)
+    const T a = xfma(-sig, src.f(j), d);
+    q = r == 0 ? a : a - (e_lo * e_lo) / q;
+    q = xabs(q) < pivmin ? -pivmin : q;
+    cnt += q > T(0) ? 1 : 0;
+    e_lo = e_hi;
+  }
+  return cnt;
+}
+
+// lam_max of the system `src` by 64-way multisection on division-form counts, from the bracket [lo, hi]: each pass runs 64 shifts
+// (lane 0 at lo, lane 63 at hi) and keeps the interval between the highest shift with an eigenvalue above it and the next one; a
+// bracket that does not hold lam_max (its end shifts say so) is moved and widened 64-fold instead.  Ends at width <= 2 eps ||A||.
+// All 64 lanes of the wave take part; the result is wave-uniform.
+// passes: sweeps used (each = n dependent divisions per lane);  returns false if 24 passes did not close (non-finite data).
+template <typename T, class Src>
+__device__ __forceinline__ bool multisect_division(const Src& src, int N, T h, T lo, T hi, T normA, int lane, T& lam, int& passes) {
+  const T ih2 = T(1) / (h * h);
+  const T epsA = Eps<T>::v * normA;
+  bool ok = false;
+  passes = 0;
+  while (passes < 24) {
+    ++passes;
+    const T w = hi - lo;
+    const T sig = lane == kWave - 1 ? hi : xfma(T(lane) * T(1.0 / 63.0), w, lo);
+    const int cnt = count_above_div<T, Src>(src, N, ih2, sig);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(cnt >= 1);
+    if (!(m & 1ull)) { hi = lo; lo = lo - T(64) * w; continue; }          // lam_max < lo
+    const int top = 63 - __builtin_clzll(m);                              // the highest shift with an eigenvalue above it
+    if (top == kWave - 1) { lo = hi; hi = hi + T(64) * w; continue; }     // lam_max >= hi
+    lo = readlane_t(sig, top); hi = readlane_t(sig, top + 1);
+    if (!(hi - lo > T(2) * epsA)) { ok = true; break; }
+  }
+  lam = T(0.5) * (lo + hi);
+  return ok;
+}
+// ... from a bracket of half width 2^11 eps ||A|| about `center` (the re-close of a suspect solve about its Rayleigh polish, which
+// was within 100 eps ||A|| of lam_max on every suspect of the 10 x 2^20-system campaign: two passes take a valid bracket to
+// 1.03 eps ||A||; a polish further off costs the passes that move the bracket)
+template <typename T, class Src>
+__device__ __forceinline__ bool reclose_division(const Src& src, int N, T h, T center, T normA, int lane, T& lam, int& passes) {
+  const T epsA = Eps<T>::v * normA;
+  return multisect_division<T, Src>(src, N, h, center - T(2048) * epsA, center + T(2048) * epsA, normA, lane, lam, passes);
+}
+
 // ---------------------------------------------------------------- per-wave solver state
 struct SolveInfo {
   int iters;    // fused double sweeps used
@@ -452,6 +520,7 @@ struct WaveSolver {
       trial_rho = T(0); trial_del = T(-1);
     }
     trial_mrg = T(8 + N / 2) * Eps<T>::v * normA;
+    chk_slack = T(N < 256 ? 2 * N : 512) * Eps<T>::v * normA;        // min(8 tol, 2 N eps ||A||), tol = 64 eps ||A||  (solve<true>)
     IBS_PROBE_AT(9);
     return __any(bad) != 0;
   }
@@ -684,6 +753,7 @@ struct WaveSolver {
   // turns such a compare into a scalar condition (ballot != 0: all lanes agree), so the control flow of the
   // iteration is scalar branches.
   __device__ __forceinline__ static bool U(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+  __device__ __forceinline__ static int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
   __device__ __forceinline__ static int lg2_of(const Pt& p) { const int e = expo_of(p.m); return e < -(1 << 27) ? e : p.e + e; }
   // Root of the parabola through (o, a, b) -- or of the secant through (a, b) when !use_o or the parabola has
   // no root in the bracket -- that lies in (lo_, hi_) nearest b.  Branch-free, one reciprocal level deep:
@@ -773,6 +843,27 @@ struct WaveSolver {
   // `width` its expected error.  The first shift is guess + width; if the count says lam_max is still
   // above, the shift walks up geometrically until the count certifies an upper bound; the next shift is
   // guess - width (expected count 1).
+  // CHK (round 6, the raw-system kernels): a consistency check of the closing bracket that costs nothing.  The counts of the
+  // prefix-product sweeps are exact for a matrix perturbed by up to ~N^2 eps ||A|| in the worst case (iid-random coefficients: a few
+  // systems per million close 2e-12 .. 1.5e-10 ||A|| away from lam_max), while the twisted factorisation at the last shift uses
+  // each solution only in its GROWING direction: its Rayleigh polish rho = sig + gamma_k / sum f x^2 (sign(gamma_k) is the twisted
+  // factorisation's verdict on which side of sig the eigenvalue lies) stays good where the eigenvector is localised -- exactly
+  // where the counts go wrong.  Measured on 10 x 2^20 systems against division-form bisection (tests/tools/reclose_campaign.py,
+  // profiles/r06_reclose_*): EVERY system beyond 4 N eps ||A|| had its polish 32 .. 2048 tol outside the certified bracket, and
+  // no system whose polish lay within 8 tol of it was off by more than 2e-13 ||A||.  (The other free check -- the backward sweep's
+  // count against the forward one at the last shift -- fired on 0.4-4 % of the rough systems and on none of the bad ones: dropped.)
+  // So: a polish within chk_slack = min(8 tol, 2 N eps ||A||) of the bracket is clamped into it (whichever of the two is right,
+  // the result is within max(4 tol, chk_slack) of lam_max); beyond that the solve is SUSPECT and the kernel closes it again by
+  // division-form multisection on the original rows (reclose_division above).  When the eigenvector is wanted as well, the kernel
+  // REPEATS set-up, one sweep pair at the re-closed eigenvalue and the growth-rate stage for that system after its regular
+  // outputs are written, i.e. where nothing of this solver is live any more: sweeping again with D / Ph still live (+16-24
+  // registers), jumping back into the iteration (+80) or looping back to set-up (+100 and scratch: the loop-invariant row loads
+  // get hoisted) all cost the raw kernels occupancy.
+  bool suspect;
+  int why;         // mark-only mode (diagnostics): floor(log2(distance of the polish from the bracket / tol)) + 8, 0 = inside
+  T rho_last;
+  T chk_slack;     // (set by setup())
+  template <bool CHK = false>
   __device__ __forceinline__ T solve(SolveInfo& inf, bool warm = false, T guess = T(0), T width = T(0)) {
     // f64: 64 ulp of ||A||;  f32: 8 ulp (the counts themselves are only good to ~eps32*||A||)
     const T tol = (sizeof(T) == 8 ? T(64) : T(8)) * Eps<T>::v * normA;
@@ -902,6 +993,15 @@ struct WaveSolver {
     IBS_PROBE_AT(12);
     if (done) lam = (finite_of(rho) && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi);
     else lam = sig;
+    if constexpr (CHK) {
+      const bool rho_in = U(finite_of(rho) && rho >= lo - chk_slack && rho <= hi + chk_slack);
+      suspect = done && !rho_in;
+      rho_last = rho;
+      if (done && rho_in) lam = xmin(xmax(rho, lo), hi);
+      const T dist = xmax(xmax(lo - rho, rho - hi), T(0));
+      int bk = dist > T(0) ? expo_of(dist) - expo_of(tol) + 8 : 0;
+      why = !done ? 0 : uniform_i(finite_of(rho) ? (bk < 1 ? (dist > T(0) ? 1 : 0) : (bk > 63 ? 63 : bk)) : 63);
+    }
 #ifdef IBS_TRACE
     if (lane == 0 && trace && it < 64) { T* q = trace + 6 * it; q[0] = sig; q[1] = T(-1); q[2] = rho; q[3] = lo; q[4] = hi; q[5] = T(wall_clock64() % 100000000); }
 #endif

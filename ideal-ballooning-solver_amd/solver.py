@@ -104,7 +104,9 @@ class Context:
         """create this rank's RCCL communicator inside the library; the unique id travels through `dist`
         (any initialised torch.distributed backend).  Collective over all ranks."""
         import torch
-        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        # (IBS_RCCL_LIB: another library with RCCL's five entry points -- the shared-memory stand-in tests/cabi/fake_rccl.c lets the
+        #  multi-rank code run on a one-GPU box, where RCCL refuses two ranks on one device)
+        rccl = os.environ.get("IBS_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         # every rank takes part in the same collectives of `dist` whatever fails locally (a rank that raised before the
         # broadcast would leave the others waiting in it): load, id, broadcast, agreement, and only then ncclCommInitRank
         ident = C.create_string_buffer(128)

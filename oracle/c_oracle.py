@@ -20,6 +20,8 @@ def lib():
         _lib.ibs_oracle_solve_gcf.argtypes = [I, D, P, P, P, P, P, P, P, P]
         _lib.ibs_oracle_solve_gcf_batch.argtypes = [L, I, D, P, P, P, L, P, P, I]
         _lib.ibs_oracle_gamma_scan.argtypes = [I, I, I, D, P, P, P, P, P, P, P, L, P, P, P, P, I]
+        _lib.ibs_oracle_lam_batch.argtypes = [L, I, D, P, P, P, L, P, I]
+        _lib.ibs_oracle_count_above_batch.argtypes = [L, I, D, P, P, P, L, P, P, I]
     return _lib
 
 
@@ -54,3 +56,22 @@ def gamma_scan(h, bmag, gradpar, cvdrift, cvdrift0, gds2, gds21, gds22, dPdrho, 
     used = lib().ibs_oracle_gamma_scan(nl, nt, N, float(h), *[_p(a) for a in arrs], N, _p(dPdrho), _p(theta0),
                                        _p(gam), _p(lam), int(nthreads))
     return gam, lam, used
+
+
+def lam_batch(h, g, c, f, nthreads=0):
+    """lam_max alone of every system (division-form bisection, no eigenvector stage)."""
+    g, c, f = (np.ascontiguousarray(a, dtype=np.float64) for a in (g, c, f))
+    n, N = g.shape
+    lam = np.zeros(n)
+    lib().ibs_oracle_lam_batch(n, N, float(h), _p(g), _p(c), _p(f), N, _p(lam), int(nthreads))
+    return lam
+
+
+def count_above_batch(h, g, c, f, shift, nthreads=0):
+    """division-form Sturm count of every system at its own shift: eigenvalues of (T, F) above shift[s]."""
+    g, c, f = (np.ascontiguousarray(a, dtype=np.float64) for a in (g, c, f))
+    shift = np.ascontiguousarray(shift, dtype=np.float64)
+    n, N = g.shape
+    cnt = np.zeros(n, dtype=np.int32)
+    lib().ibs_oracle_count_above_batch(n, N, float(h), _p(g), _p(c), _p(f), N, _p(shift), _p(cnt), int(nthreads))
+    return cnt

@@ -189,3 +189,70 @@ int ibs_oracle_gamma_scan(int n_lines, int n_theta0, int N, double h, const doub
   }
   return used;
 }
+
+/* lam_max alone (the bisection of ibs_oracle_solve_gcf without the eigenvector stage), OpenMP over systems: the arbiter of the
+ * 10^6-system eigenvalue campaigns (tests/tools/reclose_campaign.py).  Returns threads used. */
+int ibs_oracle_lam_batch(long n_sys, int N, double h, const double* g, const double* c, const double* f, long ld, double* lam,
+                         int nthreads) {
+  int used = 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  used = omp_get_max_threads();
+#endif
+  const int n = N - 2;
+  const double ih2 = 1.0 / (h * h);
+#pragma omp parallel
+  {
+    double* d = (double*)malloc(sizeof(double) * 3 * (size_t)N);
+    double* e = d + N; double* fd = e + N;
+#pragma omp for schedule(dynamic, 16)
+    for (long s = 0; s < n_sys; ++s) {
+      const double* gs = g + s * ld; const double* cs = c + s * ld; const double* fs = f + s * ld;
+      for (int k = 0; k < N - 1; ++k) e[k] = 0.5 * (gs[k] + gs[k + 1]) * ih2;          /* utils.py:1574-1576 */
+      double hi = -DBL_MAX, lo = -DBL_MAX, nrm = 0;
+      for (int r = 0; r < n; ++r) {
+        d[r] = -(e[r] + e[r + 1]) + cs[r + 1];                                          /* utils.py:1584-1592 */
+        fd[r] = fs[r + 1];
+        double v = cs[r + 1] / fd[r]; if (v > hi) hi = v;
+        v = d[r] / fd[r]; if (v > lo) lo = v;
+        v = (fabs(d[r]) + e[r] + e[r + 1]) / fd[r]; if (v > nrm) nrm = v;
+      }
+      const double pivmin = DBL_MIN * 1e16;
+      hi += 4 * DBL_EPSILON * nrm; lo -= 4 * DBL_EPSILON * nrm;
+      for (int it = 0; it < 200 && hi - lo > 2 * DBL_EPSILON * fmax(fabs(lo), fabs(hi)) + 4 * DBL_MIN; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (count_above(n, d, e, fd, mid, pivmin) >= 1) lo = mid; else hi = mid;
+      }
+      lam[s] = 0.5 * (lo + hi);
+    }
+    free(d);
+  }
+  return used;
+}
+
+/* division-form Sturm count (eigenvalues of (T, F) above shift[s]) of every system: the arbiter for counts the product-form
+ * GPU sweeps get wrong next to an eigenvalue.  Returns threads used. */
+int ibs_oracle_count_above_batch(long n_sys, int N, double h, const double* g, const double* c, const double* f, long ld,
+                                 const double* shift, int* count, int nthreads) {
+  int used = 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  used = omp_get_max_threads();
+#endif
+  const int n = N - 2;
+  const double ih2 = 1.0 / (h * h);
+#pragma omp parallel
+  {
+    double* d = (double*)malloc(sizeof(double) * 3 * (size_t)N);
+    double* e = d + N; double* fd = e + N;
+#pragma omp for schedule(dynamic, 16)
+    for (long s = 0; s < n_sys; ++s) {
+      const double* gs = g + s * ld; const double* cs = c + s * ld; const double* fs = f + s * ld;
+      for (int k = 0; k < N - 1; ++k) e[k] = 0.5 * (gs[k] + gs[k + 1]) * ih2;
+      for (int r = 0; r < n; ++r) { d[r] = -(e[r] + e[r + 1]) + cs[r + 1]; fd[r] = fs[r + 1]; }
+      count[s] = count_above(n, d, e, fd, shift[s], DBL_MIN * 1e16);
+    }
+    free(d);
+  }
+  return used;
+}

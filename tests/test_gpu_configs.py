@@ -27,12 +27,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import c5_family, norm_a, emulated_equilibria, ncsx_boundary_dofs  # noqa: E402,F401
 
 
+EPS64 = 2.220446049250313e-16
+
+
 @pytest.mark.parametrize("nz", [256, 512, 1024, 1536, 2048])      # (1536: the two-waves-per-SIMD direct form, round 5)
 @pytest.mark.parametrize("family", ["rough", "smooth"])
 def test_config5_fp64_one_million_systems(ctx, nz, family):
-    """10^6 systems per (N_zeta, family), FP64: nothing flagged; the Sturm count is 0 just above the returned eigenvalue and
-    >= 1 just below it (1 for all but near-degenerate pairs); lam is covariant under (g, c, f) -> (2g, 2c + 0.5 f, 2f);
-    a sample against the C oracle."""
+    """10^6 systems per (N_zeta, family), FP64, against a tolerance STATED a priori: |lam - lam_LAPACK-style| <= 4 N eps ||A||
+    (the matrix of utils.py:1584-1597; SURVEY 8d "max |lam_matrix - LAPACK|").  Nothing flagged; the Sturm count is 0 at
+    lam + 4 N eps ||A|| and >= 1 at lam - 4 N eps ||A|| on EVERY system; lam is covariant under (g, c, f) -> (2g, 2c + 0.5 f, 2f); a
+    sample against the C oracle's division-form bisection that includes every re-closed system's neighbourhood.
+
+    How the bound is kept (round 6): the prefix-product sweeps that move the solver's bracket are exact for a matrix perturbed by
+    up to ~N^2 eps ||A|| on iid-random coefficients -- a few systems per million used to close 2e-12 .. 1.5e-10 ||A|| off, and round 5
+    had fitted this test's tolerance to them.  Now every solve checks its closing bracket against the twisted factorisation's
+    Rayleigh polish, and a suspect one is closed again by division-form multisection (csrc/ibs_wave.hpp: reclose_division,
+    informational status bit 3).  tests/tools/reclose_campaign.py compares ALL 10 x 2^20 results with the oracle
+    (profiles/r06_reclose_campaign.txt)."""
     import torch
     from oracle import c_oracle as co
     dev = torch.device("cuda:0")
@@ -40,28 +51,31 @@ def test_config5_fp64_one_million_systems(ctx, nz, family):
     h, g, c, f = c5_family(dev, family, n, N, seed=20240 + nz)
     r = ctx.solve_gcf(h, g, c, f, want_info=True)
     lam = r["lam"]
-    assert int(((r["info"] >> 16) != 0).sum()) == 0
+    st = r["info"] >> 16
+    assert int(((st & 3) != 0).sum()) == 0
+    reclosed = torch.nonzero((st & 8) != 0).flatten().cpu().numpy()
+    assert len(reclosed) <= n // 2000, len(reclosed)      # (measured: 3 .. 90 per million on the rough family, <= 50 on the smooth one)
     nA = norm_a(h, g, c, f)
-    # the certified bracket is 256 ulp(||A||) = 5.7e-14 ||A|| wide; the counts themselves are certificates for a matrix
-    # perturbed by ~n eps (scan-form recurrence), so the probe distance grows with the number of rows
-    eps = max(2e-13, 4 * N * 1.1e-16) * nA
-    above = ctx.sturm_count(h, g, c, f, lam + eps)
-    below = ctx.sturm_count(h, g, c, f, lam - eps)
+    tol = 4 * N * EPS64                                     # the stated tolerance, in units of ||A||
+    above = ctx.sturm_count(h, g, c, f, lam + tol * nA)
+    below = ctx.sturm_count(h, g, c, f, lam - tol * nA)
+    # ibs_sturm_count_f64 is itself a product-form sweep: next to an eigenvalue of a rough system ITS count can be off.  Whatever
+    # it objects to is arbitrated by division-form counts (the C oracle's): none of the objections may stand.
     odd = torch.nonzero((above != 0) | (below < 1)).flatten().cpu().numpy()
-    assert len(odd) <= n // 5000, len(odd)    # floating-point counts of rough systems are not perfectly monotone in the shift
-    pick = np.unique(np.concatenate([odd[:64], np.random.default_rng(nz).choice(n, size=96, replace=False)]))
+    assert len(odd) <= n // 5000, len(odd)
+    if len(odd):
+        ok_ = torch.from_numpy(odd).to(dev)
+        go, co_, fo = g[ok_].cpu().numpy(), c[ok_].cpu().numpy(), f[ok_].cpu().numpy()
+        lo_, no_ = lam[ok_].cpu().numpy(), nA[ok_].cpu().numpy()
+        assert (co.count_above_batch(h, go, co_, fo, lo_ + tol * no_) == 0).all()
+        assert (co.count_above_batch(h, go, co_, fo, lo_ - tol * no_) >= 1).all()
+    pick = np.unique(np.concatenate([odd[:64], reclosed[:96], np.random.default_rng(nz).choice(n, size=96, replace=False)]))
     pk = torch.from_numpy(pick).to(dev)
     gam_c, lam_c, _ = co.solve_gcf_batch(h, g[pk].cpu().numpy(), c[pk].cpu().numpy(), f[pk].cpu().numpy())
-    # (the counts of the scan-form recurrence certify eigenvalues of a matrix perturbed by ~n eps; the systems with
-    #  non-monotone counts sit at the upper end of that)
-    # measured on the worst (non-monotone) systems of the rough family: 1e-11 ||A|| up to N_zeta = 1024, 1.1e-10 ||A|| at 2048
-    # (iid-random coefficients: ||A|| ~ 3e6 with lam ~ 2e-3, i.e. the problem itself is conditioned like 1e9)
-    # round 5: the same band holds for both one-wave-per-system forms (LDS-staged rows / rows straight from global memory:
-    # tests/tools/direct_vs_staged_accuracy.py, 2^18 rough systems at N_zeta = 1024: worst 5.1e-11 / 7.2e-11 ||A|| on the systems
-    # where the two differ most, 3e-14 / 7e-15 on a random sample); which system of 10^6 is the worst depends on the kernel, the
-    # first 64 non-monotone ones reached 1.5e-10 ||A|| with the direct form -> 2e-13 N
-    tol = max(1e-11, 2e-13 * N)
-    assert (np.abs(lam[pk].cpu().numpy() - lam_c) / nA[pk].cpu().numpy()).max() < tol
+    err = np.abs(lam[pk].cpu().numpy() - lam_c) / nA[pk].cpu().numpy()
+    assert err.max() < tol, (err.max(), tol)
+    print("N_zeta %d %s: %d of %d re-closed in division form, %d probes of the product-form count overruled; max |lam - oracle| of %d "
+          "sampled systems %.1e ||A|| (stated: 4 N eps = %.1e)" % (nz, family, len(reclosed), n, len(odd), len(pick), err.max(), tol))
     if family == "smooth":                  # well separated top eigenvalue: the growth rate is pinned too
         assert np.abs(r["gam"][pk].cpu().numpy() - gam_c).max() < 1e-8
         assert float((below == 1).double().mean()) > 0.9999
@@ -70,10 +84,9 @@ def test_config5_fp64_one_million_systems(ctx, nz, family):
     m = 8192
     r2 = ctx.solve_gcf(h, 2 * g[:m], 2 * c[:m] + 0.25 * 2 * f[:m], 2 * f[:m])
     # shift / scale property.  The two solves walk mapped shifts only while every proposal is an exact image of the other run's;
-    # the trial-vector bracket of the raw kernels (at N_zeta = 2048 its width is an estimate from a sample of rows) ends that, so
-    # on the ROUGH family they agree to what the counts themselves resolve there -- the tolerance of the oracle comparison
-    # above -- not to rounding (measured: 2.3e-12 ||A|| at N_zeta = 2048).
-    assert float(((r2["lam"] - (lam[:m] + 0.25)).abs() / nA[:m]).max()) < (3e-13 if family == "smooth" else max(3e-13, tol))
+    # the trial-vector bracket of the raw kernels ends that, so they agree to what each certifies -- the stated tolerance -- not to
+    # rounding (the smooth family: inside the certified brackets, 3e-13)
+    assert float(((r2["lam"] - (lam[:m] + 0.25)).abs() / nA[:m]).max()) < (3e-13 if family == "smooth" else max(3e-13, 2 * tol))
 
 
 # FP32 entry point of config 5 (ibs_solve_gcf_f32).
@@ -115,14 +128,14 @@ def test_config5_fp32_stated_tolerances(ctx, nz):
             assert float(el.max()) <= (nz + 4) * EPS32, (family, mode, float(el.median()), float(el.max()) / EPS32)
             if mode == 1:
                 resolved[family] = int(((st & 4) != 0).sum())
-            elif mode == 2:
-                assert int((st != 0).sum()) == 0
+            elif mode == 2:   # (FP64 solver on the FP32 arrays: nothing but the informational bit 3 of a re-closed solve)
+                assert int(((st & ~8) != 0).sum()) == 0
             else:   # the library's choice may be the all-FP32 form: its informational bit (re-solved in FP64) and nothing else
-                assert int(((st & ~4) != 0).sum()) == 0
+                assert int(((st & ~(4 | 8)) != 0).sum()) == 0
         ctx.set_option("f32_lam", None)
         # (b) growth rate wanted: widened to FP64 inside the solver
         rw = ctx.solve_gcf(h, g32, c32, f32, want_info=True, dtype=np.float32)
-        assert rw["gam"].dtype == torch.float32 and int(((rw["info"] >> 16) != 0).sum()) == 0
+        assert rw["gam"].dtype == torch.float32 and int((((rw["info"] >> 16) & 3) != 0).sum()) == 0
         ew = (rw["lam"].double() - r64["lam"]).abs() / nA
         assert float(ew.max()) < 2 * EPS32, float(ew.max())
         if family == "smooth":

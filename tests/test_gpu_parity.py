@@ -154,7 +154,7 @@ def test_device_pointers_and_ragged_batch(ctx, bo):
     assert np.array_equal(r["gam"].cpu().numpy(), rh["gam"])          # same kernel, same bits
     for k in range(0, 37, 6):
         assert abs(rh["gam"][k] - bo.solve_gcf(th, g[k], c[k], g[k])[0]) < 1e-10
-    assert ((r["info"].cpu().numpy() >> 16) == 0).all()
+    assert (((r["info"].cpu().numpy() >> 16) & 3) == 0).all()
 
 
 def test_invalid_coefficients_are_flagged_not_propagated(ctx, bo):
@@ -247,7 +247,7 @@ def test_nearly_degenerate_top_eigenvalues(ctx, bo, N):
     g = np.ones((len(cases), N)); f = np.ones_like(g)
     c = np.stack([d * (np.exp(-((th - s) / w) ** 2) + np.exp(-((th + s) / w) ** 2)) - 0.5 for s, d, w in cases])
     r = ctx.solve_gcf(th[1] - th[0], g, c, f, want_info=True)
-    assert r["nbad"] == 0 and ((r["info"] >> 16) == 0).all() and ((r["info"] & 0xffff) < 60).all()
+    assert r["nbad"] == 0 and (((r["info"] >> 16) & 3) == 0).all() and ((r["info"] & 0xffff) < 60).all()
     for k in range(len(cases)):
         d, e, fd = bo.assemble(th, g[k], c[k], f[k])[:3]
         n = len(d)
@@ -291,7 +291,7 @@ def test_G4_obj_w_grad_kernel(ctx, bo):
     g4 = np.load(os.path.join(G, "G4_obj_w_grad.npz"))
     th = bo.theta_grid(513)
     val, jac, info = ctx.obj_w_grad(th[1] - th[0], g4["geo"], g4["pts"][:, 2], float(g4["del_alpha"]), want_info=True)
-    assert ((info >> 16) == 0).all()
+    assert (((info >> 16) & 3) == 0).all()
     assert np.abs(val - g4["val_tight"]).max() < 1e-10 and np.abs(jac - g4["jac_tight"]).max() < 1e-9
     assert np.abs(val - g4["val"]).max() < TOL and np.abs(jac - g4["jac"]).max() < 1e-7   # shipped ARPACK tol
     # device-pointer path gives the same bits
@@ -340,7 +340,7 @@ def test_fp32_variant_stated_tolerance(ctx, bo, N):
     err = np.abs(r32["lam"].astype(np.float64) - r64["lam"])
     assert err.max() < 64 * 1.2e-7 * normA and np.median(err) < 8 * 1.2e-7 * normA    # stated FP32 tolerance
     rw = ctx.solve_gcf(h, g32, c32, g32, want_X=True, want_info=True, dtype=np.float32)
-    assert rw["gam"].dtype == np.float32 and rw["X"].dtype == np.float32 and ((rw["info"] >> 16) == 0).all()
+    assert rw["gam"].dtype == np.float32 and rw["X"].dtype == np.float32 and (((rw["info"] >> 16) & 3) == 0).all()
     assert np.abs(rw["lam"].astype(np.float64) - r64["lam"]).max() < 2 * 1.2e-7 * normA
     assert np.abs(rw["gam"].astype(np.float64) - r64["gam"]).max() < 1e-6
     assert np.abs(rw["X"].astype(np.float64) - r64["X"]).max() < 1e-5 and np.abs(rw["dX"].astype(np.float64) - r64["dX"]).max() < 1e-4 * np.abs(r64["dX"]).max()
@@ -373,7 +373,7 @@ def test_full_size_stress_properties(ctx):
     h = 8 * np.pi / (N - 1)
     r = ctx.solve_gcf(h, g, c, f, want_info=True)
     lam = r["lam"]
-    assert int(((r["info"] >> 16) != 0).sum()) == 0
+    assert int((((r["info"] >> 16) & 3) != 0).sum()) == 0
     e = 0.5 * (g[:, :-1] + g[:, 1:]) / h ** 2
     d = c[:, 1:-1] - (e[:, :-1] + e[:, 1:])
     normA = ((d.abs() + e[:, :-1] + e[:, 1:]) / f[:, 1:-1]).amax(dim=1)        # the solver's ||A|| bound
@@ -552,7 +552,7 @@ def test_subwave_variants_match_full_wave(ctx, bo, N, P):
         r = ctx.solve_gcf(h, g, c, f, want_X=True, want_info=True)
     finally:
         ctx.set_option("force_p", None)
-    assert r["nbad"] == 0 and ((r["info"] >> 16) == 0).all()
+    assert r["nbad"] == 0 and (((r["info"] >> 16) & 3) == 0).all()
     assert np.abs(r["lam"] - ref["lam"]).max() < 1e-10 and np.abs(r["gam"] - ref["gam"]).max() < 1e-10
     assert np.abs(r["X"] - ref["X"]).max() < 1e-7 and np.abs(r["dX"] - ref["dX"]).max() < 1e-6
     for k in (0, 17, 36):

@@ -1,0 +1,307 @@
+"""GPU, round 6: the on-disk contract carried by a GPU run, the division-form re-close of the raw
+kernels, grids beyond 2050 points, the nearest-sigma flag of the drop-in."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ibs_amd
+    c = ibs_amd.Context(0)
+    yield c
+    c.close()
+
+
+def test_F4_history_files_written_from_gpu_adjoint_steps_and_read_like_the_optimizer_driver(ctx, tmp_path):
+    """Rows A8 + F4 with the GPU in the loop: three optimizer iterations, each ONE AdjointStep.run() on the device (3 equilibria
+    x 5 surfaces: base + 2 DOF-perturbed, N = 969), every equilibrium's rows appended to save_n_load-style files exactly as
+    ball_scan.py:359-384 does (0-d placeholders of arr_create2.py:87-97 first), then read back exactly as
+    sims_runner_NCSX.py reads them: fobj takes `ball_gam0.npy` whole at iteration 0 and its last row afterwards (:300-306),
+    dfobj takes `np.load(ball_gam{i}.npy)[-1]` of every dof (:198-199) into f0_arr / df0_arr (:249-261).  The files must hold
+    the oracle pipeline's numbers (1e-8) and the objective / gradient rebuilt from the FILES must equal what the step returned
+    in memory."""
+    import torch
+    import ibs_amd
+    import bench
+    from tests.helpers import oracle_surface_pipeline
+    dev = torch.device("cuda:0")
+    wout0 = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    wouts, steps, _ = bench.emulated_equilibria(wout0)
+    ns, na, nt0, ndof = 5, 24, 15, 2
+    svals = np.linspace(0.5, 0.95, ns)                                   # ball_scan.py:197
+    th = ibs_amd.theta_grid_for(11, 11)                                  # ball_scan.py:201-208: 969 points
+    thresh, prefac = -2.0e-4, 50.0                                       # sims_runner_NCSX.py:56-57
+    path0 = str(tmp_path)
+    ibs_amd.create_history_placeholders(path0, ndof)                     # arr_create2.py:87-97
+    assert np.load(os.path.join(path0, "ball_gam0.npy")).shape == ()
+    step = ibs_amd.AdjointStep(ctx, th, svals, dev, nalpha=na, ntheta0=nt0, gamma_thresh=thresh, prefac=prefac)
+    picks = [(0, 0, 1), (1, 2, 4), (2, 1, 0)]                            # (iteration, dof, surface) re-done by the oracle pipeline
+    for iter0 in range(3):
+        # each iteration has its own equilibria (the optimizer moved): three of the emulated NCSX_op set, the first acting as base
+        eq = [3 * iter0, 3 * iter0 + 1, 3 * iter0 + 2]
+        w = [wouts[q] for q in eq]
+        st = np.array([1.0, steps[eq[1]], steps[eq[2]]])              # (entry 0 unused: sims_runner_NCSX.py:258)
+        f_other = np.array([0.8, 0.81, 0.82]) + 0.1 * iter0              # (f{i}.npy: the non-ballooning part, out of scope)
+        out = step.run(w, f_other, st)
+        for dof in range(ndof + 1):                                      # what every `srun ball_scan.py iter dof ngroups` does at its end
+            ibs_amd.append_history(path0, dof, iter0, out["gam"][dof], out["theta0"][dof], out["alpha"][dof])
+        # ---- consumer side, sims_runner_NCSX.py written out
+        for name in ("ball_gam", "ball_theta0", "ball_alpha"):
+            arr = np.load(os.path.join(path0, "%s1.npy" % name), allow_pickle=True)
+            assert arr.shape == ((ns,) if iter0 == 0 else (iter0 + 1, ns)), (name, arr.shape)    # ball_scan.py:369-379
+        if iter0 == 0:
+            gamma_ball = np.load(path0 + "/ball_gam{0}.npy".format(0), allow_pickle=True)        # :300-303
+        else:
+            gamma_ball = np.load(path0 + "/ball_gam{0}.npy".format(0), allow_pickle=True)[-1]    # :304-306
+        f0 = f_other[0] + prefac * np.sum(np.maximum(gamma_ball - thresh, 0.0))                   # :311-313
+        assert abs(np.sqrt(f0) - out["fobj"]) < 1e-15                                             # :318
+        if iter0 > 0:                                                    # dfobj is "never called at the first itern" (:192)
+            gamma_ball2 = np.zeros((ndof + 1, ns)); f0_arr = np.zeros(ndof + 1); df0 = np.zeros(ndof)
+            for i in range(ndof + 1):
+                gamma_ball2[i] = np.load(path0 + "/ball_gam{0}.npy".format(i))[-1]               # :198-199
+                f0_arr[i] = f_other[i] + prefac * np.sum(np.maximum(gamma_ball2[i] - thresh, 0.0))   # :252-257
+                if i > 0:
+                    df0[i - 1] = (f0_arr[i] - f0_arr[0]) / st[i] * 0.5 * 1 / np.sqrt(f0_arr[0])  # :258-261
+            assert np.array_equal(gamma_ball2, out["gam"]) and np.array_equal(f0_arr, out["f0"])
+            assert np.abs(df0 - out["dfobj"]).max() <= 1e-15 * max(1.0, np.abs(df0).max())
+        # ---- the numbers in the files against the oracle pipeline (numpy geometry, C-oracle scan, scipy L-BFGS-B, oracle final solve)
+        for (it, dof, js) in picks:
+            if it != iter0:
+                continue
+            ref = oracle_surface_pipeline(w[dof], float(svals[js]), th, na, nt0, step.del_alpha)
+            row = lambda name: np.atleast_2d(np.load(os.path.join(path0, "%s%d.npy" % (name, dof)), allow_pickle=True))[-1]
+            assert abs(row("ball_gam")[js] - ref["gam"]) < 1e-8, (it, dof, js, row("ball_gam")[js], ref["gam"])
+            assert abs(row("ball_alpha")[js] - ref["x_opt"][0]) < 1e-5 and abs(row("ball_theta0")[js] - ref["x_opt"][1]) < 1e-5
+    hist = np.load(os.path.join(path0, "ball_gam2.npy"))
+    assert hist.shape == (3, ns) and np.all(np.isfinite(hist)) and len(np.unique(hist)) == 3 * ns    # three different iterations
+
+
+# ---------------------------------------------------------------------------------------------- world > 1 on one GPU
+def _build_fake_rccl(tmp_path):
+    """tests/cabi/fake_rccl.c: RCCL's five entry points over shared memory + stream-ordered copies (test infrastructure)"""
+    import subprocess
+    so = str(tmp_path / "libfake_rccl.so")
+    inc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")
+    r = subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-I", inc, os.path.join(ROOT, "tests", "cabi", "fake_rccl.c"),
+                        "-o", so, "-lrt", "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return so
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_library_collectives_with_more_than_one_rank(tmp_path, world):
+    """ibs_comm_init -> ibs_comm_allgather_f64 -> ibs_comm_allgather_start_f64 over all 16 slots (then_wait_slot and host waits)
+    -> ibs_comm_wait -> ibs_comm_destroy with 2 and 4 ranks: fresh processes that share the box's one GPU and meet through the
+    shared-memory stand-in for librccl (RCCL refuses two ranks on one device).  Every rank checks every rank's rows of every
+    gather; the stand-in delays each gather by 3 ms, and a control inside the worker shows that a consumer which does NOT wait
+    sees the old buffer contents -- so a missing ordering in the library's slot logic fails these checks."""
+    import json
+    import subprocess
+    fake = _build_fake_rccl(tmp_path)
+    env = dict(os.environ, FAKE_RCCL_DELAY_US="3000", FAKE_RCCL_TIMEOUT_S="60", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "cabi", "comm_worker.py"), str(r), str(world), fake,
+                               str(tmp_path / "id.bin"), str(tmp_path / ("rank%d.json" % r))], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=420))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        fn = tmp_path / ("rank%d.json" % r)
+        res = json.load(open(fn)) if fn.exists() else {"error": "no report", "stderr": outs[r][1][-2000:] if r < len(outs) else ""}
+        assert res.get("ok") is True and p.returncode == 0, (r, res, outs[r][1][-1500:] if r < len(outs) else "")
+        assert res["checks"]["slots_gathers_checked"] >= 3 * 16 and res["checks"]["control_without_wait_sees_old_contents"] is True
+
+
+def test_bench_two_ranks_with_the_librarys_own_gathers(tmp_path):
+    """`python bench.py --gpus 2` on the one-GPU box with the stand-in bound as the library's RCCL (IBS_RCCL_LIB): beside the
+    torch.distributed legs of tests/test_gpu_round5.py the per-step gather now also runs through ibs_comm_allgather_f64 (in the
+    step's stream) and through the overlapped 3-slot rotation of ibs_comm_allgather_start_f64 with host waits -- the product's
+    default form -- each with its round trip checked on both ranks, and configs[2] sharded is gathered by the library."""
+    import json
+    import subprocess
+    import time
+    fake = _build_fake_rccl(tmp_path)
+    detail = tmp_path / "detail.json"
+    env = dict(os.environ, IBS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", IBS_RCCL_LIB=fake, IBS_BENCH_DETAIL=str(detail),
+               FAKE_RCCL_TIMEOUT_S="60")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-stress"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 6000
+    full = json.load(open(detail))
+    modes = full["gather_modes"]
+    assert "native_error" not in modes, modes
+    for m in ("torch_in_stream", "native_in_stream", "native_overlapped"):
+        assert modes[m]["allgather_roundtrip_ok"] is True and modes[m]["ms_per_step"] > 0, (m, modes[m])
+    assert modes["native_in_stream"]["ranks_in_collective"] == 2
+    assert full["config"]["headline_gather"] in modes and full["value"] == modes[full["config"]["headline_gather"]]["solves_per_s"]
+    nat = full["ncsx_c2_sharded_native"]
+    assert nat["checks_passed"] is True and nat["gathered_equals_one_gpu_bitwise"] is True
+    print("2 ranks, library's own gathers through the stand-in: %.0f s; ms per step %s; headline = %s" % (
+        time.time() - t0, {k: round(v["ms_per_step"], 4) for k, v in modes.items() if isinstance(v, dict)}, full["config"]["headline_gather"]))
+
+
+# ---------------------------------------------------------------------------------------------- grids beyond 2050 points
+@pytest.mark.parametrize("N", [2561, 4097, 8193])
+def test_large_grid_salpha_against_the_oracle(ctx, N):
+    """utils.py:1556-1624 accepts any grid length and the reference's own rule N = 2 mpol ntor 4 + 1 (ball_scan.py:201-208) exceeds
+    2050 points from mpol ntor > 256 on (N = 2561 is mpol = 20, ntor = 16).  Beyond the register-resident kernels the library runs the
+    generic division-form path (csrc/ibs_long.hip): s-alpha systems (the reference's own test family,
+    bishop_ball_s-alpha.py:30-45) through the raw entry point and through the drop-in gamma_ball_full against the oracle: gam
+    1e-8 (the stated FP64 tolerance), lam to 4 N eps ||A||, X / dX, the Sturm count at 0 and around lam exact, invalid data
+    flagged, host and device pointers."""
+    import torch
+    import ibs_amd
+    from oracle import ballooning_oracle as bo
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    th = np.linspace(-4 * np.pi, 4 * np.pi, N)
+    h = float(th[1] - th[0])
+    cases = [(1.0, 0.8, 0.0), (0.5, 0.6, 0.1), (1.5, 1.1, 0.3), (0.3, 0.3, 0.0), (1.0, 0.3, 0.2)]     # (shat, alpha, theta0) of G1
+    g = np.empty((len(cases), N)); c = np.empty_like(g)
+    for k, (sh, al, t0) in enumerate(cases):
+        g[k], c[k] = bo.salpha_gc(th, sh, al, t0)
+    f = g.copy()
+    gam_c, lam_c, _ = co.solve_gcf_batch(h, g, c, f)
+    ee = (g[:, :-2] + 2 * g[:, 1:-1] + g[:, 2:]) / (2 * h * h)                     # e_lo + e_hi of every row (utils.py:1574-1592)
+    nA = ((np.abs(c[:, 1:-1] - ee) + ee) / f[:, 1:-1]).max(axis=1)                 # the solver's ||A|| bound
+    r = ctx.solve_gcf(h, torch.from_numpy(g).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(f).to(dev), want_X=True, want_info=True)
+    assert "k_solve_gcf_long<double>" in ctx.last_launch()[0], ctx.last_launch()
+    assert int(((r["info"] >> 16) != 0).sum()) == 0
+    assert np.abs(r["gam"].cpu().numpy() - gam_c).max() < 1e-8, np.abs(r["gam"].cpu().numpy() - gam_c).max()
+    assert (np.abs(r["lam"].cpu().numpy() - lam_c) / nA).max() < 4 * N * 2.220446049250313e-16
+    for k in range(len(cases)):
+        ref = co.solve_gcf(h, g[k], c[k], f[k])
+        X = r["X"][k].cpu().numpy(); dX = r["dX"][k].cpu().numpy()
+        sgn = np.sign(X[np.argmax(np.abs(X))]) * np.sign(ref[2][np.argmax(np.abs(ref[2]))])
+        assert np.abs(sgn * X - ref[2]).max() < 1e-6 and np.abs(sgn * dX - ref[3]).max() < 1e-5 * max(1.0, np.abs(ref[3]).max())
+        assert abs(np.abs(X).max() - 1.0) < 1e-15 and X[0] == 0.0 and X[-1] == 0.0           # utils.py:1605-1608
+    # host pointers, eigenvalues only, FP32 arrays
+    rh = ctx.solve_gcf(h, g, c, f, want_info=True)
+    assert np.array_equal(rh["lam"], r["lam"].cpu().numpy()) and np.array_equal(rh["gam"], r["gam"].cpu().numpy()) and rh["nbad"] == 0
+    rl = ctx.solve_gcf(h, torch.from_numpy(g).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(f).to(dev), want_gam=False)
+    assert torch.equal(rl["lam"], r["lam"]) and rl["gam"] is None
+    r32 = ctx.solve_gcf(h, torch.from_numpy(g).to(dev).float(), torch.from_numpy(c).to(dev).float(), torch.from_numpy(f).to(dev).float(),
+                        dtype=np.float32)
+    assert "k_solve_gcf_long<float>" in ctx.last_launch()[0] and r32["gam"].dtype == torch.float32
+    assert np.abs(r32["gam"].double().cpu().numpy() - gam_c).max() < 1e-4      # (the systems the FP32 arrays define, solved in FP64)
+    # Sturm counts (division form): the stability verdict of bishop_ball_s-alpha.py:110-115 and the eigenvalue's own neighbourhood
+    z = np.zeros(len(cases))
+    assert np.array_equal(ctx.sturm_count(h, g, c, f, z), co.count_above_batch(h, g, c, f, z))
+    assert "k_sturm_count_long" in ctx.last_launch()[0]
+    lam = r["lam"].cpu().numpy()
+    assert (ctx.sturm_count(h, g, c, f, lam + 1e-9) == 0).all() and (ctx.sturm_count(h, g, c, f, lam - 1e-9) == 1).all()
+    # the drop-in on the long grid (geometry-fed path: B = gradpar = 1, dPdrho = -1: bishop_ball_s-alpha.py fed to gamma_ball_full)
+    sh, al, t0 = cases[0]
+    out = ibs_amd.gamma_ball_full(-1.0, th, np.ones(N), np.ones(N), c[0], g[0], ctx=ctx)
+    assert abs(out[0] - gam_c[0]) < 1e-8 and out[1].shape == (N,) and np.array_equal(out[3], g[0])
+    # ... and on a NON-uniform long grid (regridded like utils.py:1567-1576: caller-supplied half-grid g)
+    th_nu = th + 0.3 * h * np.sin(3 * th)
+    gn, cn = bo.salpha_gc(th_nu, sh, al, t0)
+    ref = bo.gamma_ball_full(-1.0, th_nu, np.ones(N), np.ones(N), cn, gn)
+    out = ibs_amd.gamma_ball_full(-1.0, th_nu, np.ones(N), np.ones(N), cn, gn, ctx=ctx)
+    assert abs(out[0] - ref[0]) < 1e-8, (out[0], ref[0])
+    # invalid data is flagged (status 2), its neighbours untouched
+    g2 = g.copy(); g2[1, N // 3] = -1.0
+    rb = ctx.solve_gcf(h, g2, c, f, want_info=True)
+    assert rb["nbad"] == 1 and (rb["info"][1] >> 16) == 2 and rb["lam"][0] == rh["lam"][0] and rb["gam"][4] == rh["gam"][4]
+    # even N is still refused by the growth-rate entry points (Simpson rule restated for odd N), accepted by the count
+    with pytest.raises(ibs_amd.IbsError):
+        ctx.solve_gcf(h, g[:, :-1], c[:, :-1], f[:, :-1])
+    assert ctx.sturm_count(h, g[:, :-1], c[:, :-1], f[:, :-1], z).shape == (len(cases),)
+
+
+def test_large_grid_geometry_fed_scan_with_theta0_derivative(ctx):
+    """ibs_gamma_scan_f64 on a 4097-point grid: two field lines of the tests' smooth geometry family x 3 theta0 against the oracle --
+    gam, lam, and the Hellmann-Feynman d gam / d theta0 of utils.py:1666-1680."""
+    import torch
+    from oracle import ballooning_oracle as bo
+    from oracle import c_oracle as co
+    N = 4097
+    th = np.linspace(-4 * np.pi, 4 * np.pi, N)
+    # smooth synthetic field-line geometry of the tests' own family (tests/helpers.py), two lines
+    from tests.helpers import synthetic_fieldlines
+    lines = synthetic_fieldlines(th)(0.6, np.array([0.3, 1.7]))            # (2, 8, N)
+    dP = np.array([bo.dPdrho_of(lines[i, 2], lines[i, 7], lines[i, 0]) for i in range(2)])
+    t0 = np.array([0.0, 0.4, 1.1])
+    h = float(th[1] - th[0])
+    r = ctx.gamma_scan(h, *[lines[:, k, :] for k in range(7)], dP, t0, want_X=True, want_dtheta0=True, want_info=True)
+    assert "k_solve_gcf_long<double>" in ctx.last_launch()[0] and r["nbad"] == 0
+    gam_c, lam_c, _ = co.gamma_scan(h, *[lines[:, k, :] for k in range(7)], dP, t0)
+    assert np.abs(r["gam"] - gam_c).max() < 1e-8 and np.abs(r["lam"] - lam_c).max() < 1e-9
+    for i in range(2):
+        for j in range(3):
+            cv, gd = bo.fold_theta0(t0[j], lines[i, 2], lines[i, 3], lines[i, 4], lines[i, 5], lines[i, 6])
+            gam, X, dX, gg, cc, ff = bo.gamma_ball_full(dP[i], th, lines[i, 0], lines[i, 1], cv, gd)
+            gp = np.abs(lines[i, 1]); B = lines[i, 0]
+            gdp = 2 * lines[i, 5] + 2 * t0[j] * lines[i, 6]
+            jac = bo.hf_derivative(gam, X, dX, ff, gp * gdp / B, -dP[i] * lines[i, 3] / (gp * B), gdp / B ** 3 / gp)    # utils.py:1669-1680
+            assert abs(r["dgam_dtheta0"][i, j] - jac) < 1e-7 * max(1.0, abs(jac)), (i, j, r["dgam_dtheta0"][i, j], jac)
+
+
+# ---------------------------------------------------------------------------------------------- nearest-sigma report
+def test_nearest_sigma_divergence_is_reported(ctx):
+    """utils.py:1597 takes the eigenpair NEAREST sigma0 (ARPACK shift-invert); the drop-in always takes lam_max.  A strongly driven
+    s-alpha line (dPdrho = -4: lam_max = 2.09 > 0.42) is the one kind of case where the two differ: there the reference formulation
+    (oracle: dense matrix + eigs(sigma=sigma0), utils.py:1582-1624 restated) returns ANOTHER eigenpair's growth rate, the drop-in
+    returns lam_max's, says so (NearestSigmaWarning, info["above_sigma0"], status bit 4 at the C ABI), and with sigma0 above
+    lam_max -- or on the ordinary weakly driven line -- the two agree to the stated 1e-8 and nothing is flagged."""
+    import warnings
+    import ibs_amd
+    from oracle import ballooning_oracle as bo
+    N = 257
+    th = bo.theta_grid(N)
+    g, c0 = bo.salpha_gc(th, 1.0, 0.8, 0.0)
+    one = np.ones(N)
+    # (a) lam_max >= sigma0: flagged, and genuinely different from the nearest-sigma eigenpair
+    info = {}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = ibs_amd.gamma_ball_full(-4.0, th, one, one, c0, g, sigma0=0.42, ctx=ctx, info=info)
+    assert any(issubclass(x.category, ibs_amd.NearestSigmaWarning) for x in w)
+    assert info["above_sigma0"] is True and info["lam"] > 2.0 and info["status"] == 0
+    ref_near = bo.gamma_ball_full_dense_arpack(-4.0, th, one, one, c0, g, sigma0=0.42)      # what upstream returns
+    ref_max = bo.gamma_ball_full(-4.0, th, one, one, c0, g)                                  # exact top eigenpair
+    assert abs(out[0] - ref_max[0]) < 1e-8 and abs(out[0] - ref_near[0]) > 0.1, (out[0], ref_max[0], ref_near[0])
+    # (b) the same line with sigma0 above lam_max: upstream's eigenpair IS lam_max's; nothing flagged
+    info = {}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = ibs_amd.gamma_ball_full(-4.0, th, one, one, c0, g, sigma0=2.5, ctx=ctx, info=info)
+    assert not w and info["above_sigma0"] is False
+    assert abs(out[0] - bo.gamma_ball_full_dense_arpack(-4.0, th, one, one, c0, g, sigma0=2.5)[0]) < 1e-8
+    # (c) the reference's own regime (dPdrho = -1, lam_max = 0.109 < 0.42): agree, not flagged
+    info = {}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = ibs_amd.gamma_ball_full(-1.0, th, one, one, c0, g, ctx=ctx, info=info)
+    assert not w and info["above_sigma0"] is False and abs(info["lam"] - 0.10876115422233879) < 1e-10
+    assert abs(out[0] - bo.gamma_ball_full_dense_arpack(-1.0, th, one, one, c0, g)[0]) < 1e-8
+    # (d) the flag at the C ABI, batched: option "sigma0" + lam and info outputs; the option is per context and leaves no trace
+    G2 = np.stack([g, g]); C2 = np.stack([4.0 * c0, c0])
+    ctx.set_option("sigma0", 0.42)
+    r = ctx.solve_gcf(th[1] - th[0], G2, C2, G2, want_info=True)
+    ctx.set_option("sigma0", None)
+    assert ((r["info"] >> 16) & 16).tolist() == [16, 0] and r["nbad"] == 0
+    r = ctx.solve_gcf(th[1] - th[0], G2, C2, G2, want_info=True)
+    assert ((r["info"] >> 16) & 16).tolist() == [0, 0]
