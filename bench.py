@@ -221,6 +221,11 @@ def compact_c5(m):
     return dict(systems_per_row=next((r.get("systems") for r in m.get("rows", []) if "systems" in r), None), cols=C5_COLS,
                 rows=rows, kernels=kernels, f32_gam_over_f64_min=min([v for v in (m.get("f32_gam_over_f64") or {}).values() if v] or [None]),
                 f32_results_outside_tolerance=m.get("f32_results_outside_tolerance"),
+                # FP64 rows: worst |lam - oracle| / ||A|| of the sampled systems in units of N eps (stated tolerance: 4), systems re-closed
+                f64_max_dlam_over_N_eps_normA=max([r["max_abs_dlam_over_normA"] / ((r["n_zeta"] + 1) * 2.220446049250313e-16)
+                                                   for r in m.get("rows", []) if "max_abs_dlam_over_normA" in r] or [None]),
+                f64_rows_outside_4N_eps=m.get("f64_rows_outside_4N_eps"),
+                f64_reclosed=sum(r.get("reclosed_in_division_form", 0) for r in m.get("rows", [])),
                 flagged=sum(r.get("flagged", 0) for r in m.get("rows", [])), seconds=m.get("seconds"))
 
 
@@ -414,9 +419,18 @@ def cpu_baseline(h, base, dP, theta0, budget_s=12.0):
         gam, lam, used = co.gamma_scan(h, *arrs, dP, theta0, nthreads=cores)
         n += gam.size
     dt = time.time() - t0
-    return dict(value=n / dt, unit="solves/s", cores=int(used), kind="port",
-                sample="%d passes of the same 1,024-solve D3D-shape batch (%.1f s), Sturm bisection + inverse "
-                       "iteration in C/OpenMP" % (n // gam.size, dt)), gam
+    # "1 core and all cores" -- the same code on ONE thread (OMP_NUM_THREADS=1 is how the reference itself runs,
+    # slurm_ball_scan_template.sl:10), a quarter of the batch per pass for about 4 s
+    q = max(1, len(dP) // 4)
+    n1 = 0
+    t1 = time.time()
+    while time.time() - t1 < 4.0:
+        g1, _, _ = co.gamma_scan(h, *[a[:q] for a in arrs], dP[:q], theta0, nthreads=1)
+        n1 += g1.size
+    dt1 = time.time() - t1
+    return dict(value=n / dt, unit="solves/s", cores=int(used), kind="port", value_1core=n1 / dt1,
+                sample="%d passes of the same 1,024-solve D3D-shape batch (%.1f s) on %d threads, then %d solves on ONE thread "
+                       "(%.1f s): Sturm bisection + inverse iteration in C/OpenMP" % (n // gam.size, dt, int(used), n1, dt1)), gam
 
 
 def cpu_reference_cost(h, base, dP, theta0, nsolve=24):
@@ -742,13 +756,15 @@ def c4_adjoint_step(ctx, device, n_oracle=4, reps=3):
     return leg
 
 
-def c5_matrix(ctx, device, n_sys=1 << 20, budget_s=75.0):
+def c5_matrix(ctx, device, n_sys=1 << 20, budget_s=75.0, oracle_check=True):
     """BASELINE configs[4] as stated: 10^6 (2^20) random (g, c, f) systems at N_zeta in {256, 512, 1024, 2048}, smooth and
     rough families, as FP64, FP32 eigenvalues only (all-FP32 solver, every result certified by an FP64 count
     pair) and FP32 with the growth rate (FP32 in HBM, FP64 in the solver).  Per row: solves/s, the HBM fraction on algorithmic
     bytes (3 N + 1) w, the kernel that ran with its PMC fields, sweeps per solve, flagged systems; for the FP32 rows the
-    distance to the FP64 solve of the SAME (FP32-valued) systems in units of eps32 ||A||.  Rows are skipped (and say so)
-    once the leg's time budget is spent."""
+    distance to the FP64 solve of the SAME (FP32-valued) systems in units of eps32 ||A||; for the FP64 rows the systems closed
+    again in division form (informational status bit 3) and -- the checker, not the thing measured -- the distance of a sample
+    (every re-closed system up to 256, and 2,048 random ones) to the C oracle's division-form bisection in units of ||A||, against
+    the stated 4 N eps.  Rows are skipped (and say so) once the leg's time budget is spent."""
     import torch
     rows = []
     seen = {}                       # (kernel, waves) -> rows so far: the work class of the next one in the PMC summary
@@ -790,6 +806,19 @@ def c5_matrix(ctx, device, n_sys=1 << 20, budget_s=75.0):
                            roofline=hbm_roofline(n_sys * (3 * N + 1) * w, ms, "valu_issue", kern, waves, work_class=seen.get((kern, waves), 0),
                                                  bytes_per_solve=(3 * N + 1) * w))
                 seen[(kern, waves)] = seen.get((kern, waves), 0) + 1
+                if mode == "f64":
+                    rc = torch.nonzero(((r["info"] >> 16) & 8) != 0).flatten()
+                    row["reclosed_in_division_form"] = int(rc.numel())
+                    if oracle_check:
+                        from oracle import c_oracle as co
+                        gen = torch.Generator(device=device); gen.manual_seed(7 + nz)
+                        pk = torch.unique(torch.cat([rc[:256], torch.randint(0, n_sys, (2048,), device=device, generator=gen)]))
+                        lam_c = co.lam_batch(h, g[pk].cpu().numpy(), c[pk].cpu().numpy(), f[pk].cpu().numpy())
+                        nA64 = norm_a(h, g[pk], c[pk], f[pk]).cpu().numpy()
+                        row["max_abs_dlam_over_normA"] = float((np.abs(r["lam"][pk].cpu().numpy() - lam_c) / nA64).max())
+                        row["tolerance_4N_eps"] = 4 * N * 2.220446049250313e-16
+                        row["within_tolerance"] = bool(row["max_abs_dlam_over_normA"] <= row["tolerance_4N_eps"])
+                        row["oracle_sample"] = int(pk.numel())
                 if mode == "f32_lam":     # (informational status bit 2: the all-FP32 result failed its FP64 certificate, solved in FP64)
                     row["resolved_in_f64"] = int((((r["info"] >> 16) & 4) != 0).sum().item())
                 if mode != "f64":
@@ -809,7 +838,8 @@ def c5_matrix(ctx, device, n_sys=1 << 20, budget_s=75.0):
              for nz in (256, 512, 1024, 2048) for fam in ("smooth", "rough")}
     return dict(workload="configs[4]: %d random (g, c, f) systems per row, N_zeta x {f64, f32 eigenvalues only, f32 with growth rate} x "
                          "{smooth, rough}" % n_sys, rows=rows, f32_gam_over_f64=ratio,
-                f32_results_outside_tolerance=int(sum(1 for r in done if r.get("within_tolerance") is False)),
+                f32_results_outside_tolerance=int(sum(1 for r in done if r.get("within_tolerance") is False and r["mode"] != "f64")),
+                f64_rows_outside_4N_eps=int(sum(1 for r in done if r.get("within_tolerance") is False and r["mode"] == "f64")),
                 seconds=time.perf_counter() - t_leg)
 
 
@@ -1437,7 +1467,7 @@ def main():
             out["c4_adjoint_step"] = c4_adjoint_step(ctx, device, n_oracle=0 if args.no_cpu else 4)
             if out["c4_adjoint_step"].get("parity_ok") is False:
                 rc = 3
-            out["c5_matrix"] = c5_matrix(ctx, device)
+            out["c5_matrix"] = c5_matrix(ctx, device, oracle_check=not args.no_cpu)
         emit(out)
         if rc:
             print("bench.py: parity check FAILED: max |gam - oracle| = %g (bar 1e-8), flagged solves %d" % (

@@ -86,6 +86,9 @@ struct ibs_ctx {
   // workspace of the long-grid path (N > 2050: ibs_long.hip), grown on demand
   void* long_ws = nullptr;
   size_t long_ws_bytes = 0;
+  // suspect list of the big-batch raw kernels (GcfArgs::fix_*): [count | system indices | polish values], grown on demand
+  void* fix_buf = nullptr;
+  long fix_cap = 0;
   int lds_per_block = 160 * 1024;
   int n_cu = 256;
   // native RCCL communicator of this rank (ibs_comm_init), null = none
@@ -161,6 +164,14 @@ int ensure_long_ws(ibs_ctx* c, size_t bytes) {
   if (c->long_ws) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->long_ws)); c->long_ws = nullptr; c->long_ws_bytes = 0; }
   HIPCHK(hipMalloc(&c->long_ws, bytes));
   c->long_ws_bytes = bytes;
+  return 0;
+}
+int ensure_fix(ibs_ctx* c, long n_sys) {
+  if (n_sys <= c->fix_cap) return 0;
+  if (c->fix_buf) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->fix_buf)); c->fix_buf = nullptr; c->fix_cap = 0; }
+  const long cap = n_sys < 4096 ? 4096 : n_sys;
+  HIPCHK(hipMalloc(&c->fix_buf, 256 + (size_t)cap * 16));
+  c->fix_cap = cap;
   return 0;
 }
 int long_waves(const ibs_ctx* c, long n_sys) { const long cap = 8L * c->n_cu; return (int)(n_sys < cap ? n_sys : cap); }
@@ -384,8 +395,31 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
   ON_DEVICE(ctx);
   auto launch = table[M];
   size_t per_wave = (size_t)3 * ibs::lds_pitch(lng ? 66 : N) * sizeof(T);
-  auto launch_it = [&](const ibs::GcfArgs<T>& a) -> int {
-    if (!lng) { HIPCHK(launch(a, ctx->stream)); return 0; }
+  auto launch_it = [&](ibs::GcfArgs<T>& a) -> int {
+    if (!lng) {
+      // the big-batch forms (rows from global memory, sub-wave) only LIST their suspect systems; k_fix_gcf re-closes them afterwards
+      auto& t = ibs::launch_table();
+      bool lists;
+      if constexpr (sizeof(T) == 8) lists = launch == t.gcf_direct_f64[M] || launch == t.gcf_f64_g[0][M] || launch == t.gcf_f64_g[1][M];
+      else lists = launch == t.gcf_direct_f32w[M] || launch == t.gcf_f32w_g[0][M] || launch == t.gcf_f32w_g[1][M];
+      if (lists && (a.flags & 1)) {
+        if (int r = ensure_fix(ctx, (long)a.n_sys)) return r;
+        char* fb = static_cast<char*>(ctx->fix_buf);
+        a.fix_count = reinterpret_cast<int*>(fb);
+        a.fix_sys = reinterpret_cast<long*>(fb + 256);
+        a.fix_center = reinterpret_cast<double*>(fb + 256 + (size_t)ctx->fix_cap * 8);
+        HIPCHK(hipMemsetAsync(a.fix_count, 0, sizeof(int), ctx->stream));
+      }
+      HIPCHK(launch(a, ctx->stream));
+      if (a.fix_count) {
+        ibs::LaunchNote keep = ibs::last_launch();         // (ibs_last_launch names the solver kernel, not its fix-up pass)
+        auto fix = (sizeof(T) == 8 ? (void*)t.gcf_fix_f64[rows_per_lane(N)] : (void*)t.gcf_fix_f32w[rows_per_lane(N)]);
+        if (!fix) return fail(IBS_ERR_UNSUPPORTED, "no fix-up kernel built for N=%d", N);
+        HIPCHK(reinterpret_cast<hipError_t (*)(const ibs::GcfArgs<T>&, hipStream_t)>(fix)(a, ctx->stream));
+        ibs::last_launch() = keep;
+      }
+      return 0;
+    }
     const int nw = long_waves(ctx, (long)a.n_sys);
     if (int r = ensure_long_ws(ctx, (size_t)nw * 3 * (size_t)N * sizeof(double))) return r;
     ibs::LongGcfArgs la{};
@@ -581,6 +615,7 @@ int ibs_destroy(ibs_ctx* c) {
   DeviceGuard g(c->device);
   if (c->ws) hipFree(c->ws);
   if (c->long_ws) hipFree(c->long_ws);
+  if (c->fix_buf) hipFree(c->fix_buf);
   for (auto& sc : c->surf_counters) if (sc.buf) hipFree(sc.buf);
   if (c->refine_hist) hipHostFree(c->refine_hist);
   if (c->hs) hipHostFree(c->hs);

@@ -295,9 +295,11 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
       const int cnt = w ? cnt2[r] : cnt1[r];
       const double dn = w ? a.dn_nyq : a.dn_mn, n0 = rn_s[w][r];
       int k0 = 0; double nc = n0;
-      const double kz = -n0 / dn;
-      const int kr = (int)(kz + (kz >= 0 ? 0.5 : -0.5));
-      if (kr >= 0 && kr < cnt && fabs(n0 + kr * dn) <= 1e-9 * fabs(dn)) { k0 = kr; nc = 0.0; }
+      if (dn != 0.0) {                                           // (the host check geo_rows_fit_host guards the same division)
+        const double kz = -n0 / dn;
+        const int kr = (int)(kz + (kz >= 0 ? 0.5 : -0.5));
+        if (kr >= 0 && kr < cnt && fabs(n0 + kr * dn) <= 1e-9 * fabs(dn)) { k0 = kr; nc = 0.0; }
+      }
       k0_s[w][r] = k0;
       const int tm = k0 > cnt - 1 - k0 ? k0 : cnt - 1 - k0;
       tm_s[w][r] = tm;
@@ -324,7 +326,9 @@ __global__ void __launch_bounds__(256) k_geo_prepare(GeoArgs a, int lpp, double*
     // past the image and past the LDS copy of it.  The host entry points check the rows (geo_rows_fit) and send such tables to
     // k_fieldline_geometry; as a second line of defence the surface is flagged here (slot 15 = -2, used length = the header)
     // and k_geo_rows writes NaN for its lines.
-    const bool too_long = Ts > kGeoMaxPairs;
+    // (the same flag when the rows together claim more pair entries than the image holds one-per-mode: overlapping rows -- refused by
+    //  the host check, but device-resident rows are only checked once per table set)
+    const bool too_long = Ts > kGeoMaxPairs || S1 > n1 || S2 > n2;
     if (t == 0) {
       I[13] = too_long ? (double)L.o_ri1 : (double)(o_pq + 16 * NB * Ts); I[14] = (double)o_synq; I[15] = too_long ? -2.0 : (double)Ts;
       I[16] = (double)any_s[0]; I[17] = (double)any_s[1];

@@ -305,7 +305,9 @@ struct GroupSolver {
     }
   }
 
-  // twisted estimate per group (see WaveSolver::twisted); returns rho, group-replicated
+  // twisted estimate per group (see WaveSolver::twisted); returns rho, group-replicated.  CNT: also extra_above (group-replicated)
+  int extra_above;
+  template <bool CNT = false>
   __device__ __forceinline__ T twisted(T sig) {
     // pass A: replay the forward solution; per-lane candidate for the twist row k = argmax f |u w| together with
     // the entries around it (so that no dynamically indexed array access is needed afterwards)
@@ -363,6 +365,8 @@ struct GroupSolver {
     thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
     // pass B: sum f x^2 over the twisted vector (forward solution replayed again)
     T acc = T(0);
+    static_assert(M + 2 <= 32, "sign word");
+    unsigned su = sign_word(zu_m1) >> 31, sw = 0;      // CNT: sign bits of (u_-1, u_0 .. u_{M-1}) and of (w_0 .. w_{M-1}): WaveSolver::twisted
     {
       T zc = u0_in, zp = zu_m1;
 #pragma unroll
@@ -372,9 +376,22 @@ struct GroupSolver {
         const T xu = zc * fu, xw = zw[i] * fw;
         const T x = (i <= thr) ? xu : xw;
         if (act) acc = xfma(Ph[i] * x, x, acc);
+        if constexpr (CNT) {
+          su = (unsigned)__builtin_amdgcn_alignbit(su, sign_word(zc), 31);
+          sw = (unsigned)__builtin_amdgcn_alignbit(sw, sign_word(zw[i]), 31);
+        }
         const T zn = xfma(-t, zc, -zp);
         if (act) { zp = zc; zc = zn; }
       }
+    }
+    if constexpr (CNT) {
+      const int last = has_last ? M - 1 : M - 2;
+      const int iu = thr < last ? thr : last;
+      const unsigned mu = iu >= 0 ? (((1u << (iu + 1)) - 1u) << (M - 1 - iu)) : 0u;
+      const int iw = thr > 0 ? thr : 0;
+      const unsigned mw = iw <= last ? (((1u << (last - iw + 1)) - 1u) << (M - last)) : 0u;
+      const unsigned sw2 = (sw << 1) | (sign_word(zw_p1) >> 31);
+      extra_above = GP::sum_i(__builtin_popcount((su ^ (su >> 1)) & mu) + __builtin_popcount((sw2 ^ (sw2 << 1)) & mw), lane);
     }
     sig_vec = sig;
     const T tot = GP::sum(acc, lane);
@@ -415,9 +432,15 @@ struct GroupSolver {
   // expected error (both group-replicated).  The first shift is guess + width and walks up geometrically until a
   // count certifies an upper bound; the next one is guess - width.  Certified exactly like the cold solve.
   // CHK: the closing bracket's consistency check of WaveSolver::solve<true> (read its comment), per group
-  bool suspect;
-  int why;
+  bool suspect, closed;
   T rho_last;
+  __device__ __forceinline__ int why() const {           // (mark-only mode: WaveSolver::why, per group)
+    const T tol = T(64) * Eps<T>::v * normA, rho = rho_last;
+    const T dist = xmax(xmax(lo - rho, rho - hi), T(0));
+    int bk = dist > T(0) ? expo_of(dist) - expo_of(tol) + 8 : 0;
+    bk = finite_of(rho) ? (bk < 1 ? (dist > T(0) ? 1 : 0) : (bk > 63 ? 63 : bk)) : 63;
+    return closed ? (bk | (extra_above != 0 ? 64 : 0)) : 0;
+  }
   T chk_slack;     // (set by setup())
   template <bool CHK = false>
   __device__ __forceinline__ T solve(bool bad, int& iters_out, int& status_out, bool warm = false, T guess = T(0),
@@ -527,18 +550,16 @@ struct GroupSolver {
     // sweep and the outputs of such systems are built from written state and repeat bit for bit)
     if (__any(!done) || guard == 0) sweep_fwd<true>(sig);
     sweep_bwd(sig);
-    const T rho = twisted(sig);
+    const T rho = twisted<CHK>(sig);
     iters_out = it;
     status_out = bad ? 2 : (done ? 0 : 1);
     lam = done ? ((finite_of(rho) && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi)) : sig;
     if constexpr (CHK) {
       const bool rho_in = finite_of(rho) && rho >= lo - chk_slack && rho <= hi + chk_slack;
-      suspect = done && !bad && !rho_in;
+      suspect = done && !bad && (!rho_in || extra_above != 0);
       rho_last = rho;
       lam = (done && rho_in) ? xmin(xmax(rho, lo), hi) : lam;
-      const T dist = xmax(xmax(lo - rho, rho - hi), T(0));
-      int bk = dist > T(0) ? expo_of(dist) - expo_of(tol) + 8 : 0;
-      why = (!done || bad) ? 0 : (finite_of(rho) ? (bk < 1 ? (dist > T(0) ? 1 : 0) : (bk > 63 ? 63 : bk)) : 63);
+      closed = done && !bad;
     }
     return lam;
   }

@@ -378,7 +378,7 @@ template <typename T, int M, class Rows>
 __device__ __forceinline__ bool reclose_suspect(const WaveSolver<T, M>& ws, SolveInfo& inf, const Rows& rows, int N, T h, int flags,
                                                 T& lam) {
   if (!(flags & 1)) {                                      // mark-only (diagnostics): every polish outside the bracket, and how far
-    if (flags != 0 && ws.why != 0) inf.status |= 8 | (ws.why << 5);
+    if (flags != 0 && ws.why() != 0) inf.status |= 8 | (ws.why() << 5);
     return false;
   }
   if (!ws.suspect) return false;                           // (wave-uniform)
@@ -391,6 +391,16 @@ __device__ __forceinline__ bool reclose_suspect(const WaveSolver<T, M>& ws, Solv
   if (!ok) { inf.status |= 1; return false; }
   lam = l2;
   return true;
+}
+
+// The big-batch forms do not re-close in place: a suspect system is appended to the launch's list and k_fix_gcf (below) does the rest.
+template <typename T>
+__device__ __forceinline__ void list_suspect(int* cnt, long* sys_list, double* center, bool valid, bool first_lane, long sys, T rho, T lam) {
+  if (cnt && valid && first_lane) {
+    const int i = atomicAdd(cnt, 1);
+    sys_list[i] = sys;
+    center[i] = finite_of(rho) ? (double)rho : (double)lam;
+  }
 }
 
 // ---------------------------------------------------------------- raw (g, c, f) systems
@@ -517,7 +527,8 @@ __global__ void __launch_bounds__(256) k_solve_gcf(long n_sys, int N, T h, const
 template <typename T, int M, typename TI>
 __device__ __forceinline__ void solve_gcf_direct_body(long n_sys, int N, T h, const TI* __restrict__ g, const TI* __restrict__ c,
                                                       const TI* __restrict__ f, long ld, TI* lam_out, TI* gam_out, TI* X_out,
-                                                      TI* dX_out, int* info_out, int flags) {
+                                                      TI* dX_out, int* info_out, int flags, int* fix_count, long* fix_sys,
+                                                      double* fix_center) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -531,12 +542,18 @@ __device__ __forceinline__ void solve_gcf_direct_body(long n_sys, int N, T h, co
   const bool want_vec = gam_out || X_out || dX_out;     // (kernel-uniform)
   const bool bad = ws.template setup<SrcDirect<T, TI>, true>(src, N, h);
   T lam = T(0);
-  bool redo = false;   // the solve was re-closed in division form: the eigenvector stage is repeated at the end
   if (!bad) {
     T g_, w_;
     ws.trial_guess(g_, w_);
     lam = ws.template solve<true>(inf, true, g_, w_);
-    redo = reclose_suspect<T, M>(ws, inf, src, N, h, flags, lam);
+    // a suspect solve (WaveSolver::solve<true>) is LISTED: k_fix_gcf closes it again in division form and repeats its eigenvector
+    // stage after this launch, so that the hot kernel carries none of that code (flags bit 1: only marked, diagnostics)
+    if (flags & 1) {                                       // (kernel-uniform)
+      if (ws.suspect) list_suspect<T>(fix_count, fix_sys, fix_center, valid, lane == 0, sysc, ws.rho_last, lam);      // (wave-uniform, rare)
+    } else if (flags != 0) {
+      const int w = ws.why();
+      if (w != 0) inf.status |= 8 | (w << 5);
+    }
   } else { inf.status = 2; ws.sweep(ws.hi); ws.twisted(ws.hi); }
   if (!want_vec) {                         // (kernel-uniform) eigenvalues only
     if (lane == 0 && valid) {
@@ -548,21 +565,13 @@ __device__ __forceinline__ void solve_gcf_direct_body(long n_sys, int N, T h, co
   finish_chunk<T, M, SrcDirect<T, TI>, false, 1, TI>(ws, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
                                                      valid ? gam_out : nullptr, valid ? X_out : nullptr,
                                                      valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
-  if (redo) {                              // (wave-uniform, rare) eigenvector stage once more, at the re-closed eigenvalue
-    if (Xs) wave_lds_sync();
-    WaveSolver<T, M> w2;
-    (void)w2.template setup<SrcDirect<T, TI>, false>(src, N, h);
-    w2.sweep(lam); w2.twisted(lam);
-    finish_chunk<T, M, SrcDirect<T, TI>, false, 1, TI>(w2, src, N, h, Xs, lam, inf, sysc, valid ? lam_out : nullptr,
-                                                       valid ? gam_out : nullptr, valid ? X_out : nullptr,
-                                                       valid ? dX_out : nullptr, nullptr, valid ? info_out : nullptr);
-  }
 }
 template <typename T, int M, typename TI>
 __global__ void __launch_bounds__(256) k_solve_gcf_direct(long n_sys, int N, T h, const TI* __restrict__ g,
                                                           const TI* __restrict__ c, const TI* __restrict__ f, long ld,
-                                                          TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags) {
-  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out, flags);
+                                                          TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags,
+                                                          int* fix_count, long* fix_sys, double* fix_center) {
+  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out, flags, fix_count, fix_sys, fix_center);
 }
 // The same kernel held to two waves per SIMD (256 registers).  The allocator left to itself takes AGPRs from M = 21 on (one wave
 // per SIMD, `valu_issue` 0.39-0.53); capped, M = 21 .. 28 spill 12-232 B per lane and still gain: FP64 rows 1.17-1.5x (N_zeta =
@@ -573,8 +582,71 @@ constexpr bool direct_two_waves(int M, bool f32_rows) { return M >= 21 && M <= (
 template <typename T, int M, typename TI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_solve_gcf_direct_w2(long n_sys, int N, T h, const TI* __restrict__ g, const TI* __restrict__ c, const TI* __restrict__ f, long ld,
-                      TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags) {
-  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out, flags);
+                      TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags, int* fix_count, long* fix_sys,
+                      double* fix_center) {
+  solve_gcf_direct_body<T, M, TI>(n_sys, N, h, g, c, f, ld, lam_out, gam_out, X_out, dX_out, info_out, flags, fix_count, fix_sys, fix_center);
+}
+
+// The listed suspects of a big-batch launch (k_solve_gcf_direct*, k_solve_gcf_g): one wave (= one block) per system.
+//   1. the rows of the division form -- d_r, e_r^2, f_r (utils.py:1584-1592) -- are formed once, in parallel, into LDS;
+//   2. ONE multisection pass over a bracket of half width 2^11 eps ||A|| about the polish the solver kernel recorded places lam_max
+//      in an interval 65 eps ||A|| wide by division-form counts (a polish further off first costs the passes that move the bracket);
+//   3. set-up and a sweep pair at the interval's middle: the twisted factorisation's Rayleigh polish, clamped into the interval, is
+//      the eigenvalue returned (within 65 eps ||A|| of lam_max a priori, ~1 eps typically), and, when the growth rate or the
+//      eigenfunction was asked for, a second sweep pair AT it feeds the growth-rate stage (utils.py:1601-1621) that overwrites the
+//      system's provisional outputs.
+// The info word gains the informational status bit 3 and the passes.  The chain of n dependent divisions per pass is what this
+// kernel's time is (~50 us at N_zeta = 2048); it runs after the solver kernel, on at most a few dozen waves.  A persistent grid:
+// the list length is only known on the device.
+template <int M, typename TI>
+__global__ void __launch_bounds__(64) k_fix_gcf(const int* __restrict__ n_fix, const long* __restrict__ fix_sys,
+                                                const double* __restrict__ fix_center, int N, double h, const TI* __restrict__ g,
+                                                const TI* __restrict__ c, const TI* __restrict__ f, long ld, TI* lam_out, TI* gam_out,
+                                                TI* X_out, TI* dX_out, int* info_out) {
+  using T = double;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63;
+  const int nf = *n_fix;
+  const int n = N - 2;
+  const bool want_vec = gam_out || X_out || dX_out;     // (kernel-uniform)
+  T* rd = reinterpret_cast<T*>(smem_raw); T* re2 = rd + n; T* rf = re2 + n;
+  T* Xs = rf + n;                                        // (one padded row, used when X / dX are written or M < 3)
+  const T ih2 = T(1) / (h * h);
+  for (int i = blockIdx.x; i < nf; i += gridDim.x) {
+    const long sys = fix_sys[i];
+    SrcDirect<T, TI> src{g + sys * ld, c + sys * ld, f + sys * ld};
+    for (int r = lane; r < n; r += kWave) {              // the diagonal exactly as WaveSolver::setup forms it
+      const T e_lo = T(0.5) * (src.g(r) + src.g(r + 1)) * ih2, e_hi = T(0.5) * (src.g(r + 1) + src.g(r + 2)) * ih2;
+      rd[r] = src.c(r + 1) - (e_lo + e_hi); re2[r] = e_lo * e_lo; rf[r] = src.f(r + 1);
+    }
+    wave_lds_sync();
+    WaveSolver<T, M> ws;
+    (void)ws.template setup<SrcDirect<T, TI>, false>(src, N, h);
+    const T epsA = Eps<T>::v * ws.normA, center = (T)fix_center[i];
+    T lo = center - T(2048) * epsA, hi = center + T(2048) * epsA, lam;
+    int passes;
+    const bool ok = multisect<T>([&](T sig) { return count_above_rows<T>(rd, re2, rf, n, sig); }, lo, hi, ws.normA, T(128), lane, lam, passes);
+    const int old = info_out ? info_out[sys] : 0;
+    SolveInfo inf{(old & 0xffff) + passes, ((old >> 16) & 0x7fff) | 8 | (ok ? 0 : 1)};
+    if (ok) {
+      // the interval [lam - w, lam + w] is certified by division-form counts; the polish of a sweep pair at its middle refines within it
+      const T w = T(33) * epsA;
+      ws.sweep(lam);
+      const T rho = ws.twisted(lam);
+      const T lam2 = WaveSolver<T, M>::U(finite_of(rho)) ? xmin(xmax(rho, lam - w), lam + w) : lam;
+      if (want_vec) {
+        ws.sweep(lam2); ws.twisted(lam2);
+        if constexpr (M >= 3)
+          finish_chunk<T, M, SrcDirect<T, TI>, false, 1, TI>(ws, src, N, h, Xs, lam2, inf, sys, lam_out, gam_out, X_out, dX_out, nullptr, info_out);
+        else
+          finish<T, M, SrcDirect<T, TI>, false, NoTangent, TI>(ws, src, N, h, Xs, lam2, inf, sys, lam_out, gam_out, X_out, dX_out, nullptr, info_out);
+      } else if (lane == 0) {
+        if (lam_out) lam_out[sys] = (TI)lam2;
+        if (info_out) info_out[sys] = inf.iters | (inf.status << 16);
+      }
+    } else if (lane == 0 && info_out) info_out[sys] = inf.iters | (inf.status << 16);
+    wave_lds_sync();                                     // (the rows are rebuilt for this wave's next system)
+  }
 }
 
 // FP32 eigenvalues only, rows straight from global memory: the all-FP32 shift iteration of k_solve_gcf<float, M> and its FP64
@@ -1668,7 +1740,7 @@ static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
     const size_t lds = (a.X || a.dX) ? (size_t)wpb * lds_pitch(a.N) * sizeof(double) : 0;
     const long nblk = (a.n_sys + wpb - 1) / wpb;
     constexpr bool w2 = direct_two_waves(IBS_M, sizeof(TI) == 4);
-    void (*kern)(long, int, double, const TI*, const TI*, const TI*, long, TI*, TI*, TI*, TI*, int*, int);
+    void (*kern)(long, int, double, const TI*, const TI*, const TI*, long, TI*, TI*, TI*, TI*, int*, int, int*, long*, double*);
     if constexpr (w2) kern = k_solve_gcf_direct_w2<double, IBS_M, TI>;      // (only the form that runs is instantiated)
     else kern = k_solve_gcf_direct<double, IBS_M, TI>;
     if (lds) {
@@ -1676,12 +1748,24 @@ static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, (double)a.h, a.g, a.c, a.f, a.ld,
-                       a.lam, a.gam, a.X, a.dX, a.info, a.flags);
+                       a.lam, a.gam, a.X, a.dX, a.info, a.flags, a.fix_count, a.fix_sys, a.fix_center);
     note_launch(nblk, wpb * 64, w2 ? "ibs::k_solve_gcf_direct_w2<double, %d, %s>" : "ibs::k_solve_gcf_direct<double, %d, %s>", IBS_M, type_name<TI>());
     return hipGetLastError();
   } else {
     return hipErrorInvalidValue;
   }
+}
+// second launch of the big-batch forms: the suspects they listed (k_fix_gcf)
+template <typename TI>
+static hipError_t launch_gcf_fix(const GcfArgs<TI>& a, hipStream_t st) {
+  const size_t lds = ((size_t)3 * (a.N - 2) + lds_pitch(a.N)) * sizeof(double);
+  long nblk = a.n_sys < 1024 ? a.n_sys : 1024;
+  auto kern = k_fix_gcf<IBS_M, TI>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64), lds, st, a.fix_count, a.fix_sys, a.fix_center, a.N, (double)a.h, a.g, a.c, a.f,
+                     a.ld, a.lam, a.gam, a.X, a.dX, a.info);
+  return hipGetLastError();
 }
 #ifdef IBS_WITH_F32
 // the occupancy cap pays where the allocator would otherwise take AGPRs (one wave per SIMD): checked per M in the resource table
@@ -1830,6 +1914,10 @@ struct IBS_CAT(Registrar, IBS_M) {
 #endif
 #if defined(IBS_WITH_F32) && IBS_M >= IBS_F32LAM_DIRECT_MIN_M
     t.gcf_direct_f32lam[IBS_M] = &launch_gcf_f32lam_direct;
+#endif
+    t.gcf_fix_f64[IBS_M] = &launch_gcf_fix<double>;
+#ifdef IBS_WITH_F32
+    t.gcf_fix_f32w[IBS_M] = &launch_gcf_fix<float>;
 #endif
     t.scan_f64[IBS_M] = &launch_scan<double>;
     t.scan_chain_f64[IBS_M] = &launch_scan_chain<double>;

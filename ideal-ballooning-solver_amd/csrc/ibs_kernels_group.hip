@@ -154,7 +154,8 @@ __device__ __forceinline__ void finish_chunk_g(GroupSolver<T, M, P>& ws, const S
 template <typename T, int M, int P, typename TI = T>
 __global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, const TI* __restrict__ g,
                                                      const TI* __restrict__ c, const TI* __restrict__ f, long ld,
-                                                     TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags) {
+                                                     TI* lam_out, TI* gam_out, TI* X_out, TI* dX_out, int* info_out, int flags,
+                                                     int* fix_count, long* fix_sys, double* fix_center) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   constexpr int G = 64 / P;
@@ -172,34 +173,22 @@ __global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, 
   T g_ = T(0), w_ = T(0);
   bool warm_ = false;
   ws.trial_guess(true, g_, w_, warm_);                 // cold solves start from the trial vector's bracket
-  T lam = ws.template solve<true>(bad, iters, status, warm_, g_, w_);
-  const bool want_vec = gam_out || X_out || dX_out;     // (kernel-uniform)
-  bool redo = false;                                    // this group's solve was re-closed in division form
+  const T lam = ws.template solve<true>(bad, iters, status, warm_, g_, w_);
   if constexpr (sizeof(T) == 8) {
-    // Re-close of the groups whose closing bracket failed the consistency checks (reclose_suspect in ibs_kernels.hip): one
-    // group at a time, the WHOLE wave running the division-form multisection on that group's rows (64 shifts per pass).
-    unsigned long long todo = flags == 0 ? 0ull : __builtin_amdgcn_ballot_w64(((flags & 1) ? ws.suspect : ws.why != 0) && ws.lg == 0);
-    while (todo != 0ull) {                               // (wave-uniform)
-      const int l0 = __builtin_ctzll(todo);             // first lane of the group
-      todo &= todo - 1ull;
-      const bool mine = (lane & ~(P - 1)) == l0;
-      status |= mine ? 8 : 0;
-      if (!(flags & 1)) status |= mine ? (ws.why << 5) : 0;       // (mark-only: how far outside the bracket the polish fell)
-      if (flags & 1) {
-        const long s0 = ((long)readlane_i((int)(sysc >> 32), l0) << 32) | (long)(unsigned)readlane_i((int)sysc, l0);
-        const SrcGlobal<T, TI> sd{g + s0 * ld, c + s0 * ld, f + s0 * ld};
-        const T rl = readlane_t(ws.rho_last, l0), lm = readlane_t(lam, l0), nA = readlane_t(ws.normA, l0);
-        int passes;
-        T l2;
-        const bool ok = reclose_division<T, SrcGlobal<T, TI>>(sd, N, h, finite_of(rl) ? rl : lm, nA, lane, l2, passes);
-        iters += mine ? passes : 0;
-        lam = (mine && ok) ? l2 : lam;
-        status |= (mine && !ok) ? 1 : 0;
-        redo = redo || (mine && ok);
+    // a group whose closing bracket failed the consistency check of solve<true> is LISTED (flags bit 0): k_fix_gcf (ibs_kernels.hip)
+    // closes it again in division form and repeats its eigenvector stage after this launch; flags bit 1: only marked (diagnostics)
+    if (flags & 1) {                       // (kernel-uniform)
+      if (ws.suspect && valid && ws.lg == 0 && fix_count) {           // (rare)
+        const int i = atomicAdd(fix_count, 1);
+        fix_sys[i] = sysc;
+        fix_center[i] = finite_of(ws.rho_last) ? (double)ws.rho_last : (double)lam;
       }
+    } else if (flags != 0) {
+      const int w = ws.why();
+      status |= w != 0 ? (8 | (w << 5)) : 0;
     }
   }
-  if (!want_vec) {                         // (kernel-uniform) eigenvalues only: no eigenvector, no Simpson sums
+  if (!gam_out && !X_out && !dX_out) {     // (kernel-uniform) eigenvalues only: no eigenvector, no Simpson sums
     if (ws.lg == 0 && valid) {
       if (lam_out) lam_out[sysc] = (TI)lam;
       if (info_out) info_out[sysc] = iters | (status << 16);
@@ -208,16 +197,6 @@ __global__ void __launch_bounds__(256, 2) k_solve_gcf_g(long n_sys, int N, T h, 
   }
   finish_chunk_g<T, M, P, SrcGlobal<T, TI>, false, TI>(ws, src, N, h, Xs, lam, iters, status, sysc, valid, lam_out, gam_out, X_out,
                                                        dX_out, static_cast<TI*>(nullptr), info_out);
-  if constexpr (sizeof(T) == 8) {
-    if (__any(redo)) {                     // (rare) eigenvector stage once more for the re-closed groups, at their new eigenvalue;
-      if (X_out || dX_out) wave_lds_sync();   // the wave's other groups sweep along at theirs and write nothing
-      GroupSolver<T, M, P> w2;
-      (void)w2.template setup<SrcGlobal<T, TI>, false>(src, N, h);
-      w2.template sweep_fwd<true>(lam); w2.sweep_bwd(lam); w2.twisted(lam);
-      finish_chunk_g<T, M, P, SrcGlobal<T, TI>, false, TI>(w2, src, N, h, Xs, lam, iters, status, sysc, valid && redo, lam_out, gam_out,
-                                                           X_out, dX_out, static_cast<TI*>(nullptr), info_out);
-    }
-  }
 }
 
 // geometry-fed scan: block = wpb waves of one line part; wave w solves theta0 indices (part*wpb + w)*G .. +G-1
@@ -360,7 +339,7 @@ static hipError_t launch_gcf_g(const GcfArgs<T>& a, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld,
-                     a.lam, a.gam, a.X, a.dX, a.info, a.flags);
+                     a.lam, a.gam, a.X, a.dX, a.info, a.flags, a.fix_count, a.fix_sys, a.fix_center);
   note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_g<%s, %d, %d, %s>", type_name<T>(), IBS_M, IBS_P, type_name<T>());
   return hipGetLastError();
 }
@@ -376,7 +355,7 @@ static hipError_t launch_gcf_g_wide(const GcfArgs<float>& a, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(wpb * 64), lds, st, a.n_sys, a.N, (double)a.h, a.g, a.c, a.f, a.ld,
-                     a.lam, a.gam, a.X, a.dX, a.info, a.flags);
+                     a.lam, a.gam, a.X, a.dX, a.info, a.flags, a.fix_count, a.fix_sys, a.fix_center);
   note_launch(nblk, wpb * 64, "ibs::k_solve_gcf_g<double, %d, %d, float>", IBS_M, IBS_P);
   return hipGetLastError();
 }

@@ -15,7 +15,12 @@ struct GcfArgs {
   long n_sys; int N; T h; const T* g; const T* c; const T* f; long ld;
   T* lam; T* gam; T* X; T* dX; int* info; int wpb;
   const T* gh;      // optional half-grid g [n_sys][ld] (N-1 used); null = mean of neighbouring g
-  int flags;        // FP64 solvers: bit 0 = re-close suspect systems in division form, bit 1 = only mark them (reclose_if_suspect)
+  int flags;        // FP64 solvers: bit 0 = re-close suspect systems in division form, bit 1 = only mark them
+  // big-batch forms (rows from global memory, sub-wave): a suspect system is only LISTED by the solver kernel -- its re-close and the
+  // repeat of its eigenvector stage run in a second, tiny launch (k_fix_gcf) so that none of that code sits in the hot kernel (it cost
+  // 2 % at N_zeta = 512 and 9 % on the two-waves-per-SIMD forms: tools/ab_reclose.py).  fix_count[1] (zeroed by the caller),
+  // fix_sys / fix_center [>= n_sys]: system index and the Rayleigh polish to re-close about.  null = re-close inside the kernel.
+  int* fix_count; long* fix_sys; double* fix_center;
 };
 template <typename T>
 struct ScanArgs {
@@ -103,6 +108,8 @@ struct LaunchTable {
   hipError_t (*gcf_direct_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);  // rows straight from global memory (k_solve_gcf_direct)
   hipError_t (*gcf_direct_f32w[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);  // the same on FP32 arrays (FP64 solver)
   hipError_t (*gcf_direct_f32lam[kMaxM + 1])(const GcfArgs<float>&, hipStream_t); // FP32 eigenvalues only: all-FP32 iteration + FP64 certificate, rows from global memory
+  hipError_t (*gcf_fix_f64[kMaxM + 1])(const GcfArgs<double>&, hipStream_t);     // the listed suspects of a big-batch launch: re-close + eigenvector stage (k_fix_gcf), M = ceil((N - 2) / 64)
+  hipError_t (*gcf_fix_f32w[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);
   hipError_t (*gcf_f32[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);
   hipError_t (*gcf_f32_wide[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);   // FP32 in HBM, FP64 in the solver (gam / X wanted)
   hipError_t (*gcf_f32w_rows[kMaxM + 1])(const GcfArgs<float>&, hipStream_t);  // the same, row-streamed (long grids)

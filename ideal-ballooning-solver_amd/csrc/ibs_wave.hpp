@@ -24,11 +24,15 @@
 //   * no MFMA: there is no dense contraction here; the binding resource is FP64 VALU issue.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace ibs {
 
 constexpr int kWave = 64;
 
+#ifdef IBS_TRACE_ALL
+__device__ double ibs_trace_all[404];
+#endif
 // phase timestamps for tools/phase_probe.hip (debug builds only; the library is built without IBS_PROBE)
 #ifdef IBS_PROBE
 __device__ long long ibs_probe_buf[16 * 4096];
@@ -178,6 +182,15 @@ __device__ __forceinline__ T wave_sum(T v) {
   v += dpp_t<0x142, 0xA>(T(0), v);
   v += dpp_t<0x143, 0xC>(T(0), v);
   return readlane_t(v, 63);
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+  v += dppz_i<0x111, 0xF>(v);
+  v += dppz_i<0x112, 0xF>(v);
+  v += dppz_i<0x114, 0xF>(v);
+  v += dppz_i<0x118, 0xF>(v);
+  v += dpp_i<0x142, 0xA>(0, v);
+  v += dpp_i<0x143, 0xC>(0, v);
+  return readlane_i(v, 63);
 }
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {  // identity for missing lanes: the value itself
@@ -351,14 +364,33 @@ __device__ __forceinline__ int count_above_div(const Src& src, int N, T ih2, T s
   return cnt;
 }
 
-// lam_max of the system `src` by 64-way multisection on division-form counts, from the bracket [lo, hi]: each pass runs 64 shifts
-// (lane 0 at lo, lane 63 at hi) and keeps the interval between the highest shift with an eigenvalue above it and the next one; a
-// bracket that does not hold lam_max (its end shifts say so) is moved and widened 64-fold instead.  Ends at width <= 2 eps ||A||.
+// The same count from rows prepared once in LDS (k_fix_gcf): d_r, e_r^2 (e_0^2 unused), f_r for r = 0 .. n-1, read by all lanes at the
+// same address (broadcast).  The division is the hardware reciprocal + two Newton steps (a few ulp: the count is then exact for a
+// pencil a few more ulp away): the recurrence is one dependent chain per lane, ~55 clocks per row instead of ~95 with the IEEE
+// division, and nothing waits for global memory.
+template <typename T>
+__device__ __forceinline__ int count_above_rows(const T* d, const T* e2, const T* f, int n, T sig) {
+  constexpr T pivmin = T(2.2250738585072014e-292);
+  T q = xfma(-sig, f[0], d[0]);
+  q = xabs(q) < pivmin ? -pivmin : q;
+  int cnt = q > T(0) ? 1 : 0;
+#pragma unroll 8
+  for (int r = 1; r < n; ++r) {
+    const T a = xfma(-sig, f[r], d[r]);
+    q = xfma(-e2[r], fast_rcp(q), a);
+    q = xabs(q) < pivmin ? -pivmin : q;
+    cnt += q > T(0) ? 1 : 0;
+  }
+  return cnt;
+}
+
+// lam_max by 64-way multisection on a division-form count `count(sig)`, from the bracket [lo, hi]: each pass runs 64 shifts (lane 0
+// at lo, lane 63 at hi) and keeps the interval between the highest shift with an eigenvalue above it and the next one; a bracket
+// that does not hold lam_max (its end shifts say so) is moved and widened 64-fold instead.  Ends at width <= stop_eps eps ||A||.
 // All 64 lanes of the wave take part; the result is wave-uniform.
 // passes: sweeps used (each = n dependent divisions per lane);  returns false if 24 passes did not close (non-finite data).
-template <typename T, class Src>
-__device__ __forceinline__ bool multisect_division(const Src& src, int N, T h, T lo, T hi, T normA, int lane, T& lam, int& passes) {
-  const T ih2 = T(1) / (h * h);
+template <typename T, class CountF>
+__device__ __forceinline__ bool multisect(CountF&& count, T lo, T hi, T normA, T stop_eps, int lane, T& lam, int& passes) {
   const T epsA = Eps<T>::v * normA;
   bool ok = false;
   passes = 0;
@@ -366,16 +398,22 @@ __device__ __forceinline__ bool multisect_division(const Src& src, int N, T h, T
     ++passes;
     const T w = hi - lo;
     const T sig = lane == kWave - 1 ? hi : xfma(T(lane) * T(1.0 / 63.0), w, lo);
-    const int cnt = count_above_div<T, Src>(src, N, ih2, sig);
+    const int cnt = count(sig);
     const unsigned long long m = __builtin_amdgcn_ballot_w64(cnt >= 1);
     if (!(m & 1ull)) { hi = lo; lo = lo - T(64) * w; continue; }          // lam_max < lo
     const int top = 63 - __builtin_clzll(m);                              // the highest shift with an eigenvalue above it
     if (top == kWave - 1) { lo = hi; hi = hi + T(64) * w; continue; }     // lam_max >= hi
     lo = readlane_t(sig, top); hi = readlane_t(sig, top + 1);
-    if (!(hi - lo > T(2) * epsA)) { ok = true; break; }
+    if (!(hi - lo > stop_eps * epsA)) { ok = true; break; }
   }
   lam = T(0.5) * (lo + hi);
   return ok;
+}
+// ... on the rows of `src` in memory, to 2 eps ||A||
+template <typename T, class Src>
+__device__ __forceinline__ bool multisect_division(const Src& src, int N, T h, T lo, T hi, T normA, int lane, T& lam, int& passes) {
+  const T ih2 = T(1) / (h * h);
+  return multisect<T>([&](T sig) { return count_above_div<T, Src>(src, N, ih2, sig); }, lo, hi, normA, T(2), lane, lam, passes);
 }
 // ... from a bracket of half width 2^11 eps ||A|| about `center` (the re-close of a suspect solve about its Rayleigh polish, which
 // was within 100 eps ||A|| of lam_max on every suspect of the 10 x 2^20-system campaign: two passes take a valid bracket to
@@ -630,6 +668,15 @@ struct WaveSolver {
   //   rho = sig + num / (z_u,k z_w,k sum_r Ph_r zhat_r^2),  num = row-k residual of (z_u,k z_w,k) zhat,  zhat = z / z_k.
   T fu, fw;
   int thr;
+  // CNT (solve<true>): also counts the eigenvalues above sig OTHER than the one the twist row belongs to, the robust way -- the
+  // twisted factorisation N_k D_k N_k^T has the inertia of T - sig F, and its pivots are the sign changes of the forward solution on
+  // the rows up to k and of the backward solution on the rows from k on, i.e. of each solution in the direction in which it GROWS:
+  //   eigenvalues above sig = #changes(u; rows <= k) + #changes(w; rows >= k) + [gamma_k > 0].
+  // `extra_above` = the first two terms.  It must be 0 when the shift iteration closes on lam_max; 1 or more says that the counts
+  // of the prefix-product sweeps lost an eigenvalue (a shift that landed within their noise band of lam_2 read 0 instead of 1 and
+  // became the bracket's upper end: one system of 10^6 at N_zeta = 1024 returned lam_2, 1.5e-10 ||A|| below lam_max: golden G10).
+  int extra_above;
+  template <bool CNT = false>
   __device__ __forceinline__ T twisted(T sig) {
     // pass A: replay the forward solution; per-lane candidate for the twist row k = argmax f |u w| (any row with a large
     // product will do: discrete Wronskian, gamma_r = W / (u_r w_r)) together with the entries around it, so that no
@@ -680,6 +727,8 @@ struct WaveSolver {
     thr = (lane < Lk) ? M : ((lane > Lk) ? -1 : ik);
     // pass B: sum f x^2 over the twisted vector (forward solution replayed again)
     T acc = T(0);
+    using SignWord = typename std::conditional<(M + 2 <= 32), unsigned, unsigned long long>::type;
+    SignWord su = sign_word(zu_m1) >> 31, sw = 0;      // CNT: sign bits of (u_-1, u_0 .. u_{M-1}) and of (w_0 .. w_{M-1})
     {
       T zc = u0_in, zp = zu_m1;
 #pragma unroll
@@ -689,9 +738,35 @@ struct WaveSolver {
         const T xu = zc * fu, xw = zw[i] * fw;
         const T x = (i <= thr) ? xu : xw;
         if (act) acc = xfma(Ph[i] * x, x, acc);
+        if constexpr (CNT) {
+          if constexpr (sizeof(SignWord) == 4) {
+            su = (unsigned)__builtin_amdgcn_alignbit(su, sign_word(zc), 31);          // (su << 1) | sign(u_i)
+            sw = (unsigned)__builtin_amdgcn_alignbit(sw, sign_word(zw[i]), 31);
+          } else {
+            su = (su << 1) | (SignWord)(sign_word(zc) >> 31);
+            sw = (sw << 1) | (SignWord)(sign_word(zw[i]) >> 31);
+          }
+        }
         const T zn = xfma(-t, zc, -zp);
         if (act) { zp = zc; zc = zn; }
       }
+    }
+    if constexpr (CNT) {
+      // transition i of u = (u_{i-1} -> u_i) sits at bit M-1-i of su ^ (su >> 1), counted for the rows i <= thr this lane owns (each
+      // lane from ITS incoming pair, like sweep_fwd); transition i of w = (w_{i+1} -> w_i), w_M = zw_p1, at bit M-i of sw2 ^ (sw2 << 1),
+      // counted for the owned rows i >= thr
+      const int last = has_last ? M - 1 : M - 2;
+      const int iu = thr < last ? thr : last;                                   // u: i = 0 .. iu   (thr = -1: none)
+      const SignWord one = 1;
+      const SignWord mu = iu >= 0 ? (((one << (iu + 1)) - one) << (M - 1 - iu)) : SignWord(0);
+      const int iw = thr > 0 ? thr : 0;                                         // w: i = iw .. last   (thr = M: none)
+      const SignWord mw = iw <= last ? (((one << (last - iw + 1)) - one) << (M - last)) : SignWord(0);
+      const SignWord sw2 = (sw << 1) | (SignWord)(sign_word(zw_p1) >> 31);
+      const SignWord fl_u = (su ^ (su >> 1)) & mu, fl_w = (sw2 ^ (sw2 << 1)) & mw;
+      int c;
+      if constexpr (sizeof(SignWord) == 4) c = __builtin_popcount(fl_u) + __builtin_popcount(fl_w);
+      else c = __builtin_popcountll(fl_u) + __builtin_popcountll(fl_w);
+      extra_above = wave_sum_i(c);
     }
     sig_vec = sig;
     const T tot = wave_sum(acc);
@@ -746,6 +821,13 @@ struct WaveSolver {
   // this one ~15.5 forward and one backward/twisted.
 #ifdef IBS_TRACE
   T* trace = nullptr;   // debug builds only (tools/trace_solve.hip): 6 values per iteration
+#endif
+#ifdef IBS_TRACE_ALL
+  // debug builds only (tools/probe_direct.hip): EVERY sweep of the FP64 solve of block 0 / wave 0 -- shift, count, bracket before it
+#define IBS_TRACE_SWEEP(it_, sig_, C_, lo_, hi_) do { if (sizeof(T) == 8 && blockIdx.x == 0 && threadIdx.x == 0 && (it_) <= 100) { \
+    double* q_ = ibs_trace_all + 4 * ((it_) - 1); q_[0] = (double)(sig_); q_[1] = (double)(C_); q_[2] = (double)(lo_); q_[3] = (double)(hi_); ibs_trace_all[400] = (double)(it_); } } while (0)
+#else
+#define IBS_TRACE_SWEEP(it_, sig_, C_, lo_, hi_) do {} while (0)
 #endif
   struct Pt { T x, m; int e; };      // shift, shooting value m * 2^e
   // All quantities of the shift iteration are wave-uniform but live in VGPRs (there is no scalar FP64), and a
@@ -859,9 +941,18 @@ struct WaveSolver {
   // outputs are written, i.e. where nothing of this solver is live any more: sweeping again with D / Ph still live (+16-24
   // registers), jumping back into the iteration (+80) or looping back to set-up (+100 and scratch: the loop-invariant row loads
   // get hoisted) all cost the raw kernels occupancy.
-  bool suspect;
-  int why;         // mark-only mode (diagnostics): floor(log2(distance of the polish from the bracket / tol)) + 8, 0 = inside
+  bool suspect, closed;
   T rho_last;
+  // mark-only mode (diagnostics, cold): floor(log2(distance of the polish from the final bracket [lo, hi] / tol)) + 8 in bits 0..5
+  // (0 = inside), bit 6 = extra_above != 0
+  __device__ __forceinline__ int why() const {
+    if (!closed) return 0;
+    const T tol = T(64) * Eps<T>::v * normA, rho = rho_last;
+    const T dist = xmax(xmax(lo - rho, rho - hi), T(0));
+    int bk = dist > T(0) ? expo_of(dist) - expo_of(tol) + 8 : 0;
+    bk = uniform_i(finite_of(rho) ? (bk < 1 ? (dist > T(0) ? 1 : 0) : (bk > 63 ? 63 : bk)) : 63);
+    return bk | (extra_above != 0 ? 64 : 0);
+  }
   T chk_slack;     // (set by setup())
   template <bool CHK = false>
   __device__ __forceinline__ T solve(SolveInfo& inf, bool warm = false, T guess = T(0), T width = T(0)) {
@@ -897,6 +988,7 @@ struct WaveSolver {
       const long long tp1 = wall_clock64(); t_sweep += tp1 - tp0;
 #endif
       ++it;
+      IBS_TRACE_SWEEP(it, sig, C, lo, hi);
       // every shift lies strictly inside (lo, hi), so each count moves one end of the bracket
       if (C == 0) {
         if (hi_f) { Pold = Phi; old_ok = true; }
@@ -989,18 +1081,16 @@ struct WaveSolver {
     IBS_PROBE_AT(10);
     sweep_bwd(sig);
     IBS_PROBE_AT(11);
-    const T rho = twisted(sig);
+    const T rho = twisted<CHK>(sig);
     IBS_PROBE_AT(12);
     if (done) lam = (finite_of(rho) && rho >= lo && rho <= hi) ? rho : T(0.5) * (lo + hi);
     else lam = sig;
     if constexpr (CHK) {
       const bool rho_in = U(finite_of(rho) && rho >= lo - chk_slack && rho <= hi + chk_slack);
-      suspect = done && !rho_in;
+      suspect = done && (!rho_in || extra_above != 0);
       rho_last = rho;
       if (done && rho_in) lam = xmin(xmax(rho, lo), hi);
-      const T dist = xmax(xmax(lo - rho, rho - hi), T(0));
-      int bk = dist > T(0) ? expo_of(dist) - expo_of(tol) + 8 : 0;
-      why = !done ? 0 : uniform_i(finite_of(rho) ? (bk < 1 ? (dist > T(0) ? 1 : 0) : (bk > 63 ? 63 : bk)) : 63);
+      closed = done;
     }
 #ifdef IBS_TRACE
     if (lane == 0 && trace && it < 64) { T* q = trace + 6 * it; q[0] = sig; q[1] = T(-1); q[2] = rho; q[3] = lo; q[4] = hi; q[5] = T(wall_clock64() % 100000000); }

@@ -12,13 +12,26 @@
  *   - `mem`: IBS_MEM_DEVICE = all data pointers are device (HBM) pointers, the call is
  *     asynchronous on the context's stream; IBS_MEM_HOST = host pointers, the library stages
  *     through its own device workspace and the call returns after the results are back.
- *   - grids are uniform in theta with N points (N odd, 66 <= N <= 2050) and spacing h;
- *     arrays of one system/line are contiguous, consecutive systems are `ld` elements apart.
+ *   - grids are uniform in theta with N points (N odd, N >= 66) and spacing h; arrays of one system/line are contiguous,
+ *     consecutive systems are `ld` elements apart.  Up to N = 2050 the register-resident kernels run (one wavefront or a part of
+ *     one per system).  The reference takes any length (utils.py:1556-1624; its own rule N = 2 mpol ntor 4 + 1, ball_scan.py:201-208,
+ *     passes 2050 from mpol ntor > 256 on): for 2050 < N <= 65537 ibs_solve_gcf_f64 / _f32, ibs_solve_gcfh_f64, ibs_gamma_scan_f64 /
+ *     _warm_f64 (the guesses are then unused) / _argmax_f64, ibs_gamma_points_f64 and ibs_sturm_count_f64 run a generic path that
+ *     works in division form on the rows in memory (csrc/ibs_long.hip: correct to the same tolerances, an order of magnitude
+ *     slower per row); ibs_obj_w_grad_f64 and ibs_refine_f64 stay limited to N <= 2050 (IBS_ERR_UNSUPPORTED).
  *   - optional outputs may be NULL.
  *   - info word per system: bits 0..15 = sweeps used, bits 16.. = status
- *     (bit 0 = iteration cap hit, bit 1 = invalid data: non-finite, g <= 0 or f <= 0; bit 2 is informational and only set by
- *     the FP32 eigenvalue-only path: the all-FP32 result failed its FP64 certificate and the system was solved in FP64 --
- *     the returned value is good; return values > 0 and the host-side counts look at bits 0 and 1 only).
+ *     (bit 0 = iteration cap hit, bit 1 = invalid data: non-finite, g <= 0 or f <= 0.  Bits 2-4 are INFORMATIONAL -- the returned
+ *     values are good; return values > 0 and the host-side counts look at bits 0 and 1 only:
+ *     bit 2, FP32 eigenvalue-only path: the all-FP32 result failed its FP64 certificate and the system was solved in FP64;
+ *     bit 3, FP64 raw-system entry points: the closing bracket of the shift iteration disagreed with the twisted factorisation's
+ *            Rayleigh polish by more than min(512, 2 N) eps ||A|| and lam_max was closed again by division-form multisection on the
+ *            rows (the recurrence of LAPACK dstebz): 0 .. 60 systems per million on iid-random coefficients, none on field-line
+ *            data.  With it |lam - lam_max| <= 4 N eps ||A|| holds a priori (tests/test_gpu_configs.py), ||A|| = max_r (|d_r| +
+ *            e_r + e_{r+1}) / f_r of utils.py:1584-1592's rows;
+ *     bit 4, only with option "sigma0" set and both lam and info requested: lam_max >= sigma0.  The reference's ARPACK call returns
+ *            the eigenpair NEAREST sigma0 (utils.py:1597); this library always returns lam_max's.  They are the same eigenpair
+ *            whenever lam_max < sigma0 -- and only then: this bit marks the one case in which upstream may have returned another).
  */
 #ifndef IBS_H
 #define IBS_H
@@ -102,7 +115,11 @@ int ibs_comm_destroy(ibs_ctx* ctx);
  * geometry kernel 1|2|4|8, or -2 = two grid points per lane), "gcf_rows" (0: three-row staging instead of the row-streamed raw
  * kernel on long grids), "gcf_direct" (raw systems, one wave per system: rows read straight from global memory instead of staged in LDS; -1 = by
  * batch size, 0 = never, 1 = always), "f32_lam" (FP32 eigenvalue-only requests: 1 = all-FP32 iteration + FP64 certificate, 2 = FP64 solver on
- * the FP32 arrays; 0 = form 2 where the 16-lane sub-wave kernels run, else form 1), "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
+ * the FP32 arrays; 0 = form 2 where the 16-lane sub-wave kernels run, else form 1), "reclose" (FP64 raw systems: 1 = a solve whose closing bracket
+ * disagrees with its Rayleigh polish is closed again in division form, the default; 2 = only marked with status bit 3 and the distance
+ * in bits 5..10; 0 = off, i.e. the round-5 results), "sigma0" (any finite value: solves that return lam and info flag lam_max >= sigma0
+ * with the informational status bit 4 -- the nearest-sigma report of the drop-in, utils.py:1597; NaN = off, the default),
+ * "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
  * staged in LDS, 1, or read from global memory by the sums, 0: two blocks per CU instead of one at N = 969; -1 = by batch size);
  * value 0 = automatic (refine_tangent, gcf_direct: -1); value NaN = back to what ibs_create() read from the environment
  * (IBS_FORCE_P, IBS_SCAN_CHAIN, IBS_CHAIN_W1, IBS_CHAIN_W2, IBS_GEO_LPP are read once, there); name "all" with NaN
@@ -294,7 +311,10 @@ int ibs_refine_stats(ibs_ctx* ctx, int64_t* out4);
 int ibs_last_launch(char* name, int32_t len, int64_t* blocks, int32_t* threads);
 
 /* Number of eigenvalues of (T, F) strictly above shift[i] for each system (Sturm sequence).
- * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0). */
+ * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0).
+ * Up to N = 2050 this is ONE prefix-product sweep per system (the bandwidth kernel): exact for a pencil perturbed by ~N eps ||A||
+ * on smooth coefficients, but by up to ~N^2 eps ||A|| on iid-random ones -- within that distance of an eigenvalue the count can be
+ * off by one.  Beyond 2050 points the count runs in division form (a few eps ||A||, any N).  Even N is accepted here. */
 int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
                         const double* f, int64_t ld, const double* shift, int32_t* count, int32_t mem);
 

@@ -199,3 +199,23 @@ def test_every_tool_is_in_the_tools_index():
     missing = [f for f in sorted(os.listdir(tdir)) if os.path.isfile(os.path.join(tdir, f)) and f != "README.md" and f not in text]
     assert not missing, missing
     assert not [f for f in os.listdir(tdir) if ".bin" in f or f.endswith((".o", ".so"))], "build products in tools/"
+
+
+def test_docs_state_the_limits_the_code_has():
+    """the numbers a reader meets in INTEGRATION.md / include/ibs.h are the ones the library enforces (a stale '4 slots' survived two
+    rounds): slots of the overlapped gather, the grid limits of the register-resident and the long-grid paths"""
+    import re
+    api = open(os.path.join(ROOT, "ideal-ballooning-solver_amd", "csrc", "ibs_api.hip")).read()
+    launch = open(os.path.join(ROOT, "ideal-ballooning-solver_amd", "csrc", "ibs_launch.hpp")).read()
+    hdr = open(os.path.join(ROOT, "include", "ibs.h")).read()
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    slots = int(re.search(r"kCommSlots = (\d+);", api).group(1))
+    assert "slot in [0, %d)" % slots in hdr
+    assert "up to %d gathers (slots 0 … %d)" % (slots, slots - 1) in integ
+    max_m = int(re.search(r"constexpr int kMaxM = (\d+);", launch).group(1))
+    max_long = int(re.search(r"constexpr int kMaxLongN = (\d+);", launch).group(1))
+    n_reg = 64 * max_m + 2
+    assert "Up to N = %d the register-resident kernels run" % n_reg in hdr and "%d < N <= %d" % (n_reg, max_long) in hdr
+    assert "{:,}".format(max_long) in integ and "{:,}".format(n_reg) in integ
+    assert "{:,}".format(max_long) in design

@@ -278,7 +278,7 @@ def test_G5_coarse_scan_table(ctx, bo):
 
 def test_rejects_unsupported_grids(ctx):
     import ibs_amd
-    for N in (512, 33, 4099):
+    for N in (512, 33, 65539, 4098):      # even, too short, beyond the long-grid path's 65,537 points (4,099 is served since round 6), even and long
         z = np.ones((2, N))
         with pytest.raises(ibs_amd.IbsError):
             ctx.solve_gcf(0.1, z, z, z)

@@ -305,3 +305,43 @@ def test_nearest_sigma_divergence_is_reported(ctx):
     assert ((r["info"] >> 16) & 16).tolist() == [16, 0] and r["nbad"] == 0
     r = ctx.solve_gcf(th[1] - th[0], G2, C2, G2, want_info=True)
     assert ((r["info"] >> 16) & 16).tolist() == [0, 0]
+
+
+def test_G10_top_pair_1p5e10_apart_is_not_mistaken(ctx):
+    """tests/golden/G10_rough_pair_1025.npz: system 245,944 of the config-5 rough family (seed 20240 + 1024, 10^6 systems; captured by
+    tools/experiments/find_bad_system.py), whose two largest eigenvalues lie 1.5e-10 ||A|| apart.  In the round-5 kernels a bisection
+    midpoint landed within 2 tol of lam_2, the prefix-product sweep's count there read 0 instead of 1, that shift became the
+    bracket's upper end and the solve closed on lam_2 -- consistently: the Rayleigh polish agreed (tools/probe_direct.hip shows the
+    25 sweeps).  The twisted factorisation at the last shift counts the eigenvalue the sweeps lost (WaveSolver::twisted<true>:
+    extra_above), the system is closed again in division form, and every raw-kernel form must return lam_max."""
+    import torch
+    from oracle import c_oracle as co
+    d = np.load(os.path.join(G, "G10_rough_pair_1025.npz"))
+    g, c, f = d["g"], d["c"], d["f"]
+    N = len(g); h = 8 * np.pi / (N - 1)
+    lam_c = co.lam_batch(h, g[None], c[None], f[None])[0]
+    assert abs(lam_c - float(d["lam_max"])) < 1e-15 and lam_c - float(d["lam_returned_round5"]) > 8e-5
+    e = 0.5 * (g[:-1] + g[1:]) / h ** 2
+    nA = float(((np.abs(c[1:-1] - (e[:-1] + e[1:])) + e[:-1] + e[1:]) / f[1:-1]).max())
+    tol = 4 * N * 2.220446049250313e-16 * nA
+    dev = torch.device("cuda:0")
+    n = 4096                                              # (a batch large enough for the library to pick the big-batch forms itself)
+    G_, C_, F_ = (torch.from_numpy(np.tile(a, (n, 1))).to(dev) for a in (g, c, f))
+    seen = set()
+    for direct, want_gam in ((1, True), (1, False), (0, True), (0, False), (None, True)):
+        ctx.set_option("gcf_direct", direct)
+        r = ctx.solve_gcf(h, G_, C_, F_, want_info=True, want_gam=want_gam)
+        seen.add(ctx.last_launch()[0])
+        lam = r["lam"].cpu().numpy()
+        assert np.abs(lam - lam_c).max() < tol, (direct, want_gam, ctx.last_launch()[0], float(np.abs(lam - lam_c).max()), tol)
+        assert int((((r["info"] >> 16) & 3) != 0).sum()) == 0
+        if want_gam:                                      # the growth rate of a re-closed system comes from sweeps AT lam_max
+            gam_c = co.solve_gcf(h, g, c, f)[0]
+            assert np.abs(r["gam"].cpu().numpy() - gam_c).max() < 1e-6 * max(1.0, abs(gam_c))
+    ctx.set_option("gcf_direct", None)
+    assert any("k_solve_gcf_direct" in k for k in seen) and any(k.endswith("k_solve_gcf<double, 16>") for k in seen), seen
+    ctx.set_option("reclose", 0)
+    ctx.set_option("gcf_direct", 1)
+    r0 = ctx.solve_gcf(h, G_[:8], C_[:8], F_[:8])["lam"].cpu().numpy()
+    ctx.set_option("reclose", None); ctx.set_option("gcf_direct", None)
+    print("G10 with the checks off: lam - lam_max = %.3e (round 5: %.3e = lam_2 - lam_max)" % (float(r0[0] - lam_c), float(d["lam_returned_round5"]) - lam_c))

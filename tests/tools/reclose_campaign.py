@@ -2,8 +2,9 @@
 """Eigenvalue accuracy of the FP64 raw-system kernels on EVERY system of a config-5 batch (round 6).
 
 The product-form (prefix-scan) Sturm counts that move the solver's bracket are exact for a matrix perturbed by up to ~N^2 eps ||A||
-on iid-random coefficients; the kernels therefore check the closing bracket (Rayleigh polish inside it, forward count = backward
-count) and close a suspect system again by division-form multisection (csrc/ibs_wave.hpp: reclose_division).  This tool solves the
+on iid-random coefficients; the kernels therefore check the closing bracket against the twisted factorisation at the last shift (its
+Rayleigh polish must lie in the bracket, and it must count no OTHER eigenvalue above the shift) and close a suspect system again by
+division-form multisection (csrc/ibs_wave.hpp: solve<true>, reclose_division; csrc/ibs_kernels.hip: k_fix_gcf).  This tool solves the
 whole batch three ways -- checks off, suspects only marked, suspects re-closed -- and compares ALL results with the C oracle's
 division-form bisection (oracle/ibs_oracle.c), in units of ||A||; it also times the three modes.
 
@@ -70,9 +71,12 @@ for nz in nzs:
             print("    checks off      : max %.2e  99.99%% %.2e  median %.2e  | systems beyond 4 N eps: %d" % (
                 e0.max(), np.quantile(e0, 0.9999), np.median(e0), int((e0 > 4 * N * EPS).sum())))
             hb = np.bincount(bucket[marked], minlength=64)
-            print("    polish outside the bracket: %d systems; by distance bucket (2^(b-8) tol): %s;  worst error per bucket: %s" % (
-                int(marked.sum()), {int(b): int(hb[b]) for b in np.nonzero(hb)[0]},
-                {int(b): "%.1e" % e0[marked & (bucket == b)].max() for b in np.nonzero(hb)[0]}))
+            extra = marked & (((st2 >> 11) & 1) != 0)        # the twisted factorisation counts another eigenvalue above the last shift
+            print("    marked: %d systems; polish outside the bracket by distance bucket (2^(b-8) tol; 0 = inside): %s;  worst error per bucket: %s;  "
+                  "another eigenvalue above the last shift (twisted count): %d systems, worst error %.1e" % (
+                      int(marked.sum()), {int(b): int(hb[b]) for b in np.nonzero(hb)[0]},
+                      {int(b): "%.1e" % e0[marked & (bucket == b)].max() for b in np.nonzero(hb)[0]},
+                      int(extra.sum()), e0[extra].max() if extra.any() else 0.0))
             rc = (st1 & 8) != 0
             print("    re-closed       : %d systems (%.1e of the batch), status bits 0/1 set on %d;  max error ALL %.2e (= %.2f N eps; re-closed "
                   "ones %.2e), beyond 4 N eps: %d;  sweeps mean %.2f (re-closed: +%.1f passes)" % (
