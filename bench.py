@@ -53,13 +53,15 @@ CSRC = os.path.join(ROOT, "ideal-ballooning-solver_amd", "csrc")
 # which sources a kernel's instruction stream comes from: the geometry kernels live in one translation unit, every solver /
 # scan / refinement kernel is built from the wave + group solver headers (ibs_api.hip only CHOOSES kernels, and an entry is
 # looked up by the exact kernel name and launch size the library reports, so a changed choice cannot quote wrong counters)
-SRC_GROUPS = {"geometry": ("ibs_geometry.hip", "ibs_launch.hpp"),
-              "solver": ("ibs_kernels.hip", "ibs_kernels_group.hip", "ibs_wave.hpp", "ibs_group.hpp", "ibs_refine.hpp",
-                         "ibs_lbfgsb2.hpp", "ibs_launch.hpp")}
+# (the Makefile carries the compiler flags and the -D knobs that change the code objects; ibs_api.hip holds a few kernels of its own)
+SRC_GROUPS = {"geometry": ("ibs_geometry.hip", "ibs_launch.hpp", "Makefile"),
+              "solver": ("ibs_kernels.hip", "ibs_kernels_group.hip", "ibs_long.hip", "ibs_wave.hpp", "ibs_group.hpp", "ibs_refine.hpp",
+                         "ibs_lbfgsb2.hpp", "ibs_launch.hpp", "ibs_api.hip", "Makefile")}
 
 
 def kernel_group(kernel):
-    return "geometry" if "k_geo_" in kernel else "solver"
+    # (every kernel of ibs_geometry.hip: the row kernels, the one-sincos-per-mode fallback, the dPdrho helper)
+    return "geometry" if any(t in kernel for t in ("k_geo_", "k_fieldline_geometry", "k_line_dPdrho")) else "solver"
 
 
 def src_sha(csrc=None):

@@ -111,9 +111,14 @@ struct ibs_ctx {
   int refine_hist_len = 0;
   long long refine_stats[4] = {0, 0, 0, 0};      // evaluations, forward sweeps, rounds, rounds enqueued
   bool refine_pending = false;                   // the last call's output kernel may still be running (device-pointer call)
-  // the device-resident mode-row tables last checked by geo_rows_fit (pointers + counts) and the verdict
+  // the device-resident mode-row tables last checked by geo_rows_fit (pointers + counts) and the verdict: a few entries, oldest
+  // replaced (a driver alternating between table sets does not pay the copy-back every call).  The key is addresses and sizes: a
+  // caller that REUSES device memory for other rows must say so (option "forget_rows": ibs_amd does when it uploads a table set)
   struct RowsSeen { const void* r1 = nullptr; const void* r2 = nullptr; const void* xn = nullptr; const void* xnq = nullptr;
-                    int n1 = 0, n2 = 0, mn = 0, mnq = 0; double d1 = 0, d2 = 0; int verdict = 0; } rows_seen;
+                    int n1 = 0, n2 = 0, mn = 0, mnq = 0; double d1 = 0, d2 = 0; int verdict = 0; };
+  static constexpr int kRowsSeen = 4;
+  RowsSeen rows_seen[kRowsSeen];
+  int rows_seen_next = 0;
 };
 
 namespace {
@@ -195,6 +200,11 @@ struct HostStage {
   size_t in_lo = ~size_t(0), in_hi = 0, out_lo = ~size_t(0), out_hi = 0;
   struct Piece { void* dst; size_t off, bytes; };
   std::vector<Piece> outs;
+  bool in_flight = false;      // flush_in() ran and flush_out() has not: the pinned mirror / arena are still being read by the stream
+  // (an early error return between the two must not leave that copy running while the next call refills the mirror)
+  ~HostStage() { if (in_flight) (void)hipStreamSynchronize(c->stream); }
+  HostStage(const HostStage&) = delete;
+  HostStage& operator=(const HostStage&) = delete;
   HostStage(ibs_ctx* c_, size_t need) : c(c_) {
     if (need > kMaxBytes) return;
     if (c->hs_bytes < need) {
@@ -216,6 +226,7 @@ struct HostStage {
   }
   hipError_t flush_in() {
     if (!on || in_hi <= in_lo) return hipSuccess;
+    in_flight = true;
     return hipMemcpyAsync(static_cast<char*>(c->ws) + in_lo, static_cast<char*>(c->hs) + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, c->stream);
   }
   hipError_t down(void* dst, const void* dev, size_t bytes) {
@@ -233,6 +244,7 @@ struct HostStage {
       if (e != hipSuccess) return e;
     }
     hipError_t e = hipStreamSynchronize(c->stream);
+    in_flight = false;
     if (e != hipSuccess) return e;
     for (const Piece& p : outs) std::memcpy(p.dst, static_cast<char*>(c->hs) + p.off, p.bytes);
     return hipSuccess;
@@ -642,6 +654,7 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   else if (n == "f32_lam") c->opt.f32_lam = reset ? c->opt_created.f32_lam : (int)value;
   else if (n == "reclose") c->opt.reclose = reset ? c->opt_created.reclose : (int)value;
   else if (n == "sigma0") c->opt.sigma0 = reset ? c->opt_created.sigma0 : value;
+  else if (n == "forget_rows") { for (auto& e : c->rows_seen) e = ibs_ctx::RowsSeen{}; }      // (an action, not a setting)
   else if (n == "refine_tangent") c->opt.refine_tangent = reset ? c->opt_created.refine_tangent : (int)value;
   else if (n == "chain_w1") c->opt.chain_w1 = reset ? c->opt_created.chain_w1 : value;
   else if (n == "chain_w2") c->opt.chain_w2 = reset ? c->opt_created.chain_w2 : value;
@@ -1217,9 +1230,11 @@ static int geo_rows_fit(ibs_ctx* ctx, int mnmax, int mnmax_nyq, const double* xn
     const int b = geo_rows_fit_host(rows_nyq, nrows_nyq, mnmax_nyq, xn_nyq, dn_nyq, "rows_nyq");
     return b < 0 ? b : a;            // (only the first list feeds the (P, Q) tables; the second one's pair tables hold one entry per mode)
   }
-  auto& c = ctx->rows_seen;
-  if (c.r1 == rows_mn && c.r2 == rows_nyq && c.xn == xn && c.xnq == xn_nyq && c.n1 == nrows_mn && c.n2 == nrows_nyq && c.mn == mnmax &&
-      c.mnq == mnmax_nyq && c.d1 == dn_mn && c.d2 == dn_nyq) return c.verdict;
+  for (const auto& c : ctx->rows_seen)
+    if (c.r1 == rows_mn && c.r2 == rows_nyq && c.xn == xn && c.xnq == xn_nyq && c.n1 == nrows_mn && c.n2 == nrows_nyq && c.mn == mnmax &&
+        c.mnq == mnmax_nyq && c.d1 == dn_mn && c.d2 == dn_nyq && c.r1) return c.verdict;
+  auto& c = ctx->rows_seen[ctx->rows_seen_next];
+  ctx->rows_seen_next = (ctx->rows_seen_next + 1) % ibs_ctx::kRowsSeen;
   std::vector<int32_t> r1((size_t)2 * nrows_mn), r2((size_t)2 * nrows_nyq);
   std::vector<double> x1(mnmax), x2(mnmax_nyq);
   HIPCHK(hipMemcpyAsync(r1.data(), rows_mn, r1.size() * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -4,8 +4,9 @@
 //
 // One wavefront per system, everything in DIVISION form on the original rows (no scaled rows, nothing register-resident):
 //   1. bounds        lam_max <= max c/f (Gershgorin), lam_max >= max d/f (unit vectors), ||A||; data checks
-//   2. eigenvalue    64-way multisection on division-form Sturm counts (ibs_wave.hpp: count_above_div / multisect_division --
-//                    the recurrence of SURVEY Appendix A / LAPACK dstebz), ~9 passes from the Gershgorin bracket to eps ||A||
+//   2. eigenvalue    64-way multisection on division-form Sturm counts (ibs_wave.hpp: multisect; the recurrence of SURVEY Appendix A /
+//                    LAPACK dstebz, the rows passed through LDS in chunks: count_above_chunked), ~9 passes from the Gershgorin
+//                    bracket to eps ||A||
 //   3. eigenvector   twisted factorisation N_k D_k N_k^T of T - lam F (the getvec step of MRRR): forward pivots D+ (lane 0) and
 //                    backward pivots D- (lane 1) in one serial pass, gamma_r = D+_r + D-_r - (d_r - lam f_r) in parallel, twist row
 //                    k = argmin |gamma_r|, then z_k = 1, z_{r-1} = -e_r z_r / D+_{r-1} downwards (lane 0) and
@@ -34,6 +35,44 @@ struct SrcLong {
   }
 };
 
+// Division-form count of one system at 64 shifts (lane L = shift L) with the rows passed through LDS in chunks of kLongChunk: the 64
+// lanes form d_r, e_r^2, f_r of a chunk together (coalesced loads), then every lane runs the recurrence over the chunk from LDS (all
+// lanes read the same address: broadcast) -- the serial chain never waits for global memory (read per row it cost one exposed memory
+// latency per four rows: 27 ms per system at N = 8,193; so: 3).  Same arithmetic as count_above_rows (ibs_wave.hpp).
+constexpr int kLongChunk = 1024;
+template <class Src>
+__device__ __forceinline__ int count_above_chunked(const Src& src, int n, double ih2, double sig, double* lds, int lane) {
+  constexpr double pivmin = 2.2250738585072014e-292;
+  double* rd = lds; double* re2 = lds + kLongChunk; double* rf = lds + 2 * kLongChunk;
+  int cnt = 0;
+  double q = 1.0;
+  for (int r0 = 0; r0 < n; r0 += kLongChunk) {
+    const int m = n - r0 < kLongChunk ? n - r0 : kLongChunk;
+    for (int i = lane; i < m; i += kWave) {
+      const int r = r0 + i;
+      const double e_lo = src.e(r, ih2), e_hi = src.e(r + 1, ih2);
+      rd[i] = src.c(r + 1) - (e_lo + e_hi); re2[i] = e_lo * e_lo; rf[i] = src.f(r + 1);
+    }
+    wave_lds_sync();
+    int i = 0;
+    if (r0 == 0) {
+      q = xfma(-sig, rf[0], rd[0]);
+      q = xabs(q) < pivmin ? -pivmin : q;
+      cnt += q > 0.0 ? 1 : 0;
+      i = 1;
+    }
+#pragma unroll 8
+    for (; i < m; ++i) {
+      const double a = xfma(-sig, rf[i], rd[i]);
+      q = xfma(-re2[i], fast_rcp(q), a);
+      q = xabs(q) < pivmin ? -pivmin : q;
+      cnt += q > 0.0 ? 1 : 0;
+    }
+    wave_lds_sync();
+  }
+  return cnt;
+}
+
 __device__ __forceinline__ void long_fence() {      // stores of two lanes, read by all lanes of the same wave afterwards
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __builtin_amdgcn_wave_barrier();
@@ -42,7 +81,7 @@ __device__ __forceinline__ void long_fence() {      // stores of two lanes, read
 
 template <typename TI, bool HAS_GH>
 __device__ __forceinline__ void solve_long_one(const SrcLong<TI, HAS_GH>& src, int N, double h, long sys, double* work, TI* lam_out,
-                                               TI* gam_out, TI* X_out, TI* dX_out, int* info_out) {
+                                               TI* gam_out, TI* X_out, TI* dX_out, int* info_out, double* lds) {
   constexpr double pivmin = 2.2250738585072014e-292;
   const int lane = threadIdx.x & 63;
   const int n = N - 2;
@@ -71,7 +110,8 @@ __device__ __forceinline__ void solve_long_one(const SrcLong<TI, HAS_GH>& src, i
     lam = __builtin_nan("");
   } else {
     // ---- 2. eigenvalue
-    if (!multisect_division<double>(src, N, h, lo, hi, normA, lane, lam, passes)) status = 1;
+    if (!multisect<double>([&](double sig) { return count_above_chunked(src, n, ih2, sig, lds, lane); }, lo, hi, normA, 2.0, lane, lam, passes))
+      status = 1;
   }
   double gam = __builtin_nan("");
   if (want_vec && status == 0) {
@@ -164,14 +204,15 @@ template <typename TI>
 __global__ void __launch_bounds__(64) k_solve_gcf_long(long n_sys, int N, double h, const TI* __restrict__ g, const TI* __restrict__ c,
                                                        const TI* __restrict__ f, const TI* __restrict__ gh, long ld, TI* lam_out,
                                                        TI* gam_out, TI* X_out, TI* dX_out, int* info_out, double* work) {
+  __shared__ double lds[3 * kLongChunk];
   double* my = work + (size_t)blockIdx.x * 3 * (size_t)N;
   for (long sys = blockIdx.x; sys < n_sys; sys += gridDim.x) {
     if (gh) {
       const SrcLong<TI, true> src{g + sys * ld, c + sys * ld, f + sys * ld, gh + sys * ld};
-      solve_long_one<TI, true>(src, N, h, sys, my, lam_out, gam_out, X_out, dX_out, info_out);
+      solve_long_one<TI, true>(src, N, h, sys, my, lam_out, gam_out, X_out, dX_out, info_out, lds);
     } else {
       const SrcLong<TI, false> src{g + sys * ld, c + sys * ld, f + sys * ld, nullptr};
-      solve_long_one<TI, false>(src, N, h, sys, my, lam_out, gam_out, X_out, dX_out, info_out);
+      solve_long_one<TI, false>(src, N, h, sys, my, lam_out, gam_out, X_out, dX_out, info_out, lds);
     }
     long_fence();                                           // (the workspace is reused by this wave's next system)
   }
@@ -182,10 +223,11 @@ __global__ void __launch_bounds__(64) k_solve_gcf_long(long n_sys, int N, double
 __global__ void __launch_bounds__(64) k_sturm_count_long(long n_sys, int N, double h, const double* __restrict__ g,
                                                          const double* __restrict__ c, const double* __restrict__ f, long ld,
                                                          const double* __restrict__ shift, int* count_out) {
+  __shared__ double lds[3 * kLongChunk];
   const double ih2 = 1.0 / (h * h);
   for (long sys = blockIdx.x; sys < n_sys; sys += gridDim.x) {
     const SrcLong<double, false> src{g + sys * ld, c + sys * ld, f + sys * ld, nullptr};
-    const int cnt = count_above_div<double>(src, N, ih2, shift[sys]);
+    const int cnt = count_above_chunked(src, N - 2, ih2, shift[sys], lds, (int)(threadIdx.x & 63));
     if ((threadIdx.x & 63) == 0) count_out[sys] = cnt;
   }
 }

@@ -377,6 +377,9 @@ class Context:
         if key not in cache:
             host = [tables.xm, tables.xn, tables.xm_nyq, tables.xn_nyq, tables.tab_mn, tables.tab_nyq, tables.scal]
             cache[key] = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in host + [tables.rows_mn, tables.rows_nyq]]
+            # (a caching allocator may hand these rows the addresses of a freed table set: the library's verdict on device-resident
+            #  rows is keyed by address and size)
+            self.set_option("forget_rows", 1)
         return cache[key]
 
     def upload_tables_rows(self, tables, device, r0, r1):
@@ -391,6 +394,7 @@ class Context:
             e = lambda a: torch.empty(a.shape, dtype=torch.float64, device=device)
             cache[key] = [t(tables.xm), t(tables.xn), t(tables.xm_nyq), t(tables.xn_nyq), e(tables.tab_mn), e(tables.tab_nyq),
                           e(tables.scal), t(tables.rows_mn), t(tables.rows_nyq)]
+            self.set_option("forget_rows", 1)
         dev = cache[key]
         pinned = getattr(tables, "_pinned", {})
         for k, name in ((4, "tab_mn"), (5, "tab_nyq"), (6, "scal")):

@@ -119,6 +119,7 @@ int ibs_comm_destroy(ibs_ctx* ctx);
  * disagrees with its Rayleigh polish is closed again in division form, the default; 2 = only marked with status bit 3 and the distance
  * in bits 5..10; 0 = off, i.e. the round-5 results), "sigma0" (any finite value: solves that return lam and info flag lam_max >= sigma0
  * with the informational status bit 4 -- the nearest-sigma report of the drop-in, utils.py:1597; NaN = off, the default),
+ * "forget_rows" (an action: drop the remembered verdicts on device-resident mode rows, see ibs_fieldline_geometry_f64),
  * "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
  * staged in LDS, 1, or read from global memory by the sums, 0: two blocks per CU instead of one at N = 969; -1 = by batch size);
  * value 0 = automatic (refine_tangent, gcf_direct: -1); value NaN = back to what ibs_create() read from the environment
@@ -247,7 +248,9 @@ int ibs_hf_grad_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, const double* X, con
  *   (else IBS_ERR_ARG).  The row kernels hold at most 64 pair indices about a row's centre -- the mode with n = 0 if the
  *   row has one, else its first mode: rows of up to 129 modes n = -64 dn .. 64 dn, or up to 65 modes otherwise; tables
  *   with a longer row in rows_mn are valid and run on the one-sincos-per-mode kernel (split such rows to stay on the fast
- *   path: ibs_amd.geometry.mode_rows does).  Device-resident rows are copied back and checked once per table set.
+ *   path: ibs_amd.geometry.mode_rows does).  Rows of one list must not overlap (IBS_ERR_ARG).  Device-resident rows are copied back
+ *   and checked once per table set, the verdict kept under the rows' ADDRESSES and sizes (four sets): a caller that reuses that device
+ *   memory for other rows calls ibs_set_option(ctx, "forget_rows", 1) first.
  * The first seven planes of geo and dPdrho are exactly the inputs of ibs_gamma_scan_f64. */
 int ibs_fieldline_geometry_f64(ibs_ctx* ctx, int32_t n_surf, int32_t mnmax, int32_t mnmax_nyq, const double* xm,
                                const double* xn, const double* xm_nyq, const double* xn_nyq, const double* tab_mn,

@@ -49,3 +49,24 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.ibs_create(None, 0) < 0
     assert lib.ibs_solve_gcf_f64(None, 1, 513, 0.1, None, None, None, 513, None, None, None, None, None, 0) < 0
     assert b"null" in lib.ibs_last_error()
+
+
+def test_rccl_stand_in_compiles_as_strict_c():
+    """tests/cabi/fake_rccl.c (test infrastructure of the multi-rank GPU tests): builds with -Wall -Wextra -Werror against the HIP
+    headers and exports RCCL's five entry points the library binds (ibs_api.hip: ibs_comm_load)"""
+    import shutil
+    import subprocess
+    import tempfile
+    import pytest
+    inc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")
+    if shutil.which("gcc") is None or not os.path.exists(os.path.join(inc, "hip", "hip_runtime_api.h")):
+        pytest.skip("no gcc / HIP headers")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "libfake_rccl.so")
+        r = subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-I", inc, os.path.join(root, "tests", "cabi", "fake_rccl.c"),
+                            "-o", so, "-lrt", "-lpthread"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+        for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString"):
+            assert " T " + name in syms, name
