@@ -510,9 +510,25 @@ def sturm_sweep(ctx, device, n_sys, reps=5):
     ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
     bytes_per = (3 * N + 1) * 8 + 4
     kern, waves = ctx.last_launch()
+    # the same counts in DIVISION form (lanes as systems, rows through an LDS transpose: exact for a pencil a few ulp away, any N):
+    # what the 10^6-system tests certify with; the prefix-product sweep above is the bandwidth kernel
+    cnt_p = ctx.sturm_count(h, g, c, f, sh)
+    cnt_d = ctx.sturm_count(h, g, c, f, sh, exact=True)
+    kern_d = ctx.last_launch()[0]
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        ctx.sturm_count(h, g, c, f, sh, exact=True)
+        b.record()
+    torch.cuda.synchronize()
+    ms_d = float(np.median([a.elapsed_time(b) for a, b in evs]))
     return dict(workload="one Sturm-count sweep per system, %d random systems, N_zeta=512, f64" % n_sys,
                 sweeps_per_s=n_sys / (ms * 1e-3), ms_per_launch=ms,
-                roofline=hbm_roofline(n_sys * bytes_per, ms, "hbm", kern, waves, bytes_per_sweep=bytes_per))
+                roofline=hbm_roofline(n_sys * bytes_per, ms, "hbm", kern, waves, bytes_per_sweep=bytes_per),
+                division_form=dict(kernel=kern_d, ms_per_launch=ms_d, gb_per_s=n_sys * bytes_per / (ms_d * 1e6),
+                                   frac_of_8_tb_s=n_sys * bytes_per / (ms_d * 1e6) / 8000.0,
+                                   counts_equal_the_sweeps=bool(torch.equal(cnt_p, cnt_d))))
 
 
 def warm_rescan(ctx, device, h, geo7, dP_d, th0_d, reps=20):

@@ -67,6 +67,7 @@ struct ibs_options {
   int pack_mode = 0;      // hand-off of the fused scan + argmax: 1 = write-through + sc1 loads, 2 = release / acquire fences
   int f32_lam = 0;        // FP32 eigenvalue-only requests: 0 = by grid size, 1 = all-FP32 iteration + FP64 certificate, 2 = FP32 in HBM + FP64 solver
   double sigma0 = std::numeric_limits<double>::quiet_NaN();   // not NaN: solves that return lam AND info flag lam_max >= sigma0 (informational status bit 4: utils.py:1597 would have taken the eigenpair nearest sigma0)
+  int sturm_form = 0;     // ibs_sturm_count_f64: 0 = by size (see there), 1 = prefix-product sweep (N <= 2050), 2 = division form, lanes as systems, 3 = division form, one wave per system
   int reclose = 1;        // FP64 raw systems: 1 = a solve whose closing bracket fails its consistency checks is re-closed in division form, 2 = only marked, 0 = off
   int refine_tangent = -1; // refinement: alpha-tangent of a point staged in LDS (1) or read from global memory in the sums (0); -1 = by batch size
   double chain_w1 = 0.25, chain_w2 = 1.0;   // relative widths of the chain's warm starts
@@ -653,6 +654,7 @@ int ibs_set_option(ibs_ctx* c, const char* name, double value) {
   else if (n == "pack_mode") c->opt.pack_mode = reset ? c->opt_created.pack_mode : (int)value;
   else if (n == "f32_lam") c->opt.f32_lam = reset ? c->opt_created.f32_lam : (int)value;
   else if (n == "reclose") c->opt.reclose = reset ? c->opt_created.reclose : (int)value;
+  else if (n == "sturm_form") c->opt.sturm_form = reset ? c->opt_created.sturm_form : (int)value;
   else if (n == "sigma0") c->opt.sigma0 = reset ? c->opt_created.sigma0 : value;
   else if (n == "forget_rows") { for (auto& e : c->rows_seen) e = ibs_ctx::RowsSeen{}; }      // (an action, not a setting)
   else if (n == "refine_tangent") c->opt.refine_tangent = reset ? c->opt_created.refine_tangent : (int)value;
@@ -1372,9 +1374,14 @@ int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const 
   if (N < 66 || N > ibs::kMaxLongN) return fail(IBS_ERR_UNSUPPORTED, "N=%d outside [66, %d]", N, ibs::kMaxLongN);
   if (!(h > 0)) return fail(IBS_ERR_ARG, "h must be > 0");
   if (n_sys == 0) return 0;
-  const bool lng = is_long(N);                 // (grids beyond 2050 points: division-form count, one wave per system: ibs_long.hip)
+  // forms: the prefix-product sweep (one wave per system, N <= 2050: the bandwidth kernel of rounds 1-5), and two division-form
+  // kernels for any N (ibs_long.hip): lanes as systems (batches) and one wave per system (a handful of systems on a long grid)
+  int form = ctx->opt.sturm_form;
+  if (form == 0) form = is_long(N) ? (n_sys >= 64 ? 2 : 3) : 1;
+  if (form == 1 && is_long(N)) form = 2;
+  const bool lng = form != 1;
   const int M = lng ? 1 : rows_per_lane(N);
-  auto fn = lng ? &ibs::launch_sturm_long : ibs::launch_table().sturm_f64[M];
+  auto fn = form == 2 ? &ibs::launch_sturm_div : (form == 3 ? &ibs::launch_sturm_long : ibs::launch_table().sturm_f64[M]);
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
   ON_DEVICE(ctx);
   const size_t per_wave = (size_t)N * sizeof(double);

@@ -58,6 +58,7 @@ struct LongGcfArgs {
 };
 hipError_t launch_gcf_long(const LongGcfArgs& a, hipStream_t st);
 hipError_t launch_sturm_long(const SturmArgs<double>& a, hipStream_t st);
+hipError_t launch_sturm_div(const SturmArgs<double>& a, hipStream_t st);     // lanes as systems, division form, any N
 template <typename T> struct ScanArgs;
 hipError_t launch_assemble_long(const ScanArgs<double>& a, double* g, double* c, double* f, double* gt, double* ct, double* ft, hipStream_t st);
 

@@ -232,6 +232,66 @@ __global__ void __launch_bounds__(64) k_sturm_count_long(long n_sys, int N, doub
   }
 }
 
+// Division-form Sturm count with LANES AS SYSTEMS (round 6): every lane walks its own system's rows serially -- q_r = (d_r - sig f_r) -
+// e_r^2 / q_{r-1}, IEEE division, pivmin guard: exact for a pencil a few ulp away, any N (the prefix-product sweep k_sturm_count is
+// exact only for ~N eps ||A||, ~N^2 eps ||A|| on iid-random coefficients) -- while the rows reach it through an LDS transpose: per chunk
+// of 16 grid points the wave loads, for 64 systems, 16 consecutive values of g, c, f per system (four systems per load instruction:
+// 128-byte segments), writes them to LDS as [system][point] and reads them back one system per lane.  The next chunk's 48 loads are in
+// flight while the current one is worked on; a chain of 16 dependent divisions per chunk is ~1.5k clocks per 24.6 KB and SIMD, five
+// times the HBM rate: the kernel is bound by the memory system, like the sweep it certifies.
+constexpr int kDivChunk = 16, kDivPitch = kDivChunk + 1, kDivWaves = 2;      // (2 waves per block: 52 KB of LDS, three blocks per CU)
+__global__ void __launch_bounds__(64 * kDivWaves) k_sturm_count_div(long n_sys, int N, double h, const double* __restrict__ g,
+                                                         const double* __restrict__ c, const double* __restrict__ f, long ld,
+                                                         const double* __restrict__ shift, int* count_out) {
+  constexpr double pivmin = 2.2250738585072014e-292;
+  __shared__ double tile[kDivWaves][3][kWave * kDivPitch];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long base = ((long)blockIdx.x * kDivWaves + wave) * kWave;    // first system of this wave
+  if (base >= n_sys) return;                                           // (wave-uniform; no block-level barrier below)
+  const int sub = lane >> 4, rr = lane & 15;                           // loader role: system 4 k + sub, point rr of the chunk
+  const long mine = base + lane < n_sys ? base + lane : n_sys - 1;     // worker role: this lane's system
+  const double sig = shift[mine];
+  const double ih2 = 1.0 / (h * h);
+  const int n = N - 2;
+  double* tg = tile[wave][0]; double* tc = tile[wave][1]; double* tf = tile[wave][2];
+  double vg[16], vc[16], vf[16];
+  auto load_chunk = [&](int j0) {                                      // grid points j0 .. j0 + 15: g[j + 1], c[j], f[j]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      long sy = base + 4 * k + sub; sy = sy < n_sys ? sy : n_sys - 1;
+      int j = j0 + rr; j = j <= N - 2 ? j : N - 2;
+      const long o = sy * ld + j;
+      vg[k] = g[o + 1]; vc[k] = c[o]; vf[k] = f[o];
+    }
+  };
+  const double gl = g[mine * ld], gc0 = g[mine * ld + 1];
+  double gm1 = gl, g0 = gc0, q = 1.0;
+  int cnt = 0;
+  load_chunk(1);
+  for (int j0 = 1; j0 <= n; j0 += kDivChunk) {
+    wave_lds_sync();                                                   // (the previous chunk has been consumed)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int o = (4 * k + sub) * kDivPitch + rr;
+      tg[o] = vg[k]; tc[o] = vc[k]; tf[o] = vf[k];
+    }
+    wave_lds_sync();
+    if (j0 + kDivChunk <= n) load_chunk(j0 + kDivChunk);               // in flight during the recurrence below
+    const int m = n - j0 + 1 < kDivChunk ? n - j0 + 1 : kDivChunk;
+#pragma unroll 4
+    for (int i = 0; i < m; ++i) {
+      const double gp1 = tg[lane * kDivPitch + i], cj = tc[lane * kDivPitch + i], fj = tf[lane * kDivPitch + i];
+      const double e_lo = 0.5 * (gm1 + g0) * ih2, e_hi = 0.5 * (g0 + gp1) * ih2;       // utils.py:1574-1576
+      const double a = xfma(-sig, fj, cj - (e_lo + e_hi));                             // utils.py:1584-1592
+      q = (j0 + i == 1) ? a : a - (e_lo * e_lo) / q;
+      q = xabs(q) < pivmin ? -pivmin : q;
+      cnt += q > 0.0 ? 1 : 0;
+      gm1 = g0; g0 = gp1;
+    }
+  }
+  if (base + lane < n_sys) count_out[base + lane] = cnt;
+}
+
 // (g, c, f) of every (line, theta0) system of a geometry-fed scan, and their theta0 tangents, written out as rows: the long-grid
 // form of the staging the scan kernels do in LDS -- the same expressions in the same order (k_gamma_scan, SrcGeo), i.e.
 // ball_scan.py:267-268 + utils.py:1560-1562 and utils.py:1669-1673.
@@ -282,6 +342,13 @@ hipError_t launch_sturm_long(const SturmArgs<double>& a, hipStream_t st) {
   const unsigned grid = (unsigned)(a.n_sys < cap ? a.n_sys : cap);
   hipLaunchKernelGGL(k_sturm_count_long, dim3(grid), dim3(64), 0, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld, a.shift, a.count);
   note_launch(grid, 64, "ibs::k_sturm_count_long");
+  return hipGetLastError();
+}
+
+hipError_t launch_sturm_div(const SturmArgs<double>& a, hipStream_t st) {
+  const long per = 64 * kDivWaves, nblk = (a.n_sys + per - 1) / per;
+  hipLaunchKernelGGL(k_sturm_count_div, dim3((unsigned)nblk), dim3((unsigned)per), 0, st, a.n_sys, a.N, a.h, a.g, a.c, a.f, a.ld, a.shift, a.count);
+  note_launch(nblk, (int)per, "ibs::k_sturm_count_div");
   return hipGetLastError();
 }
 
