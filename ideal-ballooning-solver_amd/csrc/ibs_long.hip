@@ -40,6 +40,7 @@ struct SrcLong {
 // lanes read the same address: broadcast) -- the serial chain never waits for global memory (read per row it cost one exposed memory
 // latency per four rows: 27 ms per system at N = 8,193; so: 3).  Same arithmetic as count_above_rows (ibs_wave.hpp).
 constexpr int kLongChunk = 1024;
+constexpr int kVecChunk = kLongChunk / 2;      // pivots / eigenvector: two directions x (two operands + one result) in the same 24 KB
 template <class Src>
 __device__ __forceinline__ int count_above_chunked(const Src& src, int n, double ih2, double sig, double* lds, int lane) {
   constexpr double pivmin = 2.2250738585072014e-292;
@@ -116,19 +117,52 @@ __device__ __forceinline__ void solve_long_one(const SrcLong<TI, HAS_GH>& src, i
   double gam = __builtin_nan("");
   if (want_vec && status == 0) {
     double* Dp = work; double* Dm = work + N; double* A = work + 2 * (size_t)N;     // A[r] = d_r - lam f_r, later z_r
-    // ---- 3a. pivots: lane 0 walks the rows upwards (D+), lane 1 downwards (D-)
-    if (lane < 2) {
-      const bool fw = lane == 0;
+    // ---- 3a. pivots: lane 0 walks the rows upwards (D+), lane 1 downwards (D-).  The rows pass through LDS in chunks of kVecChunk
+    // per direction: all 64 lanes form a_r and e_r^2 (coalesced loads), lanes 0 / 1 run the two recurrences from LDS eight rows at a
+    // time (operands in registers before the dependent chain starts), all lanes write the pivots out (coalesced).  Read and written
+    // row by row from the two lanes the chain waited for global memory at every step: 400 cycles per row, as long as the whole
+    // multisection.
+    {
+      const int dsel = lane & 1;
+      const double* xa = lds + dsel * 3 * kVecChunk; const double* xe = xa + kVecChunk; double* xq = lds + dsel * 3 * kVecChunk + 2 * kVecChunk;
       double q = 1.0;
-      for (int s = 0; s < n; ++s) {
-        const int r = fw ? s : n - 1 - s;
-        const int j = r + 1;
-        const double e_lo = src.e(r, ih2), e_hi = src.e(j, ih2);
-        const double a = xfma(-lam, src.f(j), src.c(j) - (e_lo + e_hi));
-        const double ec = fw ? e_lo : e_hi;                 // the coupling to the row this lane comes from
-        q = s == 0 ? a : a - (ec * ec) / q;
-        q = xabs(q) < pivmin ? -pivmin : q;
-        if (fw) { Dp[r] = q; A[r] = a; } else Dm[r] = q;
+      for (int c0 = 0; c0 < n; c0 += kVecChunk) {
+        const int m = n - c0 < kVecChunk ? n - c0 : kVecChunk;
+        for (int i = lane; i < m; i += kWave) {
+          {
+            const int r = c0 + i, j = r + 1;
+            const double e_lo = src.e(r, ih2), e_hi = src.e(j, ih2);
+            lds[i] = xfma(-lam, src.f(j), src.c(j) - (e_lo + e_hi)); lds[kVecChunk + i] = e_lo * e_lo;
+          }
+          {
+            const int r = n - 1 - (c0 + i), j = r + 1;
+            const double e_lo = src.e(r, ih2), e_hi = src.e(j, ih2);
+            lds[3 * kVecChunk + i] = xfma(-lam, src.f(j), src.c(j) - (e_lo + e_hi)); lds[4 * kVecChunk + i] = e_hi * e_hi;
+          }
+        }
+        wave_lds_sync();
+        if (lane < 2) {
+          for (int i0 = 0; i0 < m; i0 += 8) {
+            double av[8], ev[8], qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u < m ? i0 + u : m - 1; av[u] = xa[i]; ev[u] = xe[i]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (i0 + u < m) {
+                q = (c0 + i0 + u == 0) ? av[u] : xfma(-ev[u], fast_rcp(q), av[u]);      // (the arithmetic of the counts)
+                q = xabs(q) < pivmin ? -pivmin : q;
+              }
+              qv[u] = q;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u < m) xq[i0 + u] = qv[u];
+          }
+        }
+        wave_lds_sync();
+        for (int i = lane; i < m; i += kWave) {
+          Dp[c0 + i] = lds[2 * kVecChunk + i]; A[c0 + i] = lds[i]; Dm[n - 1 - (c0 + i)] = lds[5 * kVecChunk + i];
+        }
+        wave_lds_sync();
       }
     }
     long_fence();
@@ -147,19 +181,44 @@ __device__ __forceinline__ void solve_long_one(const SrcLong<TI, HAS_GH>& src, i
     }
     const int k = __builtin_amdgcn_readfirstlane(bi);
     long_fence();                                           // (A is overwritten by z below: every lane has read it)
-    // ---- 3c. eigenvector from the twist row outwards
-    if (lane < 2) {
-      const bool dn = lane == 0;
+    // ---- 3c. eigenvector from the twist row outwards (staged like 3a: lane 0 downwards from row k, lane 1 upwards)
+    //   downwards: z_t = -e_{t+1} z_{t+1} / D+_t;  upwards: z_t = -e_t z_{t-1} / D-_t
+    {
+      const int dsel = lane & 1;
+      const double* xe = lds + dsel * 3 * kVecChunk; double* xz = lds + dsel * 3 * kVecChunk + 2 * kVecChunk;
+      const int steps_dn = k, steps_up = n - 1 - k;
+      const int smax = steps_dn > steps_up ? steps_dn : steps_up;
       double z = 1.0;
-      if (dn) A[k] = 1.0;
-      const int steps = dn ? k : n - 1 - k;
-      for (int s = 0; s < steps; ++s) {
-        const int r = dn ? k - s : k + s;                   // row whose z is known
-        // downwards: z_{r-1} = -e_r z_r / D+_{r-1};  upwards: z_{r+1} = -e_{r+1} z_r / D-_{r+1}
-        const double ec = dn ? src.e(r, ih2) : src.e(r + 1, ih2);
-        const int t = dn ? r - 1 : r + 1;
-        z = -(ec * z) / (dn ? Dp[t] : Dm[t]);
-        A[t] = z;
+      if (lane == 0) A[k] = 1.0;
+      for (int c0 = 0; c0 < smax; c0 += kVecChunk) {
+        const int md = steps_dn - c0 < 0 ? 0 : (steps_dn - c0 < kVecChunk ? steps_dn - c0 : kVecChunk);
+        const int mu = steps_up - c0 < 0 ? 0 : (steps_up - c0 < kVecChunk ? steps_up - c0 : kVecChunk);
+        for (int i = lane; i < kVecChunk; i += kWave) {
+          if (i < md) { const int t = k - 1 - (c0 + i); lds[i] = -src.e(t + 1, ih2) / Dp[t]; }        // z_t / z_{t+1}: formed by all lanes,
+          if (i < mu) { const int t = k + 1 + (c0 + i); lds[3 * kVecChunk + i] = -src.e(t, ih2) / Dm[t]; } // the chain is one product per row
+        }
+        wave_lds_sync();
+        if (lane < 2) {
+          const int m = dsel ? mu : md;
+          for (int i0 = 0; i0 < m; i0 += 8) {
+            double rv[8], zv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rv[u] = xe[i0 + u < m ? i0 + u : m - 1];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (i0 + u < m) z *= rv[u];
+              zv[u] = z;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u < m) xz[i0 + u] = zv[u];
+          }
+        }
+        wave_lds_sync();
+        for (int i = lane; i < kVecChunk; i += kWave) {
+          if (i < md) A[k - 1 - (c0 + i)] = lds[2 * kVecChunk + i];
+          if (i < mu) A[k + 1 + (c0 + i)] = lds[5 * kVecChunk + i];
+        }
+        wave_lds_sync();
       }
     }
     long_fence();

@@ -162,7 +162,7 @@ def test_bench_two_ranks_with_the_librarys_own_gathers(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------- grids beyond 2050 points
-@pytest.mark.parametrize("N", [2561, 4097, 8193])
+@pytest.mark.parametrize("N", [2561, 4097, 8193, 65537])
 def test_large_grid_salpha_against_the_oracle(ctx, N):
     """utils.py:1556-1624 accepts any grid length and the reference's own rule N = 2 mpol ntor 4 + 1 (ball_scan.py:201-208) exceeds
     2050 points from mpol ntor > 256 on (N = 2561 is mpol = 20, ntor = 16).  Beyond the register-resident kernels the library runs the

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Round 6: the long-grid path (csrc/ibs_long.hip) -- s-alpha systems at N = 2,561 ... 16,385: latency of one system and rate of a
+"""Round 6: the long-grid path (csrc/ibs_long.hip) -- s-alpha systems at N = 2,561 ... 65,537: latency of one system and rate of a
 batch, growth rate wanted / eigenvalue only; the C oracle on one core beside it.      python tools/bench_long.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, ibs_amd
 dev = torch.device("cuda", 0); ctx = ibs_amd.Context(0)
-for N in (2561, 4097, 8193, 16385):
+for N in (2561, 4097, 8193, 16385, 65537):
     th = np.linspace(-4 * np.pi, 4 * np.pi, N); h = float(th[1] - th[0])
     rng = np.random.default_rng(N)
     for n in (1, 2048):
