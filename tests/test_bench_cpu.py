@@ -125,6 +125,20 @@ def test_the_stdout_line_fits_the_drivers_capture():
     o5 = json.loads(line5)
     assert len(line5) < 6000 and "dropped_for_length" not in o5 and o5["value"] == full5["value"]
     assert len(o5["c5_matrix"]["rows"]) == 24 and any("k_solve_gcf_direct" in k for k in o5["c5_matrix"]["kernels"])
+    # round 6 (profiles/r06a_bench_detail.json: the per-row accuracy fields of c5_matrix, the division-form count beside the sweep) and
+    # the 2-rank run through the stand-in for librccl (three gather modes with two ranks in the collective, the native sharded leg)
+    full6 = json.load(open(os.path.join(ROOT, "profiles", "r06a_bench_detail.json")))
+    line6 = bench.compact_line(full6)
+    o6 = json.loads(line6)
+    assert len(line6) < 6000 and "dropped_for_length" not in o6 and o6["value"] == full6["value"]
+    assert o6["roofline"]["counters"] == "pmc:r06a" and o6["cpu_baseline"]["value_1core"] > 0
+    rec6 = json.loads(open(os.path.join(ROOT, "profiles", "r06a_bench_line.json")).read())       # the line that run printed
+    assert {k: v for k, v in rec6.items() if k != "detail"} == {k: v for k, v in o6.items() if k != "detail"}
+    assert all(r["within_tolerance"] for r in full6["c5_matrix"]["rows"]) and full6["c5_matrix"]["f64_rows_outside_4N_eps"] == 0
+    two6 = json.load(open(os.path.join(ROOT, "profiles", "r06a_rehearsal_standin_2ranks.json")))
+    l26 = bench.compact_line(two6)
+    assert len(l26) < 6000 and set(json.loads(l26)["gather_modes"]) >= {"torch_in_stream", "native_in_stream", "native_overlapped"}
+    assert two6["gather_modes"]["native_in_stream"]["ranks_in_collective"] == 2 and two6["ncsx_c2_sharded_native"]["checks_passed"] is True
     # a 2-rank line (profiles/r04_rehearsal_2rank.json): the sharded legs keep their flags
     two = next(json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r04_rehearsal_2rank.json")) if l.startswith("{"))
     o2 = json.loads(bench.compact_line(two))
