@@ -492,10 +492,16 @@ int solve_gcf_impl(ibs_ctx* ctx, int64_t n_sys, int32_t N, T h, const T* g, cons
     auto fd = ibs::launch_table().gcf_direct_f64[M];
     if (!gh && (launch == table[M] || launch == fr) && fd && use_direct(ctx, N, (long)n_sys)) { launch = fd; per_wave = (size_t)ibs::lds_pitch(N) * sizeof(T); }
   }
-  int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
+  // the direct forms stage nothing: four waves per block, LDS only for the row X / dX are written from (ibs_kernels.hip: launch_gcf_direct,
+  // launch_gcf_f32lam_direct take the block shape from a.wpb)
+  bool direct_form;
+  if constexpr (sizeof(T) == 8) direct_form = !lng && launch == ibs::launch_table().gcf_direct_f64[M];
+  else direct_form = !lng && (launch == ibs::launch_table().gcf_direct_f32w[M] || launch == ibs::launch_table().gcf_direct_f32lam[M]);
+  if (direct_form) per_wave = (X || dX) ? (size_t)ibs::lds_pitch(N) * sizeof(double) : 0;
+  int wpb = per_wave ? (int)((size_t)ctx->lds_per_block / per_wave) : 4;
   if (wpb > 4) wpb = 4;
   // keep >= 3 blocks per CU resident when LDS allows it
-  while (wpb > 1 && (size_t)wpb * per_wave * 3 > (size_t)ctx->lds_per_block) --wpb;
+  while (!direct_form && wpb > 1 && (size_t)wpb * per_wave * 3 > (size_t)ctx->lds_per_block) --wpb;
   if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d needs %zu B of LDS per wave", N, per_wave);
   ibs::GcfArgs<T> a{};
   a.n_sys = n_sys; a.N = N; a.h = h; a.ld = ld; a.wpb = wpb;

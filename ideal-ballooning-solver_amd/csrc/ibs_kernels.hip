@@ -1736,7 +1736,7 @@ static hipError_t launch_gcf_wide(const GcfArgs<float>& a, hipStream_t st) {
 template <typename TI>
 static hipError_t launch_gcf_direct(const GcfArgs<TI>& a, hipStream_t st) {
   if constexpr (IBS_M >= IBS_DIRECT_MIN_M) {
-    const int wpb = 4;
+    const int wpb = a.wpb > 0 ? a.wpb : 4;
     const size_t lds = (a.X || a.dX) ? (size_t)wpb * lds_pitch(a.N) * sizeof(double) : 0;
     const long nblk = (a.n_sys + wpb - 1) / wpb;
     constexpr bool w2 = direct_two_waves(IBS_M, sizeof(TI) == 4);
@@ -1772,7 +1772,7 @@ static hipError_t launch_gcf_fix(const GcfArgs<TI>& a, hipStream_t st) {
 constexpr bool f32lam_two_waves(int M) { return M >= 21 && M <= 30; }   // (M = 32: 4.4 against 5.7e7 solves/s capped against free, rough family; tools/bench_f32lam.py)
 static hipError_t launch_gcf_f32lam_direct(const GcfArgs<float>& a, hipStream_t st) {
   if constexpr (IBS_M >= IBS_F32LAM_DIRECT_MIN_M) {
-    const int wpb = 4;
+    const int wpb = a.wpb > 0 ? a.wpb : 4;
     const long nblk = (a.n_sys + wpb - 1) / wpb;
     constexpr bool w2 = f32lam_two_waves(IBS_M);
     void (*kern)(long, int, float, const float*, const float*, const float*, long, float*, int*);

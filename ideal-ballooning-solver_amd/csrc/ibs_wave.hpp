@@ -729,6 +729,8 @@ struct WaveSolver {
     T acc = T(0);
     using SignWord = typename std::conditional<(M + 2 <= 32), unsigned, unsigned long long>::type;
     SignWord su = sign_word(zu_m1) >> 31, sw = 0;      // CNT: sign bits of (u_-1, u_0 .. u_{M-1}) and of (w_0 .. w_{M-1})
+    constexpr int MH = M / 2;                          // (M > 30: collected in two 32-bit words, rows below / from MH, joined after the loop)
+    unsigned su_b = 0, sw_a = 0, sw_b = 0, su_a = sign_word(zu_m1) >> 31;
     {
       T zc = u0_in, zp = zu_m1;
 #pragma unroll
@@ -742,9 +744,12 @@ struct WaveSolver {
           if constexpr (sizeof(SignWord) == 4) {
             su = (unsigned)__builtin_amdgcn_alignbit(su, sign_word(zc), 31);          // (su << 1) | sign(u_i)
             sw = (unsigned)__builtin_amdgcn_alignbit(sw, sign_word(zw[i]), 31);
+          } else if (i < MH) {
+            su_a = (unsigned)__builtin_amdgcn_alignbit(su_a, sign_word(zc), 31);
+            sw_a = (unsigned)__builtin_amdgcn_alignbit(sw_a, sign_word(zw[i]), 31);
           } else {
-            su = (su << 1) | (SignWord)(sign_word(zc) >> 31);
-            sw = (sw << 1) | (SignWord)(sign_word(zw[i]) >> 31);
+            su_b = (unsigned)__builtin_amdgcn_alignbit(su_b, sign_word(zc), 31);
+            sw_b = (unsigned)__builtin_amdgcn_alignbit(sw_b, sign_word(zw[i]), 31);
           }
         }
         const T zn = xfma(-t, zc, -zp);
@@ -755,6 +760,10 @@ struct WaveSolver {
       // transition i of u = (u_{i-1} -> u_i) sits at bit M-1-i of su ^ (su >> 1), counted for the rows i <= thr this lane owns (each
       // lane from ITS incoming pair, like sweep_fwd); transition i of w = (w_{i+1} -> w_i), w_M = zw_p1, at bit M-i of sw2 ^ (sw2 << 1),
       // counted for the owned rows i >= thr
+      if constexpr (sizeof(SignWord) == 8) {
+        su = ((SignWord)su_a << (M - MH)) | (SignWord)su_b;
+        sw = ((SignWord)sw_a << (M - MH)) | (SignWord)sw_b;
+      }
       const int last = has_last ? M - 1 : M - 2;
       const int iu = thr < last ? thr : last;                                   // u: i = 0 .. iu   (thr = -1: none)
       const SignWord one = 1;

@@ -114,7 +114,8 @@ int ibs_comm_destroy(ibs_ctx* ctx);
  * "chain_w1" / "chain_w2" (relative widths of the chain's warm starts), "geo_lpp" (lanes per grid point of the
  * geometry kernel 1|2|4|8, or -2 = two grid points per lane), "gcf_rows" (0: three-row staging instead of the row-streamed raw
  * kernel on long grids), "gcf_direct" (raw systems, one wave per system: rows read straight from global memory instead of staged in LDS; -1 = by
- * batch size, 0 = never, 1 = always), "f32_lam" (FP32 eigenvalue-only requests: 1 = all-FP32 iteration + FP64 certificate, 2 = FP64 solver on
+ * batch size, 0 = never, 1 = wherever a one-wave-per-system form would run: not where the sub-wave forms are picked, with a half-grid g, or
+ * below the rows-per-lane the direct kernels are built for), "f32_lam" (FP32 eigenvalue-only requests: 1 = all-FP32 iteration + FP64 certificate, 2 = FP64 solver on
  * the FP32 arrays; 0 = form 2 where the 16-lane sub-wave kernels run, else form 1), "reclose" (FP64 raw systems: 1 = a solve whose closing bracket
  * disagrees with its Rayleigh polish is closed again in division form, the default; 2 = only marked with status bit 3 and the distance
  * in bits 5..10; 0 = off, i.e. the round-5 results), "sigma0" (any finite value: solves that return lam and info flag lam_max >= sigma0
