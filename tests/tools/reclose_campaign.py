@@ -8,7 +8,8 @@ division-form multisection (csrc/ibs_wave.hpp: solve<true>, reclose_division; cs
 whole batch three ways -- checks off, suspects only marked, suspects re-closed -- and compares ALL results with the C oracle's
 division-form bisection (oracle/ibs_oracle.c), in units of ||A||; it also times the three modes.
 
-    python tests/tools/reclose_campaign.py [n_sys] [families] [nz,nz,...]       (default 2^20, rough+smooth, 256 512 1024 1536 2048)
+    python tests/tools/reclose_campaign.py [n_sys] [families] [nz,nz,...] [seed0]    (default 2^20, rough+smooth, 256 512 1024 1536 2048, 20240:
+    the bench's batches; another seed0 = systems the detector rule was not chosen on)
 """
 import os
 import sys
@@ -20,6 +21,7 @@ from oracle import c_oracle as co
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 families = sys.argv[2].split(",") if len(sys.argv) > 2 else ["rough", "smooth"]
 nzs = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [256, 512, 1024, 1536, 2048]
+seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 20240
 dev = torch.device("cuda", 0); ctx = ibs_amd.Context(0)
 EPS = 2.220446049250313e-16
 
@@ -42,10 +44,10 @@ def oracle_lam(h, g, c, f, chunk=32768):
 for nz in nzs:
     N = nz + 1
     for family in families:
-        h, g, c, f = bench.c5_family(dev, family, n, N, seed=20240 + nz)
+        h, g, c, f = bench.c5_family(dev, family, n, N, seed=seed0 + nz)
         nA = bench.norm_a(h, g, c, f).cpu().numpy()
         t0 = time.perf_counter(); lam_c = oracle_lam(h, g, c, f); t_or = time.perf_counter() - t0
-        print("N_zeta %d %s: %d systems, oracle %.0f s, bound 4 N eps = %.2e" % (nz, family, n, t_or, 4 * N * EPS), flush=True)
+        print("N_zeta %d %s (seed %d): %d systems, oracle %.0f s, bound 4 N eps = %.2e" % (nz, family, seed0 + nz, n, t_or, 4 * N * EPS), flush=True)
         for want_gam in (True, False):
             res = {}
             for mode in (0, 2, 1):
