@@ -180,7 +180,7 @@ int ensure_fix(ibs_ctx* c, long n_sys) {
   c->fix_cap = cap;
   return 0;
 }
-int long_waves(const ibs_ctx* c, long n_sys) { const long cap = 8L * c->n_cu; return (int)(n_sys < cap ? n_sys : cap); }
+int long_waves(const ibs_ctx* c, long n_sys) { const long cap = 8L * c->n_cu; return (int)(n_sys < cap ? n_sys : cap); }   // (ibs_long.hip: kLongChunk)
 
 int ensure_ws(ibs_ctx* c, size_t bytes) {
   if (bytes <= c->ws_bytes) return 0;

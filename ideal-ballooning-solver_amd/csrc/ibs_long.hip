@@ -39,8 +39,12 @@ struct SrcLong {
 // lanes form d_r, e_r^2, f_r of a chunk together (coalesced loads), then every lane runs the recurrence over the chunk from LDS (all
 // lanes read the same address: broadcast) -- the serial chain never waits for global memory (read per row it cost one exposed memory
 // latency per four rows: 27 ms per system at N = 8,193; so: 3).  Same arithmetic as count_above_rows (ibs_wave.hpp).
-constexpr int kLongChunk = 1024;
-constexpr int kVecChunk = kLongChunk / 2;      // pivots / eigenvector: two directions x (two operands + one result) in the same 24 KB
+constexpr int kLongChunk = 768;      // 18 KB per block: eight blocks per CU (the persistent grid of long_waves(), ibs_api.hip) stay resident -- the
+                                     // recurrence is a chain of dependent divisions, two waves per SIMD overlap almost freely.  Chunks of 1,024: six
+                                     // blocks per CU, 2,048 systems ran as 1,536 + 512 (24 ms at N = 16,385 against 15); chunks of 384, sixteen
+                                     // blocks: one system 25 % slower (twice the chunk boundaries), 8,192 systems no faster
+static_assert(8 * 3 * kLongChunk * sizeof(double) <= 160 * 1024, "eight blocks per CU");
+constexpr int kVecChunk = kLongChunk / 2;      // pivots / eigenvector: two directions x (two operands + one result) in the same LDS
 template <class Src>
 __device__ __forceinline__ int count_above_chunked(const Src& src, int n, double ih2, double sig, double* lds, int lane) {
   constexpr double pivmin = 2.2250738585072014e-292;

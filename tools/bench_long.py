@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0); ctx = ibs_amd.Context(0)
 for N in (2561, 4097, 8193, 16385, 65537):
     th = np.linspace(-4 * np.pi, 4 * np.pi, N); h = float(th[1] - th[0])
     rng = np.random.default_rng(N)
-    for n in (1, 2048):
+    for n in (1, 2048) + ((8192,) if N <= 8193 else ()):
         sh, al, t0 = rng.uniform(0.1, 2.0, (n, 1)), rng.uniform(0.0, 1.2, (n, 1)), rng.uniform(0.0, np.pi / 2, (n, 1))
         lam = sh * (th[None] - t0) - al * (np.sin(th)[None] - np.sin(t0))
         g = torch.from_numpy(1 + lam ** 2).to(dev); c = torch.from_numpy(al * (np.cos(th)[None] + np.sin(th)[None] * lam)).to(dev); f = g.clone()
