@@ -1382,8 +1382,17 @@ int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const 
   if (n_sys == 0) return 0;
   // forms: the prefix-product sweep (one wave per system, N <= 2050: the bandwidth kernel of rounds 1-5), and two division-form
   // kernels for any N (ibs_long.hip): lanes as systems (batches) and one wave per system (a handful of systems on a long grid)
+  // By size: the sweep up to 2,050 points -- except where its lanes sit 128 / 256 bytes apart (16 / 32 rows per lane: 4.2 / 2.8 TB/s
+  // against 6.3 at 8, 12, 24 rows) and the batch fills the chip with 64 systems per wave: there the division form is exact AND faster
+  // (4.9-5.1 TB/s; tools/experiments/sturm_crossover.py)
   int form = ctx->opt.sturm_form;
-  if (form == 0) form = is_long(N) ? (n_sys >= 64 ? 2 : 3) : 1;
+  if (form == 0) {
+    if (is_long(N)) form = n_sys >= 64 ? 2 : 3;
+    else {
+      const int Mr = rows_per_lane(N);
+      form = ((Mr == 16 && n_sys >= 65536) || (Mr == 32 && n_sys >= 32768)) ? 2 : 1;
+    }
+  }
   if (form == 1 && is_long(N)) form = 2;
   const bool lng = form != 1;
   const int M = lng ? 1 : rows_per_lane(N);

@@ -92,8 +92,17 @@ __device__ __forceinline__ void solve_long_one(const SrcLong<TI, HAS_GH>& src, i
   const int n = N - 2;
   const double ih2 = 1.0 / (h * h);
   // ---- 1. bounds and data checks (lanes strided over the rows)
+  // The Gershgorin-type lower end max_r d_r / f_r is ~ -||A|| (d_r = c_r - 2 g / h^2) while lam_max is O(1): every factor 64 of
+  // bracket is a pass over the rows.  Rayleigh quotients of four trial vectors x_j = sin^p(pi j / (N - 1)), p = 1, 4, 16, 64 (zero at
+  // both ends like the eigenfunctions, ever more localised about the middle of the grid where ballooning modes sit) are rigorous
+  // lower bounds of lam_max (Courant-Fischer) and cost this one parallel pass: on s-alpha and geometry lines the bracket starts
+  // O(1) wide instead of O(||A||), three passes of nine less; on rough coefficients the bounds are poor and nothing changes.
   double vhi = -1e300, vlo = -1e300, vna = 0.0;
+  double tn[4] = {0.0, 0.0, 0.0, 0.0}, td[4] = {0.0, 0.0, 0.0, 0.0};
   bool bad = false;
+  const double dth = 3.141592653589793 / (double)(N - 1);
+  double sdl, cdl;
+  sincos(dth, &sdl, &cdl);
   for (int r = lane; r < n; r += kWave) {
     const int j = r + 1;
     const double e_lo = src.e(r, ih2), e_hi = src.e(j, ih2);
@@ -102,11 +111,32 @@ __device__ __forceinline__ void solve_long_one(const SrcLong<TI, HAS_GH>& src, i
     const double rf = 1.0 / fj;
     vhi = xmax(vhi, cj * rf); vlo = xmax(vlo, d * rf); vna = xmax(vna, (xabs(d) + e_lo + e_hi) * rf);
     bad = bad || !(fj > 0.0) || !(gj > 0.0) || !(e_lo > 0.0) || !(e_hi > 0.0) || !finite_of(cj) || !finite_of(fj) || !finite_of(e_lo + e_hi);
+    double sj, cjs;
+    sincos(dth * (double)j, &sj, &cjs);
+    double xm = sj * cdl - cjs * sdl, x0 = sj, xp = sj * cdl + cjs * sdl;      // sin at j - 1, j, j + 1
+    xm = j == 1 ? 0.0 : xm; xp = j == N - 2 ? 0.0 : xp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tn[k] = xfma(x0, xfma(e_lo, xm, xfma(d, x0, e_hi * xp)), tn[k]);
+      td[k] = xfma(fj * x0, x0, td[k]);
+      xm *= xm; xm *= xm; x0 *= x0; x0 *= x0; xp *= xp; xp *= xp;               // p -> 4 p
+    }
   }
   if (lane == 0) bad = bad || !(src.g(0) > 0.0) || !(src.g(N - 1) > 0.0);
   const double normA = uniform(wave_max(vna));
   double hi = uniform(wave_max(vhi)) + 8.0 * Eps<double>::v * normA;
   double lo = uniform(wave_max(vlo)) - 8.0 * Eps<double>::v * normA;
+  {
+    double rho = -1e300;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double a = wave_sum(tn[k]), b = wave_sum(td[k]);
+      const double q = a / b;
+      rho = (b > 0.0 && finite_of(q) && q > rho) ? q : rho;
+    }
+    rho = uniform(rho) - (8.0 + 0.5 * (double)N) * Eps<double>::v * normA;       // (rounding of the sums: N terms)
+    if (rho > lo && rho < hi) lo = rho;
+  }
   int status = 0, passes = 0;
   double lam = 0.0;
   const bool want_vec = gam_out || X_out || dX_out;        // (kernel-uniform)
@@ -298,10 +328,14 @@ __global__ void __launch_bounds__(64) k_sturm_count_long(long n_sys, int N, doub
 // Division-form Sturm count with LANES AS SYSTEMS (round 6): every lane walks its own system's rows serially -- q_r = (d_r - sig f_r) -
 // e_r^2 / q_{r-1}, IEEE division, pivmin guard: exact for a pencil a few ulp away, any N (the prefix-product sweep k_sturm_count is
 // exact only for ~N eps ||A||, ~N^2 eps ||A|| on iid-random coefficients) -- while the rows reach it through an LDS transpose: per chunk
-// of 16 grid points the wave loads, for 64 systems, 16 consecutive values of g, c, f per system (four systems per load instruction:
-// 128-byte segments), writes them to LDS as [system][point] and reads them back one system per lane.  The next chunk's 48 loads are in
-// flight while the current one is worked on; a chain of 16 dependent divisions per chunk is ~1.5k clocks per 24.6 KB and SIMD, five
-// times the HBM rate: the kernel is bound by the memory system, like the sweep it certifies.
+// the wave loads, for 64 systems, ONE 128-byte line of g, c and f per system (four systems per load instruction), writes them to LDS as
+// [system][point] and reads them back one system per lane.  The next chunk's 48 loads are in flight while the current one is worked on.
+// Rows of N doubles start at any multiple of 8 bytes: a chunk of 16 grid points at the same j in every system straddled two lines per
+// system and array, and the second half was gone from the L2 by the time the next chunk asked for it (PMC: 1.82 x the algorithmic bytes).
+// So every system is walked from ITS OWN line boundary: lane s runs a_s = (its row's first element) mod 16 points behind the chunk index
+// -- the systems are independent, nothing needs them at the same grid point at the same time -- and a row is eliminated one step late,
+// when g of the next point has arrived (c and f of the row wait one step in registers).  Steps before point 1 / after point N - 2 of a
+// lane are masked.
 constexpr int kDivChunk = 16, kDivPitch = kDivChunk + 1, kDivWaves = 2;      // (2 waves per block: 52 KB of LDS, three blocks per CU)
 __global__ void __launch_bounds__(64 * kDivWaves) k_sturm_count_div(long n_sys, int N, double h, const double* __restrict__ g,
                                                          const double* __restrict__ c, const double* __restrict__ f, long ld,
@@ -311,27 +345,29 @@ __global__ void __launch_bounds__(64 * kDivWaves) k_sturm_count_div(long n_sys, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long base = ((long)blockIdx.x * kDivWaves + wave) * kWave;    // first system of this wave
   if (base >= n_sys) return;                                           // (wave-uniform; no block-level barrier below)
-  const int sub = lane >> 4, rr = lane & 15;                           // loader role: system 4 k + sub, point rr of the chunk
+  const int sub = lane >> 4, rr = lane & 15;                           // loader role: system 4 k + sub, element rr of its line
   const long mine = base + lane < n_sys ? base + lane : n_sys - 1;     // worker role: this lane's system
   const double sig = shift[mine];
   const double ih2 = 1.0 / (h * h);
-  const int n = N - 2;
+  auto phase = [&](long sy) { return (int)((reinterpret_cast<unsigned long long>(g + sy * ld) >> 3) & 15ull); };   // in doubles, of g's row
   double* tg = tile[wave][0]; double* tc = tile[wave][1]; double* tf = tile[wave][2];
   double vg[16], vc[16], vf[16];
-  auto load_chunk = [&](int j0) {                                      // grid points j0 .. j0 + 15: g[j + 1], c[j], f[j]
+  auto load_chunk = [&](int B) {                                       // system sy: grid points 16 B - a_sy + (0 .. 15), clamped into the row
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       long sy = base + 4 * k + sub; sy = sy < n_sys ? sy : n_sys - 1;
-      int j = j0 + rr; j = j <= N - 2 ? j : N - 2;
-      const long o = sy * ld + j;
-      vg[k] = g[o + 1]; vc[k] = c[o]; vf[k] = f[o];
+      int pnt = 16 * B - phase(sy) + rr;
+      pnt = pnt < 0 ? 0 : (pnt > N - 1 ? N - 1 : pnt);
+      const long o = sy * ld + pnt;
+      vg[k] = g[o]; vc[k] = c[o]; vf[k] = f[o];
     }
   };
-  const double gl = g[mine * ld], gc0 = g[mine * ld + 1];
-  double gm1 = gl, g0 = gc0, q = 1.0;
+  const int a_m = phase(mine);
+  double gm2 = 0.0, gm1 = 0.0, cprev = 0.0, fprev = 1.0, q = 1.0;
   int cnt = 0;
-  load_chunk(1);
-  for (int j0 = 1; j0 <= n; j0 += kDivChunk) {
+  const int nB = (N - 1 + 15) / 16 + 1;                                // chunks until every lane has seen its point N - 1
+  load_chunk(0);
+  for (int B = 0; B < nB; ++B) {
     wave_lds_sync();                                                   // (the previous chunk has been consumed)
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -339,17 +375,20 @@ __global__ void __launch_bounds__(64 * kDivWaves) k_sturm_count_div(long n_sys, 
       tg[o] = vg[k]; tc[o] = vc[k]; tf[o] = vf[k];
     }
     wave_lds_sync();
-    if (j0 + kDivChunk <= n) load_chunk(j0 + kDivChunk);               // in flight during the recurrence below
-    const int m = n - j0 + 1 < kDivChunk ? n - j0 + 1 : kDivChunk;
+    if (B + 1 < nB) load_chunk(B + 1);                                 // in flight during the recurrence below
+    const int p0 = 16 * B - a_m;                                       // this lane's grid point at i = 0
 #pragma unroll 4
-    for (int i = 0; i < m; ++i) {
-      const double gp1 = tg[lane * kDivPitch + i], cj = tc[lane * kDivPitch + i], fj = tf[lane * kDivPitch + i];
-      const double e_lo = 0.5 * (gm1 + g0) * ih2, e_hi = 0.5 * (g0 + gp1) * ih2;       // utils.py:1574-1576
-      const double a = xfma(-sig, fj, cj - (e_lo + e_hi));                             // utils.py:1584-1592
-      q = (j0 + i == 1) ? a : a - (e_lo * e_lo) / q;
-      q = xabs(q) < pivmin ? -pivmin : q;
-      cnt += q > 0.0 ? 1 : 0;
-      gm1 = g0; g0 = gp1;
+    for (int i = 0; i < kDivChunk; ++i) {
+      const double gp = tg[lane * kDivPitch + i], cp = tc[lane * kDivPitch + i], fp = tf[lane * kDivPitch + i];
+      const int j = p0 + i - 1;                                        // the row that can be eliminated now: g[j + 1] has arrived
+      const double e_lo = 0.5 * (gm2 + gm1) * ih2, e_hi = 0.5 * (gm1 + gp) * ih2;      // utils.py:1574-1576
+      const double a = xfma(-sig, fprev, cprev - (e_lo + e_hi));                       // utils.py:1584-1592
+      double qn = (j == 1) ? a : a - (e_lo * e_lo) / q;
+      qn = xabs(qn) < pivmin ? -pivmin : qn;
+      const bool row = j >= 1 && j <= N - 2;
+      q = row ? qn : q;
+      cnt += (row && qn > 0.0) ? 1 : 0;
+      gm2 = gm1; gm1 = gp; cprev = cp; fprev = fp;
     }
   }
   if (base + lane < n_sys) count_out[base + lane] = cnt;

@@ -491,8 +491,9 @@ class Context:
 
     def sturm_count(self, h, g, c, f, shift, exact=False):
         """eigenvalues of (T, F) above shift[i] per system (ibs_sturm_count_f64).  exact=True: the division-form kernel (lanes as
-        systems: a few eps ||A||, any N, ~4 TB/s) instead of the prefix-product sweep (N <= 2050: ~6 TB/s, exact for ~N eps ||A|| on
-        smooth and up to ~N^2 eps ||A|| on iid-random coefficients: within that distance of an eigenvalue it can be off by one)"""
+        systems: a few eps ||A||, any N, ~5 TB/s in big batches) instead of the prefix-product sweep (N <= 2050: ~6 TB/s, exact for
+        ~N eps ||A|| on smooth and up to ~N^2 eps ||A|| on iid-random coefficients: within that distance of an eigenvalue it can be
+        off by one).  Without it the library picks by size (include/ibs.h: ibs_sturm_count_f64)."""
         if exact:
             self.set_option("sturm_form", 2)
             try:

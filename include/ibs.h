@@ -121,7 +121,7 @@ int ibs_comm_destroy(ibs_ctx* ctx);
  * in bits 5..10; 0 = off, i.e. the round-5 results), "sigma0" (any finite value: solves that return lam and info flag lam_max >= sigma0
  * with the informational status bit 4 -- the nearest-sigma report of the drop-in, utils.py:1597; NaN = off, the default),
  * "sturm_form" (ibs_sturm_count_f64: 1 = prefix-product sweep, 2 = division form with lanes as systems, 3 = division form with one wave
- * per system; 0 = by grid length), "forget_rows" (an action: drop the remembered verdicts on device-resident mode rows, see ibs_fieldline_geometry_f64),
+ * per system; 0 = by grid length and batch size, see ibs_sturm_count_f64), "forget_rows" (an action: drop the remembered verdicts on device-resident mode rows, see ibs_fieldline_geometry_f64),
  * "pack_mode" (1|2: hand-off of the fused argmax), "refine_tangent" (refinement: the alpha-tangent of a point
  * staged in LDS, 1, or read from global memory by the sums, 0: two blocks per CU instead of one at N = 969; -1 = by batch size);
  * value 0 = automatic (refine_tangent, gcf_direct: -1); value NaN = back to what ibs_create() read from the environment
@@ -319,9 +319,12 @@ int ibs_last_launch(char* name, int32_t len, int64_t* blocks, int32_t* threads);
  * Replaces: tests/shifted-circle-s-alpha/bishop_ball_s-alpha.py:20-115 check_ball (isunstable <=> count(0) > 0).
  * Up to N = 2050 this is ONE prefix-product sweep per system (the bandwidth kernel): exact for a pencil perturbed by ~N eps ||A||
  * on smooth coefficients, but by up to ~N^2 eps ||A|| on iid-random ones -- within that distance of an eigenvalue the count can be
- * off by one.  Option "sturm_form" = 2 selects the DIVISION-form kernel instead (lanes as systems, the rows through an LDS transpose:
- * exact for a pencil a few ulp away, any N, 3.5-4 TB/s against the sweep's 6 TB/s at N_zeta <= 512; Python: sturm_count(...,
- * exact=True)); it is what grids beyond 2050 points get (batches under 64 systems: one wave per system).  Even N is accepted here. */
+ * off by one.  Option "sturm_form" = 2 selects the DIVISION-form kernel instead (lanes as systems, the rows through an LDS transpose,
+ * every system read from its own 128-byte line boundary: exact for a pencil a few ulp away, any N, 4.8-5.5 TB/s in batches of 65,536
+ * systems or more against the sweep's 6 TB/s at N_zeta <= 512; Python: sturm_count(..., exact=True)); it is what grids beyond 2050
+ * points get (batches under 64 systems: one wave per system) and, where it is also the faster one, what big batches get by default
+ * (16 rows per lane = N in 963 .. 1026 from 65,536 systems, 32 rows = 1987 .. 2050 from 32,768: the sweep runs at 4.2 / 2.8 TB/s
+ * there).  Even N is accepted here. */
 int ibs_sturm_count_f64(ibs_ctx* ctx, int64_t n_sys, int32_t N, double h, const double* g, const double* c,
                         const double* f, int64_t ld, const double* shift, int32_t* count, int32_t mem);
 

@@ -65,7 +65,12 @@ def test_config5_fp64_one_million_systems(ctx, nz, family):
     assert "k_sturm_count_div" in ctx.last_launch()[0]
     odd = torch.nonzero((above != 0) | (below < 1)).flatten().cpu().numpy()
     assert len(odd) == 0, (len(odd), odd[:8])
-    ab_p = ctx.sturm_count(h, g, c, f, lam + tol * nA); be_p = ctx.sturm_count(h, g, c, f, lam - tol * nA)
+    ctx.set_option("sturm_form", 1)         # (the default form is the division form where it is also the faster one: M = 16 / 32, big batches)
+    try:
+        ab_p = ctx.sturm_count(h, g, c, f, lam + tol * nA); be_p = ctx.sturm_count(h, g, c, f, lam - tol * nA)
+        assert "k_sturm_count<" in ctx.last_launch()[0]
+    finally:
+        ctx.set_option("sturm_form", None)
     odd_p = torch.nonzero((ab_p != 0) | (be_p < 1)).flatten().cpu().numpy()
     assert len(odd_p) <= n // 5000, len(odd_p)
     if len(odd_p):                          # (the C oracle agrees with the division-form kernel on them)
