@@ -259,6 +259,42 @@ def test_large_grid_rough_coefficients_against_the_oracle(ctx):
         assert np.abs(r["gam"].cpu().numpy() - gam_c).max() < 1e-7, (N, np.abs(r["gam"].cpu().numpy() - gam_c).max())
 
 
+def test_division_form_count_with_rows_at_any_alignment(ctx):
+    """k_sturm_count_div walks every system from its own 128-byte line boundary (the phase of its row's first element): rows with a
+    leading dimension beyond N, arrays that start 8, 40 and 120 bytes into a line, g / c / f at DIFFERENT phases, batches that do not
+    fill the last wave -- through the C ABI with device pointers, against the oracle's division-form count; N around the chunk
+    boundaries (multiples of 16 +- 1), even N included (ibs.h: accepted here)."""
+    import ctypes as C
+    import torch
+    from ibs_amd._lib import check, lib
+    from oracle import c_oracle as co
+    L = lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    ctx.set_option("sturm_form", 2)
+    try:
+        for N, n, ld, offs in ((513, 200, 513, (1, 5, 15)), (512, 67, 520, (0, 3, 9)), (81, 130, 96, (15, 15, 2)), (2049, 70, 2051, (7, 0, 11)),
+                                (66, 64, 66, (1, 2, 3)), (97, 1, 97, (13, 6, 0))):
+            h = 8 * np.pi / (N - 1)
+            g = np.exp(rng.uniform(-1, 2, (n, N))); c = rng.uniform(-2.5, 3.5, (n, N)); f = np.exp(rng.uniform(0, 3, (n, N)))
+            sh = rng.uniform(-3.0, 1.0, n)
+            bufs, ptrs = [], []
+            for arr, off in zip((g, c, f), offs):
+                flat = torch.zeros(off + n * ld + 16, dtype=torch.float64, device=dev)
+                flat[off:off + n * ld].view(n, ld)[:, :N] = torch.from_numpy(arr).to(dev)
+                bufs.append(flat); ptrs.append(C.c_void_p(flat.data_ptr() + 8 * off))
+            d_sh = torch.from_numpy(sh).to(dev); d_cnt = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            check(L.ibs_sturm_count_f64(ctx._h, n, N, float(h), ptrs[0], ptrs[1], ptrs[2], ld, C.c_void_p(d_sh.data_ptr()),
+                                        C.c_void_p(d_cnt.data_ptr()), 0), "ibs_sturm_count_f64")      # (0 = IBS_MEM_DEVICE)
+            check(L.ibs_synchronize(ctx._h), "ibs_synchronize")
+            assert "k_sturm_count_div" in ctx.last_launch()[0]
+            want = co.count_above_batch(h, g, c, f, sh)
+            assert np.array_equal(d_cnt.cpu().numpy(), want), (N, n, ld, offs, int((d_cnt.cpu().numpy() != want).sum()))
+    finally:
+        ctx.set_option("sturm_form", None)
+
+
 def test_large_grid_geometry_fed_scan_with_theta0_derivative(ctx):
     """ibs_gamma_scan_f64 on a 4097-point grid: two field lines of the tests' smooth geometry family x 3 theta0 against the oracle --
     gam, lam, and the Hellmann-Feynman d gam / d theta0 of utils.py:1666-1680."""
