@@ -9,7 +9,8 @@ whole batch three ways -- checks off, suspects only marked, suspects re-closed -
 division-form bisection (oracle/ibs_oracle.c), in units of ||A||; it also times the three modes.
 
     python tests/tools/reclose_campaign.py [n_sys] [families] [nz,nz,...] [seed0]    (default 2^20, rough+smooth, 256 512 1024 1536 2048, 20240:
-    the bench's batches; another seed0 = systems the detector rule was not chosen on)
+    the bench's batches; another seed0 = systems the detector rule was not chosen on; RECLOSE_OPTS=name=value,... sets library options first,
+    e.g. gcf_direct=0,force_p=64 for the staged one-wave-per-system forms, which re-close in place)
 """
 import os
 import sys
@@ -23,6 +24,8 @@ families = sys.argv[2].split(",") if len(sys.argv) > 2 else ["rough", "smooth"]
 nzs = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [256, 512, 1024, 1536, 2048]
 seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 20240
 dev = torch.device("cuda", 0); ctx = ibs_amd.Context(0)
+for kv in filter(None, os.environ.get("RECLOSE_OPTS", "").split(",")):        # e.g. RECLOSE_OPTS=gcf_direct=0,force_p=64: the staged forms
+    k, v = kv.split("="); ctx.set_option(k, float(v)); print("option %s = %s" % (k, v))
 EPS = 2.220446049250313e-16
 
 
