@@ -71,6 +71,10 @@ def test_config5_fp64_one_million_systems(ctx, nz, family):
         assert "k_sturm_count<" in ctx.last_launch()[0]
     finally:
         ctx.set_option("sturm_form", None)
+    # left to itself the library takes the division form where it is also the faster one (16 / 32 rows per lane, big batches)
+    ab_0 = ctx.sturm_count(h, g, c, f, lam + tol * nA)
+    assert ("k_sturm_count_div" in ctx.last_launch()[0]) == ((N - 2 + 63) // 64 in (16, 32)), ctx.last_launch()
+    assert torch.equal(ab_0, above if "k_sturm_count_div" in ctx.last_launch()[0] else ab_p)
     odd_p = torch.nonzero((ab_p != 0) | (be_p < 1)).flatten().cpu().numpy()
     assert len(odd_p) <= n // 5000, len(odd_p)
     if len(odd_p):                          # (the C oracle agrees with the division-form kernel on them)
