@@ -35,6 +35,17 @@ struct SrcLong {
   }
 };
 
+// Every S-th grid point of a system: the same operator on a coarser grid (two-grid start of the multisection, solve_long_one)
+template <class Src>
+struct SrcCoarse {
+  static constexpr bool kHasGh = false;
+  const Src& s; int S;
+  __device__ __forceinline__ double g(int j) const { return s.g(S * j); }
+  __device__ __forceinline__ double c(int j) const { return s.c(S * j); }
+  __device__ __forceinline__ double f(int j) const { return s.f(S * j); }
+  __device__ __forceinline__ double e(int k, double ih2c) const { return 0.5 * (s.g(S * k) + s.g(S * (k + 1))) * ih2c; }
+};
+
 // Division-form count of one system at 64 shifts (lane L = shift L) with the rows passed through LDS in chunks of kLongChunk: the 64
 // lanes form d_r, e_r^2, f_r of a chunk together (coalesced loads), then every lane runs the recurrence over the chunk from LDS (all
 // lanes read the same address: broadcast) -- the serial chain never waits for global memory (read per row it cost one exposed memory
@@ -144,9 +155,38 @@ __device__ __forceinline__ void solve_long_one(const SrcLong<TI, HAS_GH>& src, i
     status = 2;
     lam = __builtin_nan("");
   } else {
-    // ---- 2. eigenvalue
+    // ---- 2. eigenvalue.  Two-grid start: where the trial vectors have brought the bracket down from O(||A||) to O(1) -- smooth
+    // coefficients -- lam_max of the same operator on every 16th and every 8th grid point (a sixteenth / an eighth of a pass per
+    // multisection pass, closed to 1e-7 of the bracket) differ from the fine grid's by C (16 h)^2 and C (8 h)^2: their Richardson
+    // extrapolate, +- a quarter of their difference, is where the fine multisection starts (a bracket that misses is moved and
+    // widened by multisect itself, at a pass per miss).  6 fine passes become 3-4 + 0.6.
+    int coarse_passes = 0;
+    if ((N - 1) % 16 == 0 && N >= 1025 && (hi - lo) < 1e-3 * normA) {
+      double l16 = 0.0, l8 = 0.0;
+      int p16 = 0, p8 = 0;
+      const double stop_c = 1e-7 * (hi - lo) / (Eps<double>::v * normA);      // multisect ends at width <= stop eps ||A||
+      const SrcCoarse<SrcLong<TI, HAS_GH>> c16{src, 16}, c8{src, 8};
+      const int n16 = (N - 1) / 16 - 1, n8 = (N - 1) / 8 - 1;
+      const bool ok16 = multisect<double>([&](double sig) { return count_above_chunked(c16, n16, ih2 * (1.0 / 256.0), sig, lds, lane); },
+                                          lo, hi, normA, stop_c, lane, l16, p16);
+      bool ok8 = false;
+      if (ok16) {
+        const double w8 = 1e-2 * (hi - lo);                                  // (the two coarse grids differ by far less on smooth data)
+        ok8 = multisect<double>([&](double sig) { return count_above_chunked(c8, n8, ih2 * (1.0 / 64.0), sig, lds, lane); },
+                                xmax(lo, l16 - w8), xmin(hi, l16 + w8), normA, stop_c, lane, l8, p8);
+      }
+      coarse_passes = (p16 + 15) / 16 + (p8 + 7) / 8;                         // (in units of a fine pass, rounded up)
+      if (ok16 && ok8) {
+        const double dl = l16 - l8;
+        const double est = l8 - dl * (1.0 / 3.0);
+        const double w = xmax(0.25 * xabs(dl), 8.0 * 1e-7 * (hi - lo));
+        const double lo2 = xmax(lo, est - w), hi2 = xmin(hi, est + w);
+        if (lo2 < hi2) { lo = lo2; hi = hi2; }
+      }
+    }
     if (!multisect<double>([&](double sig) { return count_above_chunked(src, n, ih2, sig, lds, lane); }, lo, hi, normA, 2.0, lane, lam, passes))
       status = 1;
+    passes += coarse_passes;
   }
   double gam = __builtin_nan("");
   if (want_vec && status == 0) {
