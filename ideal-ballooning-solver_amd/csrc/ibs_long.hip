@@ -1,12 +1,13 @@
 // Grids beyond the register-resident kernels (N > 64 * kMaxM + 2 = 2050 points, up to kMaxLongN): the generic path that keeps the
 // drop-in from refusing what the reference computes -- utils.py:1556-1624 accepts any length, and the reference's own grid rule
-// N = 2 mpol ntor 4 + 1 (ball_scan.py:201-208) passes 2050 from mpol ntor > 256 on.  Correctness first, speed second.
+// N = 2 mpol ntor 4 + 1 (ball_scan.py:201-208) passes 2050 from mpol ntor > 256 on.
 //
 // One wavefront per system, everything in DIVISION form on the original rows (no scaled rows, nothing register-resident):
-//   1. bounds        lam_max <= max c/f (Gershgorin), lam_max >= max d/f (unit vectors), ||A||; data checks
+//   1. bounds        lam_max <= max c/f (Gershgorin), lam_max >= max d/f (unit vectors) and >= the Rayleigh
+//                    quotients of four trial vectors sin^p(pi j / (N - 1)) taken in the same pass, ||A||; data checks
 //   2. eigenvalue    64-way multisection on division-form Sturm counts (ibs_wave.hpp: multisect; the recurrence of SURVEY Appendix A /
-//                    LAPACK dstebz, the rows passed through LDS in chunks: count_above_chunked), ~9 passes from the Gershgorin
-//                    bracket to eps ||A||
+//                    LAPACK dstebz, the rows passed through LDS in chunks: count_above_chunked) to a bracket of 2 eps ||A||: first on
+//                    every 16th and every 8th grid point (two-grid start), then 3-5 passes on all rows (9 from the Gershgorin bracket alone)
 //   3. eigenvector   twisted factorisation N_k D_k N_k^T of T - lam F (the getvec step of MRRR): forward pivots D+ (lane 0) and
 //                    backward pivots D- (lane 1) in one serial pass, gamma_r = D+_r + D-_r - (d_r - lam f_r) in parallel, twist row
 //                    k = argmin |gamma_r|, then z_k = 1, z_{r-1} = -e_r z_r / D+_{r-1} downwards (lane 0) and
