@@ -1271,8 +1271,14 @@ def main():
 
     def timed_steps(n_steps, with_events):
         """K steps between two fences; max over the ranks.  Returns (seconds, live kernel ms or None)."""
-        EV = 8            # the dominant kernel is bracketed on every 8th step (an event pair costs stream time)
+        # the dominant kernel is bracketed by a HIP-event pair on eight steps of the region (at least ten steps apart): a pair costs
+        # 6.5 us of stream time (tools/experiments/step_fixed_cost.py) -- on every 8th step that was 0.7 us per step, 2.8 % of `value`
+        EV = max(10, n_steps // 8)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((n_steps + EV - 1) // EV)] if with_events else None
+        if with_events:               # (torch creates the HIP event at its first record: that is not the region's work)
+            for a, b in evs:
+                a.record(); b.record()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(n_steps):
             step(k, evs[k // EV] if (with_events and k % EV == 0) else None)
