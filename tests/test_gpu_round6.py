@@ -325,6 +325,38 @@ def test_large_grid_geometry_fed_scan_with_theta0_derivative(ctx):
             assert abs(r["dgam_dtheta0"][i, j] - jac) < 1e-7 * max(1.0, abs(jac)), (i, j, r["dgam_dtheta0"][i, j], jac)
 
 
+def test_large_grid_scan_variants_agree_with_the_plain_scan(ctx):
+    """The other geometry-fed entry points on a 2561-point grid (ibs.h: all of them accept grids up to 65,537 points): the scan with
+    the per-surface first maximum (ibs_gamma_scan_argmax_f64; ball_scan.py:283-288), one (line, theta0) pair per point
+    (ibs_gamma_points_f64; the final solve of ball_scan.py:322-339), and the warm-started scan (a guess is accepted and, on this path,
+    not needed) return what ibs_gamma_scan_f64 returns, which the test above pins to the oracle."""
+    import torch
+    from oracle import ballooning_oracle as bo
+    from tests.helpers import synthetic_fieldlines
+    dev = torch.device("cuda:0")
+    N = 2561
+    th = np.linspace(-4 * np.pi, 4 * np.pi, N)
+    h = float(th[1] - th[0])
+    al = np.array([0.2, 0.9, 1.6, 2.4])
+    lines = np.concatenate([synthetic_fieldlines(th)(0.5, al), synthetic_fieldlines(th)(0.7, al)])        # 2 surfaces x 4 lines
+    dP = np.array([bo.dPdrho_of(lines[i, 2], lines[i, 7], lines[i, 0]) for i in range(8)])
+    t0 = np.array([0.0, 0.5, 1.2])
+    geo = [torch.from_numpy(np.ascontiguousarray(lines[:, k, :])).to(dev) for k in range(7)]
+    dP_d, t0_d = torch.from_numpy(dP).to(dev), torch.from_numpy(t0).to(dev)
+    base = ctx.gamma_scan(h, *geo, dP_d, t0_d, want_info=True)
+    assert "k_solve_gcf_long<double>" in ctx.last_launch()[0] and int(((base["info"] >> 16) & 3).sum()) == 0
+    am = ctx.gamma_scan_argmax(h, geo, dP_d, t0_d, 2)
+    assert torch.equal(am["gam"], base["gam"]) and torch.equal(am["lam"], base["lam"])
+    for s in range(2):
+        blk = base["gam"][4 * s:4 * s + 4].reshape(-1)
+        k = int(torch.argmax(blk))                                               # (first maximum: torch.argmax returns the first)
+        assert float(am["pack"][s, 0]) == float(blk[k]) and int(am["pack"][s, 1]) == k
+    pts = ctx.gamma_points(h, *geo, dP_d, torch.from_numpy(np.full(8, 0.5)).to(dev))
+    assert torch.equal(pts["gam"], base["gam"][:, 1]) and torch.equal(pts["lam"], base["lam"][:, 1])
+    warm = ctx.gamma_scan(h, *geo, dP_d, t0_d, lam_guess=base["lam"], guess_width=1e-3)
+    assert torch.equal(warm["gam"], base["gam"])
+
+
 # ---------------------------------------------------------------------------------------------- nearest-sigma report
 def test_nearest_sigma_divergence_is_reported(ctx):
     """utils.py:1597 takes the eigenpair NEAREST sigma0 (ARPACK shift-invert); the drop-in always takes lam_max.  A strongly driven
