@@ -1145,18 +1145,90 @@ int ibs_scan_starts_f64(ibs_ctx* ctx, int32_t n_surf, int32_t n_alpha, int32_t n
   return 0;
 }
 
+// ---- objective + Hellmann-Feynman gradient on grids beyond 2050 points (utils.py:1632-1728 takes any length): composed from the
+// long-grid pieces -- dPdrho of the 3 n lines (k_line_dPdrho), their (g, c, f) rows and theta0-tangents at the point's theta0
+// (k_assemble_gcf_long), the centre lines' rows and the alpha-tangents (right - left) / del_alpha packed per point, ONE long-grid
+// solve per point with eigenfunction (k_solve_gcf_long), two Hellmann-Feynman sums (k_hf_grad).
+__global__ void k_grad_long_t0(int n_pts, const double* __restrict__ theta0, double* __restrict__ th3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * n_pts) th3[i] = theta0[i / 3];
+}
+__global__ void __launch_bounds__(256) k_grad_long_pack(int n_pts, int N, double inv_del, const double* __restrict__ G, const double* __restrict__ C,
+                                                        const double* __restrict__ F, const double* __restrict__ GT, const double* __restrict__ CT,
+                                                        const double* __restrict__ FT, double* gC, double* cC, double* fC, double* gtC, double* ctC,
+                                                        double* ftC, double* gaC, double* caC, double* faC) {
+  const int p = blockIdx.y;
+  const size_t l = (size_t)(3 * p) * N, m = l + N, r = m + N, o = (size_t)p * N;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+    gC[o + j] = G[m + j]; cC[o + j] = C[m + j]; fC[o + j] = F[m + j];
+    gtC[o + j] = GT[m + j]; ctC[o + j] = CT[m + j]; ftC[o + j] = FT[m + j];                 // utils.py:1669-1673
+    gaC[o + j] = (G[r + j] - G[l + j]) * inv_del; caC[o + j] = (C[r + j] - C[l + j]) * inv_del;      // utils.py:1705-1719
+    faC[o + j] = (F[r + j] - F[l + j]) * inv_del;
+  }
+}
+__global__ void k_grad_long_out(int n_pts, const double* __restrict__ gam, const double* __restrict__ ja, const double* __restrict__ jt,
+                                double* val, double* jac, double* gam_o, double* da_o, double* dt_o) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  val[p] = -gam[p]; jac[2 * p] = -ja[p]; jac[2 * p + 1] = -jt[p];                            // utils.py:1728
+  if (gam_o) gam_o[p] = gam[p];
+  if (da_o) da_o[p] = ja[p];
+  if (dt_o) dt_o[p] = jt[p];
+}
+static hipError_t launch_grad_long(const ibs::GradArgs<double>& a, hipStream_t st) {
+  ibs_ctx* ctx = g_long_ctx;
+  const size_t n = (size_t)a.n_pts, N = (size_t)a.N, rows = n * N;
+  const int nw = long_waves(ctx, (long)n);
+  const size_t need = (size_t)nw * 3 * N + 6 * 3 * rows + 11 * rows + 6 * n + 3 * n + 512;
+  if (ensure_long_ws(ctx, need * sizeof(double)) != 0) return hipErrorOutOfMemory;
+  double* w = static_cast<double*>(ctx->long_ws);
+  auto take = [&](size_t k) { double* q = w; w += k; return q; };
+  double* work = take((size_t)nw * 3 * N);
+  double *G = take(3 * rows), *C = take(3 * rows), *F = take(3 * rows), *GT = take(3 * rows), *CT = take(3 * rows), *FT = take(3 * rows);
+  double *gC = take(rows), *cC = take(rows), *fC = take(rows), *gtC = take(rows), *ctC = take(rows), *ftC = take(rows);
+  double *gaC = take(rows), *caC = take(rows), *faC = take(rows), *Xw = take(rows), *dXw = take(rows);
+  double *dP3 = take(3 * n), *th3 = take(3 * n), *gamw = take(n), *lamw = take(n), *ja = take(n), *jt = take(n);
+  const long lds = a.ld;                                                  // geo: [n_pts][3][8][ld]
+  hipError_t e = ibs::launch_line_dPdrho((int)(3 * n), a.N, 8 * lds, (size_t)lds, a.geo, dP3, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_grad_long_t0, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, st, a.n_pts, a.theta0, th3);
+  ibs::ScanArgs<double> sa{};
+  sa.n_lines = (int)(3 * n); sa.n_theta0 = 1; sa.N = a.N; sa.h = a.h; sa.ld = 8 * lds;
+  sa.bmag = a.geo; sa.gradpar = a.geo + lds; sa.cvdrift = a.geo + 2 * lds; sa.cvdrift0 = a.geo + 3 * lds;
+  sa.gds2 = a.geo + 4 * lds; sa.gds21 = a.geo + 5 * lds; sa.gds22 = a.geo + 6 * lds;
+  sa.dPdrho = dP3; sa.theta0 = th3; sa.t0_stride = 1;
+  e = ibs::launch_assemble_long(sa, G, C, F, GT, CT, FT, st);
+  if (e != hipSuccess) return e;
+  int bx = (a.N + 255) / 256;
+  if (bx > 16) bx = 16;
+  hipLaunchKernelGGL(k_grad_long_pack, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, a.n_pts, a.N, 1.0 / a.del_alpha, G, C, F, GT, CT, FT,
+                     gC, cC, fC, gtC, ctC, ftC, gaC, caC, faC);
+  ibs::LongGcfArgs la{};
+  la.n_sys = (long)n; la.N = a.N; la.h = a.h; la.g = gC; la.c = cC; la.f = fC; la.gh = nullptr; la.f32 = 0; la.ld = (long)N;
+  la.lam = lamw; la.gam = gamw; la.X = Xw; la.dX = dXw; la.info = a.info; la.work = work; la.n_waves = nw;
+  e = ibs::launch_gcf_long(la, st);
+  if (e != hipSuccess) return e;
+  const unsigned hb = (unsigned)((n + 3) / 4);
+  hipLaunchKernelGGL(k_hf_grad, dim3(hb), dim3(256), 0, st, (long)n, a.N, (long)N, Xw, dXw, fC, gtC, ctC, ftC, gamw, jt);
+  hipLaunchKernelGGL(k_hf_grad, dim3(hb), dim3(256), 0, st, (long)n, a.N, (long)N, Xw, dXw, fC, gaC, caC, faC, gamw, ja);
+  hipLaunchKernelGGL(k_grad_long_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.n_pts, gamw, ja, jt, a.val, a.jac, a.gam, a.dalpha, a.dth0);
+  return hipGetLastError();
+}
+
 int ibs_obj_w_grad_f64(ibs_ctx* ctx, int32_t n_pts, int32_t N, double h, const double* geo, int64_t ld,
                        const double* theta0, double del_alpha, double* val, double* jac, int32_t* info,
                        int32_t mem) {
   if (!ctx) return fail(IBS_ERR_ARG, "null context");
   if (n_pts < 0 || !geo || !theta0 || !val || !jac || ld < N || !(del_alpha > 0)) return fail(IBS_ERR_ARG, "bad arguments");
-  if (int r = check_grid(N, h)) return r;
+  if (int r = check_grid(N, h, true)) return r;
   if (n_pts == 0) return 0;
-  const int M = rows_per_lane(N);
-  auto fn = ibs::launch_table().grad_f64[M];
+  const bool lng = is_long(N);                 // grids beyond 2050 points: launch_grad_long
+  const int M = lng ? 1 : rows_per_lane(N);
+  auto fn = lng ? &launch_grad_long : ibs::launch_table().grad_f64[M];
   if (!fn) return fail(IBS_ERR_UNSUPPORTED, "no kernel built for rows-per-lane M=%d (N=%d)", M, N);
+  if (lng) g_long_ctx = ctx;
   ON_DEVICE(ctx);
-  const size_t per_wave = (size_t)8 * ibs::lds_pitch(N) * sizeof(double);
+  const size_t per_wave = (size_t)8 * ibs::lds_pitch(lng ? 66 : N) * sizeof(double);
   int wpb = (int)((size_t)ctx->lds_per_block / per_wave);
   if (wpb > 4) wpb = 4;
   if (wpb < 1) return fail(IBS_ERR_UNSUPPORTED, "N=%d does not fit the LDS staging", N);

@@ -1155,6 +1155,11 @@ __global__ void __launch_bounds__(256) k_line_dPdrho(int n_lines, int N, long ld
   if (threadIdx.x == 0) dPdrho[line] = -0.5 * (part[0] + part[1] + part[2] + part[3]) / N;
 }
 
+hipError_t launch_line_dPdrho(int n_lines, int N, long ld, size_t plane, const double* geo, double* dPdrho, hipStream_t st) {
+  hipLaunchKernelGGL(k_line_dPdrho, dim3((unsigned)n_lines), dim3(256), 0, st, n_lines, N, ld, plane, geo, dPdrho);
+  return hipGetLastError();
+}
+
 // Which form serves a batch of n_lines x N grid points on a chip of n_cu CUs: the persistent kernel has 8 n_cu wave slots
 // (two waves per SIMD); the forms with more points per wave-item cost less per point (one lane per point: rows in n-symmetric
 // form fed by DPP broadcasts), so the choice is the SMALLEST item that still gives no wave slot a second item

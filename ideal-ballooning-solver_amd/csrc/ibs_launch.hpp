@@ -63,6 +63,8 @@ template <typename T> struct ScanArgs;
 hipError_t launch_assemble_long(const ScanArgs<double>& a, double* g, double* c, double* f, double* gt, double* ct, double* ft, hipStream_t st);
 
 // field-line geometry kernel (ibs_geometry.hip)
+// dPdrho[line] = -0.5 mean((cvdrift - gbdrift) bmag^2) of lines laid out geo[k * plane + line * ld + j], k = 0 .. 7 (ball_scan.py:262)
+hipError_t launch_line_dPdrho(int n_lines, int N, long ld, size_t plane, const double* geo, double* dPdrho, hipStream_t st);
 struct GeoForm { int ppl, lpp; };   // grid points per lane, lanes per grid point (one of them is 1)
 constexpr int kGeoMaxPairs = 64;    // pair indices about a row's centre the one-lane-per-point table image holds for the root solve
 struct GeoArgs {

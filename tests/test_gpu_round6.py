@@ -357,6 +357,36 @@ def test_large_grid_scan_variants_agree_with_the_plain_scan(ctx):
     assert torch.equal(warm["gam"], base["gam"])
 
 
+def test_large_grid_obj_w_grad_against_the_oracle(ctx):
+    """utils.py:1632-1728 (objective + Hellmann-Feynman gradient of one (alpha, theta0) point from the field lines at alpha - d/2,
+    alpha, alpha + d/2) takes any grid length: on 2561 and 4097 points ibs_obj_w_grad_f64 is composed from the long-grid pieces
+    (csrc/ibs_api.hip: launch_grad_long) -- batched call on host and on device arrays, and the literal drop-in obj_w_grad(x0, vs,
+    rho, theta, vguess, sigma) that scipy's minimize would call (ball_scan.py:307-314) -- against the oracle's restatement."""
+    import torch
+    import ibs_amd
+    from oracle import ballooning_oracle as bo
+    from tests.helpers import synthetic_fieldlines
+    dev = torch.device("cuda:0")
+    for N in (2561, 4097):
+        th = np.linspace(-4 * np.pi, 4 * np.pi, N)
+        fl = synthetic_fieldlines(th)
+        pts = [(0.6, 1.0, 0.4), (0.8, 2.2, 0.0), (0.5, 0.3, 1.1)]                       # (s, alpha, theta0)
+        d = 0.004
+        geo = np.stack([fl(s_, np.array([a_ - d / 2, a_, a_ + d / 2])) for s_, a_, _ in pts])     # (n_pts, 3, 8, N)
+        t0 = np.array([p[2] for p in pts])
+        val, jac, info = ctx.obj_w_grad(float(th[1] - th[0]), geo, t0, d, want_info=True)
+        assert (((info >> 16) & 3) == 0).all()
+        for k, (s_, a_, t_) in enumerate(pts):
+            vo, jo = bo.obj_w_grad_lines(th, t_, geo[k, 0], geo[k, 1], geo[k, 2], d)
+            assert abs(val[k] - vo) < 1e-8, (N, k, val[k], vo)
+            assert np.abs(jac[k] - jo).max() < 1e-6 * max(1.0, np.abs(jo).max()), (N, k, jac[k], jo)
+        v2, j2 = ctx.obj_w_grad(float(th[1] - th[0]), torch.from_numpy(geo).to(dev), torch.from_numpy(t0).to(dev), d)
+        assert np.array_equal(v2.cpu().numpy(), val) and np.array_equal(j2.cpu().numpy(), jac)
+    drop = ibs_amd.make_obj_w_grad(lambda vs, s, al, theta: fl(s, al), ctx=ctx)
+    v, j = drop((1.0, 0.4), None, 0.6, th, None, 0.42)
+    assert abs(v - val[0]) < 1e-11 and np.abs(j - jac[0]).max() < 1e-9        # (the drop-in takes h from the whole grid, the calls above from its first step)
+
+
 # ---------------------------------------------------------------------------------------------- nearest-sigma report
 def test_nearest_sigma_divergence_is_reported(ctx):
     """utils.py:1597 takes the eigenpair NEAREST sigma0 (ARPACK shift-invert); the drop-in always takes lam_max.  A strongly driven
