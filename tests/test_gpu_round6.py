@@ -387,6 +387,26 @@ def test_large_grid_obj_w_grad_against_the_oracle(ctx):
     assert abs(v - val[0]) < 1e-11 and np.abs(j - jac[0]).max() < 1e-9        # (the drop-in takes h from the whole grid, the calls above from its first step)
 
 
+def test_large_grid_scan_driver_end_to_end(ctx):
+    """ball_scan.py:248-339 on a 2561-point grid (mpol = 20, ntor = 16 in the reference's rule): coarse scan, first maximum,
+    L-BFGS-B refinement under scipy's minimize with the drop-in obj_w_grad (the reference's own optimizer call, ball_scan.py:305-314),
+    final solve -- the GPU-backed driver against the same driver on the oracle."""
+    import ibs_amd
+    from oracle import ballooning_oracle as bo
+    from tests.helpers import OracleContext, synthetic_fieldlines
+    N = 2561
+    th = np.linspace(-4 * np.pi, 4 * np.pi, N)
+    fl = synthetic_fieldlines(th)
+    rho = np.array([0.55, 0.8])
+    gpu = ibs_amd.BallooningScan(ctx, fl, th, rho, nalpha=4, ntheta0=3)
+    cpu = ibs_amd.BallooningScan(OracleContext(), fl, th, rho, nalpha=4, ntheta0=3)
+    assert np.abs(gpu.coarse() - cpu.coarse()).max() < 1e-8
+    tg, ag, gg = gpu.run(refine=True)
+    tc, ac, gc = cpu.run(refine=True)
+    assert np.abs(gg - gc).max() < 1e-8, (gg, gc)
+    assert np.abs(tg - tc).max() < 1e-4 and np.abs(ag - ac).max() < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------- nearest-sigma report
 def test_nearest_sigma_divergence_is_reported(ctx):
     """utils.py:1597 takes the eigenpair NEAREST sigma0 (ARPACK shift-invert); the drop-in always takes lam_max.  A strongly driven
