@@ -296,7 +296,14 @@ class BallooningScan:
             bad = bad + ((sc["info"] >> 16) != 0).sum()
         mark("r0")
         if refine:
-            xo, fo, ne, rounds = ctx.refine_device(self.tables, res["pt_surf"], start, res["th"], self.del_alpha)
+            if len(self.theta) > 2050:
+                # ibs_refine_f64 holds the register-resident evaluation kernel (N <= 2050): beyond, the same L-BFGS-B state machines
+                # run on the host (ibs_lbfgsb2_*) and every round is ONE batched geometry + ibs_obj_w_grad_f64 launch for the
+                # surfaces still running (refine_batched: the form refine_device is tested against)
+                xh, fh, rounds = self.refine_batched(start.cpu().numpy())
+                xo = torch.from_numpy(xh).to(dev); ne = None
+            else:
+                xo, fo, ne, rounds = ctx.refine_device(self.tables, res["pt_surf"], start, res["th"], self.del_alpha)
             mark("r1")
             xa, xt = xo[:, 0].contiguous(), xo[:, 1].contiguous()
             gf = ctx.fieldline_geometry(self.tables, res["pt_surf"], xa, res["th"], device=dev)

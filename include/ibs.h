@@ -18,8 +18,9 @@
  *     passes 2050 from mpol ntor > 256 on): for 2050 < N <= 65537 ibs_solve_gcf_f64 / _f32, ibs_solve_gcfh_f64, ibs_gamma_scan_f64 /
  *     _warm_f64 (the guesses are then unused) / _argmax_f64, ibs_gamma_points_f64, ibs_obj_w_grad_f64 and ibs_sturm_count_f64 run a
  *     generic path that works in division form on the rows in memory (csrc/ibs_long.hip: correct to the same tolerances, slower per
- *     row); the batched on-device refinement ibs_refine_f64 stays limited to N <= 2050 (IBS_ERR_UNSUPPORTED): beyond, the drop-in
- *     obj_w_grad under the caller's own optimizer, as upstream (ball_scan.py:307-314), is the way.
+ *     row); the on-device refinement ibs_refine_f64 stays limited to N <= 2050 (IBS_ERR_UNSUPPORTED): beyond, ibs_obj_w_grad_f64
+ *     under the caller's optimizer -- upstream's own form (ball_scan.py:307-314); the Python host layer drives the library's
+ *     L-BFGS-B state machines (ibs_lbfgsb2_*) with one batched ibs_obj_w_grad_f64 launch per round.
  *   - optional outputs may be NULL.
  *   - info word per system: bits 0..15 = sweeps used, bits 16.. = status
  *     (bit 0 = iteration cap hit, bit 1 = invalid data: non-finite, g <= 0 or f <= 0.  Bits 2-4 are INFORMATIONAL -- the returned

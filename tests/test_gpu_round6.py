@@ -407,6 +407,29 @@ def test_large_grid_scan_driver_end_to_end(ctx):
     assert np.abs(tg - tc).max() < 1e-4 and np.abs(ag - ac).max() < 1e-4
 
 
+def test_large_grid_resident_scan_from_wout_tables(ctx):
+    """The HBM-resident worker (geometry from the wout tables of tests/golden/G8, coarse scan with the fused first maximum, start
+    points, refinement, final solve) on a 2561-point grid: the refinement runs the library's L-BFGS-B state machines on the host
+    with ONE batched geometry + ibs_obj_w_grad_f64 launch per round (ibs_refine_f64 holds the register-resident evaluation
+    kernel, N <= 2050) and reaches the stopping point of the per-surface scipy path of ball_scan.py:307-314."""
+    import torch
+    import ibs_amd
+    G = os.path.join(ROOT, "tests", "golden")
+    wout = dict(np.load(os.path.join(G, "G8_wout_ncsx_op.npz")))
+    svals = np.array([0.6, 0.9])
+    tabs = ibs_amd.SurfaceTables.from_wout(wout, svals)
+    th = np.linspace(-4 * np.pi, 4 * np.pi, 2561)
+    scan = ibs_amd.BallooningScan(ctx, None, th, svals, nalpha=8, ntheta0=5, tables=tabs, device=torch.device("cuda:0"))
+    t0, al, gam = scan.run()
+    assert np.isfinite(gam).all() and scan.last_refine["rounds"] >= 2
+    tabs_c = scan.coarse()
+    for k, s_ in enumerate(svals):
+        a0, th0 = ibs_amd.pick_start(tabs_c[k], scan.alpha_scan, scan.theta0_scan)[:2]
+        t_opt, a_opt, gam_opt, res = scan.refine(s_, a0, th0)
+        assert gam[k] >= tabs_c[k].max() - 1e-9
+        assert abs(gam[k] - gam_opt) < 1e-8, (k, gam[k], gam_opt)
+
+
 # ---------------------------------------------------------------------------------------------- nearest-sigma report
 def test_nearest_sigma_divergence_is_reported(ctx):
     """utils.py:1597 takes the eigenpair NEAREST sigma0 (ARPACK shift-invert); the drop-in always takes lam_max.  A strongly driven
