@@ -430,6 +430,32 @@ def test_large_grid_resident_scan_from_wout_tables(ctx):
         assert abs(gam[k] - gam_opt) < 1e-8, (k, gam[k], gam_opt)
 
 
+def test_large_grid_adjoint_step_against_the_oracle_pipeline(ctx):
+    """One optimizer iteration of the reference's workflow (sims_runner_NCSX.py:249-261: equilibria x surfaces -> refined maxima ->
+    objective and gradient) on a 2561-point grid: AdjointStep.run() with two emulated equilibria, every (equilibrium, surface)
+    pair against the oracle on every link (tests/helpers.py: numpy geometry, C-oracle scan, scipy's L-BFGS-B on the oracle
+    objective, oracle final solve)."""
+    import torch
+    import ibs_amd
+    import bench
+    from tests.helpers import oracle_surface_pipeline
+    dev = torch.device("cuda:0")
+    wout0 = dict(np.load(os.path.join(ROOT, "tests", "golden", "G8_wout_ncsx_op.npz")))
+    wouts, steps, x0 = bench.emulated_equilibria(wout0)
+    wouts, steps = wouts[:2], steps[:1]
+    svals = np.array([0.6, 0.9])
+    na, nt0 = 6, 4
+    th = np.linspace(-4 * np.pi, 4 * np.pi, 2561)
+    step = ibs_amd.AdjointStep(ctx, th, svals, dev, nalpha=na, ntheta0=nt0, gamma_thresh=-2.0e-4, prefac=50.0)
+    out = step.run(wouts, 0.8 + 0.01 * np.arange(2), steps)
+    gam = out["gam"]
+    assert gam.shape == (2, 2) and np.isfinite(gam).all() and np.isfinite(out["dfobj"]).all()
+    for q in range(2):
+        for js in range(2):
+            ref = oracle_surface_pipeline(wouts[q], float(svals[js]), th, na, nt0, step.del_alpha)
+            assert abs(ref["gam"] - gam[q, js]) < 1e-8, (q, js, ref["gam"], gam[q, js])
+
+
 # ---------------------------------------------------------------------------------------------- nearest-sigma report
 def test_nearest_sigma_divergence_is_reported(ctx):
     """utils.py:1597 takes the eigenpair NEAREST sigma0 (ARPACK shift-invert); the drop-in always takes lam_max.  A strongly driven
