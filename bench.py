@@ -240,7 +240,7 @@ def _strip_prose(d, limit=90):
 
 
 # what may be dropped, first to last, if a line is still over the limit (it never is with today's legs: the test pins 6,000)
-_DROP_ORDER = ("batch_scaling", "warm_rescan", "gather_modes", "dropin_call_us", "sturm_sweep", "scan_large", "stress_rough",
+_DROP_ORDER = ("batch_scaling", "warm_rescan", "gather_modes", "dropin_call_us", "long_grid", "sturm_sweep", "scan_large", "stress_rough",
                "reference_batch", "ncsx_c3", "c5_matrix", "ncsx_c2_sharded_native", "cpu_reference_cost")
 
 
@@ -529,6 +529,41 @@ def sturm_sweep(ctx, device, n_sys, reps=5):
                 division_form=dict(kernel=kern_d, ms_per_launch=ms_d, gb_per_s=n_sys * bytes_per / (ms_d * 1e6),
                                    frac_of_8_tb_s=n_sys * bytes_per / (ms_d * 1e6) / 8000.0,
                                    counts_equal_the_sweeps=bool(torch.equal(cnt_p, cnt_d))))
+
+
+def long_grid(ctx, device, N=4097, n_batch=2048, oracle_check=True):
+    """grids beyond the register-resident kernels (csrc/ibs_long.hip; the reference's grid rule passes 2,050 points from
+    mpol ntor > 256 on): s-alpha systems at N = 4,097 -- one system with its growth rate (latency), a batch (rate), and a sample
+    against the C oracle"""
+    import torch
+    th = np.linspace(-4 * np.pi, 4 * np.pi, N); h = float(th[1] - th[0])
+    rng = np.random.default_rng(N)
+    sh, al, t0 = rng.uniform(0.1, 2.0, (n_batch, 1)), rng.uniform(0.0, 1.2, (n_batch, 1)), rng.uniform(0.0, np.pi / 2, (n_batch, 1))
+    lam = sh * (th[None] - t0) - al * (np.sin(th)[None] - np.sin(t0))
+    g = torch.from_numpy(1 + lam ** 2).to(device); c = torch.from_numpy(al * (np.cos(th)[None] + np.sin(th)[None] * lam)).to(device)
+    f = g.clone()
+    out = dict(workload="s-alpha systems, N = %d, f64: one system / %d systems per call, growth rate wanted" % (N, n_batch))
+    for name, sl in (("one", slice(0, 1)), ("batch", slice(0, n_batch))):
+        gg, cc, ff = g[sl], c[sl], f[sl]
+        r = ctx.solve_gcf(h, gg, cc, ff, want_info=True); torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for a, b in evs:
+            a.record(); ctx.solve_gcf(h, gg, cc, ff); b.record()
+        torch.cuda.synchronize()
+        ms = float(min(a.elapsed_time(b) for a, b in evs))
+        if name == "one":
+            out["one_system_ms"] = ms
+        else:
+            out["batch_systems_per_s"] = n_batch / (ms * 1e-3); out["batch_ms"] = ms
+            out["kernel"] = ctx.last_launch()[0]
+            out["passes_mean"] = float((r["info"] & 0xffff).double().mean().item())
+            out["flagged"] = int(((r["info"] >> 16) != 0).sum().item())
+            if oracle_check:
+                from oracle import c_oracle as co
+                gam_c, lam_c, _ = co.solve_gcf_batch(h, gg[:8].cpu().numpy(), cc[:8].cpu().numpy(), ff[:8].cpu().numpy())
+                out["max_abs_dgam_vs_oracle"] = float(np.abs(r["gam"][:8].cpu().numpy() - gam_c).max())
+                out["parity_ok"] = bool(out["max_abs_dgam_vs_oracle"] < 1e-8 and out["flagged"] == 0)
+    return out
 
 
 def warm_rescan(ctx, device, h, geo7, dP_d, th0_d, reps=20):
@@ -1491,6 +1526,9 @@ def main():
             out["batch_scaling"] = batch_scaling(ctx, device, h, geo7, dP_d, th0_d)
             out.update(ncsx_pipeline(ctx, device))
             out["dropin_call_us"] = dropin_call(ctx)
+            out["long_grid"] = long_grid(ctx, device, oracle_check=not args.no_cpu)
+            if out["long_grid"].get("parity_ok") is False:
+                rc = 3
             out["c4_adjoint_step"] = c4_adjoint_step(ctx, device, n_oracle=0 if args.no_cpu else 4)
             if out["c4_adjoint_step"].get("parity_ok") is False:
                 rc = 3
